@@ -1,0 +1,72 @@
+import json
+import pathlib
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+GOLDEN = pathlib.Path(__file__).resolve().parent / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def rust_vectors():
+    return json.loads((GOLDEN / "rust_unit_vectors.json").read_text())
+
+
+@pytest.fixture(scope="session")
+def mash_vectors():
+    return json.loads((GOLDEN / "mash_distance_vectors.json").read_text())
+
+
+# cogent3 DNA alphabet order T,C,A,G (diverse_seq/util.py:41-45; tests/test_util.py:9-16)
+_DNA = np.full(256, 4, dtype=np.uint8)
+for _i, _c in enumerate("TCAG"):
+    _DNA[ord(_c)] = _i
+    _DNA[ord(_c.lower())] = _i
+_DNA[ord("U")] = 0
+_DNA[ord("u")] = 0
+
+
+def str2arr(seq: str) -> np.ndarray:
+    return _DNA[np.frombuffer(seq.encode(), dtype=np.uint8)]
+
+
+def read_fasta(path) -> dict:
+    seqs, name, chunks = {}, None, []
+    for line in pathlib.Path(path).read_text().splitlines():
+        if line.startswith(">"):
+            if name is not None:
+                seqs[name] = "".join(chunks)
+            name, chunks = line[1:].strip().split()[0], []
+        elif line.strip():
+            chunks.append(line.strip())
+    if name is not None:
+        seqs[name] = "".join(chunks)
+    return seqs
+
+
+@pytest.fixture(scope="session")
+def brca1():
+    """{name: uint8 codes} of the degapped BRCA1 demo alignment (config C1)"""
+    raw = read_fasta(GOLDEN / "brca1.fasta")
+    return {n: str2arr(s.replace("-", "").replace("?", "")) for n, s in raw.items()}
+
+
+def synth_seqs(nseq, length, seed, invalid_frac=0.0, ragged=False):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(nseq):
+        n = int(rng.integers(max(1, length // 2), length + 1)) if ragged else length
+        s = rng.integers(0, 4, size=n, dtype=np.uint8)
+        if invalid_frac:
+            s[rng.random(n) < invalid_frac] = 4
+        out.append(s)
+    return out
