@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Headline benchmark: sequences scored/sec for the greedy delta-JSD selection
+(`dvs nmost`) at k=6 on synthetic DNA, inputs resident in HBM.
+
+One "step" = one full pass of the hot path over one batch: k-mer histogram build
+(N x 4^k uint32 count matrix) + the windowed delta-JSD scan + every set update,
+for N sequences per GPU.  With --gpus G > 1 (launched by torch.distributed.run,
+one process per GPU) each rank owns a contiguous shard of the sequences and runs
+the greedy on it -- the reference's own `-np G` scheme (diverse_seq/records.py:
+225-245, diverse_seq/util.py:82-102) -- then the G*n winners' frequency rows are
+exchanged with ONE RCCL all_gather and merged with the reference's final_nmost
+(src/records.rs:363-382) on the device.  Work per GPU is fixed: weak scaling.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nseq", type=int, default=100_000, help="sequences per GPU")
+    ap.add_argument("--length", type=int, default=5_000)
+    ap.add_argument("-k", type=int, default=6)
+    ap.add_argument("-n", type=int, default=10, help="size of the divergent set")
+    ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=100_000,
+                    help="sequences of the same workload the 1-thread CPU oracle is timed on")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from diverseseq_amd import engine
+    from diverseseq_amd.parallel import merge_nmost
+
+    ctx = engine.Context(local)
+    B = 4 ** a.k
+    # synthetic input, generated in HBM: i.i.d. uniform symbols, 1 byte per base
+    g = torch.Generator(device=dev)
+    g.manual_seed(20260421 + rank)
+    seqs = torch.randint(0, 4, (a.nseq * a.length,), dtype=torch.uint8, device=dev, generator=g)
+    offsets = np.arange(a.nseq + 1, dtype=np.uint64) * np.uint64(a.length)
+    torch.cuda.synchronize()
+
+    stats = {"rows_scored": 0, "scan_ms": 0.0, "scan_launches": 0, "n_accepts": 0,
+             "n_windows": 0, "n_arbitrated": 0, "hist_ms": 0.0}
+
+    def step(collect: bool):
+        t0 = time.perf_counter()
+        m = ctx.build_matrix_device(seqs.data_ptr(), offsets, a.k, 4)
+        t1 = time.perf_counter()
+        sel = m.nmost(a.n, window=a.window)
+        if world > 1:
+            merged = merge_nmost(ctx, sel, a.n, rank, world, rank * a.nseq, dev)
+            merged.close()
+        if collect:
+            s = sel.summary()
+            for key in ("rows_scored", "scan_ms", "scan_launches", "n_accepts", "n_windows",
+                        "n_arbitrated"):
+                stats[key] += getattr(s, key)
+            stats["hist_ms"] += (t1 - t0) * 1e3
+        sel.close()
+        m.close()
+
+    for _ in range(a.warmup):
+        step(False)
+    ctx.set_timing(True)  # HIP-event pairs around every scan launch, read after the run
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    ctx.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_seqs = a.nseq * world * a.steps
+        scan_s = stats["scan_ms"] / 1e3
+        alg_bytes = stats["rows_scored"] * B * 4  # rows scored x 4^k x sizeof(u32)
+        achieved = alg_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
+        peak = 8000.0  # GB/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
+        out = {
+            "metric": "sequences scored/sec (delta-JSD, k=6)",
+            "value": total_seqs / elapsed,
+            "unit": "sequences/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": (f"dvs nmost n={a.n}: k-mer histogram + greedy delta-JSD scan + set updates over "
+                             f"{a.nseq} x {a.length} bp synthetic DNA per GPU, k={a.k} ({B} bins), "
+                             "inputs resident in HBM (north-star shape)"),
+                "nseq_per_gpu": a.nseq, "length": a.length, "k": a.k, "n": a.n,
+                "parallelism": (f"{world} shards, independent greedy per GPU + one RCCL all_gather "
+                                "+ final_nmost merge (reference -np semantics)") if world > 1 else "single GPU",
+                "accepts_per_step": stats["n_accepts"] / a.steps,
+                "scan_launches_per_step": stats["scan_launches"] / a.steps,
+                "rows_scored_per_step": stats["rows_scored"] / a.steps,
+                "hist_ms_per_step": stats["hist_ms"] / a.steps,
+                "scan_ms_per_step": stats["scan_ms"] / a.steps,
+                "tie_arbitrations": stats["n_arbitrated"],
+            },
+            "roofline": {
+                "kernel": "scan_kernel<uint32>",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": peak,
+                "unit": "GB/s",
+                "frac": achieved / peak,
+                "traffic": None,
+                "bytes_per_launch": alg_bytes / max(1, stats["scan_launches"]),
+                "avg_launch_us": stats["scan_ms"] * 1e3 / max(1, stats["scan_launches"]),
+            },
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            import oracle
+
+            ns = min(a.cpu_sample, a.nseq)
+            host = seqs[: ns * a.length].cpu().numpy()
+            t0 = time.perf_counter()
+            oracle.nmost_concat(host, offsets[: ns + 1], a.n, a.k, 4)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {
+                "value": ns / dt, "unit": "sequences/s", "cores": 1, "kind": "port",
+                "sample": (f"the first {ns} sequences of the same workload, 1 thread, C restatement of the "
+                           "Rust path (oracle/dvs_oracle.c), data in RAM"),
+            }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    main()

@@ -1,0 +1,347 @@
+"""Drop-in for the reference's PyO3 extension module ``diverse_seq._dvs``.
+
+Same names, keyword arguments, return attributes and exception types as the
+functions/classes registered in the reference's ``src/lib.rs:175-189``; the
+arithmetic runs in libdvs_hip.so (HIP kernels for gfx950) through ctypes.
+
+    reference                                     here
+    ---------                                     ----
+    make_zarr_store(path=None, mode="r")          in-memory store (on-disk .dvseqsz: SURVEY 8f, next)
+    get_seqids_from_store(path)                   NotImplementedError (storage engine, out of scope)
+    nmost_divergent / final_nmost                 dvs_select_run MODE_NMOST
+    max_divergent / final_max                     dvs_select_run MODE_MAX
+    get_delta_jsd_calculator                      dvs_select_run MODE_SET + dvs_select_delta_jsd
+    mash_sketch                                   dvs_mash_sketch
+    SummedRecordsResult, LazySeq, ZarrStoreWrapper python classes with the same attributes
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib, engine
+
+__all__ = [
+    "LazySeq", "SummedRecordsResult", "ZarrStoreWrapper", "final_max", "final_nmost",
+    "get_delta_jsd_calculator", "get_seqids_from_store", "make_zarr_store", "mash_sketch",
+    "max_divergent", "nmost_divergent",
+]
+
+
+# --------------------------------------------------------------------- classes
+class SummedRecordsResult:
+    """src/records_py.rs:7-88: read-only result of a selection, picklable"""
+
+    __slots__ = ("total_jsd", "records", "mean_delta_jsd", "std_delta_jsd", "cov_delta_jsd",
+                 "size", "k", "num_states", "stats")
+
+    def __init__(self):
+        self.total_jsd = 0.0
+        self.records: list[tuple[str, list[float], float]] = []
+        self.mean_delta_jsd = 0.0
+        self.std_delta_jsd = 0.0
+        self.cov_delta_jsd = 0.0
+        self.size = 0
+        self.k = 0
+        self.num_states = 0
+        self.stats = None  # engine statistics (not part of the reference's object)
+
+    @property
+    def record_names(self) -> list[str]:
+        return [r[0] for r in self.records]
+
+    def __getstate__(self) -> dict:
+        return {n: getattr(self, n) for n in ("total_jsd", "records", "mean_delta_jsd",
+                                              "std_delta_jsd", "cov_delta_jsd", "size", "k",
+                                              "num_states")}
+
+    def __setstate__(self, state: dict) -> None:
+        for n in ("total_jsd", "records", "mean_delta_jsd", "std_delta_jsd", "cov_delta_jsd",
+                  "size", "k", "num_states"):
+            setattr(self, n, state[n])  # KeyError on a missing field, as the reference
+        self.stats = None
+
+    def __repr__(self):
+        return f"SummedRecordsResult(size={self.size}, total_jsd={self.total_jsd})"
+
+
+class ZarrStoreWrapper:
+    """In-memory sequence store with the python face of src/zarr_py.rs:9-247.
+
+    Sequences are deduplicated by content: ``unique_seqids`` holds one id per
+    distinct sequence, the last one written (src/zarr_io.rs:376-384;
+    reference tests/test_zarr_store.py:48-61).  The reference returns ids in
+    FxHashMap iteration order; here it is insertion order (parity is defined on
+    "same ordered seqids in -> same ids out", SURVEY.md hard part 6).
+    """
+
+
+    def __init__(self, path: str | None = None, mode: str = "r"):
+        if path is not None:
+            raise NotImplementedError(
+                "on-disk .dvseqsz (Zarr v3 + zstd) stores are not part of this build "
+                "(SURVEY.md 8f rank 1); use make_zarr_store() for an in-memory store")
+        self._seqs: dict[str, bytes] = {}
+        self._meta: dict[str, dict] = {}
+        self.source = ""
+
+    def __repr__(self):
+        return f"ZarrStoreWrapper(source='in memory', num members={len(self)})"
+
+    def __contains__(self, key: str) -> bool:
+        return key in self._seqs
+
+    def __len__(self) -> int:
+        return len(self._seqs)
+
+    def __getstate__(self):
+        raise TypeError("Cannot pickle in-memory store")  # src/zarr_py.rs:91-95
+
+    def write(self, seqid: str, seq, metadata: dict | None = None) -> None:
+        data = bytes(seq)
+        if len(data) == 0:
+            raise ValueError(f"Failed to create add {seqid}")
+        if seqid in self._seqs:
+            return  # idempotent per seqid (src/zarr_io.rs:217-219)
+        self._seqs[seqid] = data
+        self._meta[seqid] = dict(metadata) if metadata else {"source": "unknown"}
+
+    def write_log(self, unique_id: str, data: str) -> None:
+        pass
+
+    def write_citations(self, data) -> None:
+        pass
+
+    def read(self, seqid: str) -> bytes:
+        try:
+            return self._seqs[seqid]
+        except KeyError:
+            raise RuntimeError(f"Failed to create add {seqid}") from None
+
+    def read_metadata(self, seqid: str) -> dict:
+        try:
+            return dict(self._meta[seqid])
+        except KeyError:
+            raise RuntimeError(f"Failed to read metadata for {seqid}") from None
+
+    def num_unique(self) -> int:
+        return len(set(self._seqs.values()))
+
+    @property
+    def unique_seqids(self) -> list[str]:
+        last: dict[bytes, str] = {}
+        for sid, data in self._seqs.items():
+            last[data] = sid
+        return list(last.values())
+
+    def get_seqids(self) -> list[str]:
+        return list(self._seqs)
+
+    def get_lazyseq(self, seqid: str, num_states: int) -> "LazySeq":
+        return LazySeq(seqid, self, num_states)
+
+    def get_lazyseqs(self, num_states: int) -> list["LazySeq"]:
+        return [self.get_lazyseq(s, num_states) for s in self._seqs]
+
+
+class LazySeq:
+    """src/record.rs:212-269"""
+
+
+    def __init__(self, seqid: str, storage: ZarrStoreWrapper, num_states: int):
+        self.seqid, self._storage, self.num_states = seqid, storage, num_states
+
+    def __repr__(self):
+        return f"LazySeq(seqid={self.seqid}, num_states={self.num_states}, storage={self._storage!r})"
+
+    def get_seq(self) -> bytes:
+        return self._storage.read(self.seqid)
+
+    def get_kcounts(self, k: int) -> list[int]:
+        counts, _, _ = engine.default_context().kmer_counts([self.get_seq()], k, self.num_states)
+        return counts[0].tolist()
+
+    def get_kfreqs(self, k: int) -> list[float]:
+        counts, totals, _ = engine.default_context().kmer_counts([self.get_seq()], k, self.num_states)
+        # record.rs:256-261: no zero check -> NaN for an all-invalid sequence
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return (counts[0].astype(np.float64) / np.float64(totals[0])).tolist()
+
+
+# ------------------------------------------------------------------- functions
+def make_zarr_store(path: str | None = None, mode: str = "r") -> ZarrStoreWrapper:
+    return ZarrStoreWrapper(path, mode)
+
+
+def get_seqids_from_store(path: str) -> list[str]:
+    raise NotImplementedError("on-disk .dvseqsz stores are not part of this build (SURVEY.md 8f)")
+
+
+def _gather(store: ZarrStoreWrapper, seqids):
+    """stream of sequences for `seqids` + integer identity labels (same id -> same label)"""
+    ids = list(store.unique_seqids) if seqids is None else list(seqids)
+    seqs, labels, label_of = [], [], {}
+    for sid in ids:
+        try:
+            seqs.append(store._seqs[sid])
+        except KeyError:  # read_uint8_array(..).unwrap() panics (src/record.rs:206)
+            raise ValueError(f"sequence {sid!r} not in store") from None
+        labels.append(label_of.setdefault(sid, len(label_of)))
+    return ids, seqs, np.asarray(labels, dtype=np.uint32)
+
+
+def _result(sel: engine.Selection, ids, k: int, num_states: int) -> SummedRecordsResult:
+    s = sel.summary()
+    mem = sel.members(with_freqs=True)
+    r = SummedRecordsResult()
+    r.total_jsd = s.total_jsd
+    r.mean_delta_jsd = s.mean_delta_jsd
+    r.std_delta_jsd = s.std_delta_jsd
+    r.cov_delta_jsd = s.cov_delta_jsd
+    r.size = int(s.size)
+    r.k, r.num_states = k, num_states
+    r.records = [(ids[int(p)], mem.kfreqs[i].tolist(), float(mem.delta_jsd[i]))
+                 for i, p in enumerate(mem.positions)]
+    r.stats = {n: getattr(s, n) for n in ("rows_scored", "rows_rechecked", "n_windows", "n_events",
+                                          "n_accepts", "n_arbitrated", "scan_ms", "scan_launches")}
+    return r
+
+
+def _check_k(k: int):
+    if k == 0:
+        raise ValueError("k cannot be 0")  # src/record.rs:126
+
+
+def nmost_divergent(store: ZarrStoreWrapper, n: int, k: int, num_states: int = 4,
+                    seqids=None) -> SummedRecordsResult:
+    """src/lib.rs:59-73 -> select_nmost_divergent (src/records.rs:311-342)"""
+    ids, seqs, labels = _gather(store, seqids)
+    if len(ids) < n:
+        raise ValueError(f"The number of sequences {len(ids)} is < n {n}")
+    _check_k(k)
+    ctx = engine.default_context()
+    m = ctx.build_matrix(seqs, k, num_states)
+    try:
+        sel = m.nmost(n, labels=labels)
+        try:
+            return _result(sel, ids, k, num_states)
+        finally:
+            sel.close()
+    finally:
+        m.close()
+
+
+def max_divergent(store: ZarrStoreWrapper, min_size: int, max_size: int, k: int,
+                  num_states: int = 4, seqids=None, stat: str = "stdev") -> SummedRecordsResult:
+    """src/lib.rs:105-137 -> select_max_divergent (src/records.rs:390-454)"""
+    ids, seqs, labels = _gather(store, seqids)
+    if len(ids) < min_size:
+        raise ValueError(f"The number of sequences {len(ids)} is < n {min_size}")
+    _check_k(k)
+    ctx = engine.default_context()
+    m = ctx.build_matrix(seqs, k, num_states)
+    try:
+        sel = m.max_divergent(min_size, max_size, stat, labels=labels)
+        try:
+            return _result(sel, ids, k, num_states)
+        finally:
+            sel.close()
+    finally:
+        m.close()
+
+
+def _merge_inputs(records):
+    """get_kmerseqs_and_init_summed_records (src/records.rs:344-360): concatenate the member
+    rows of every result in list order; NB k / num_states come back swapped (:353)."""
+    ids, rows, labels, label_of = [], [], [], {}
+    for sr in records:
+        for sid, kfreqs, _ in sr.records:
+            ids.append(sid)
+            rows.append(kfreqs)
+            labels.append(label_of.setdefault(sid, len(label_of)))
+    first = records[0] if records else None
+    k, ns = (first.num_states, first.k) if first is not None else (0, 0)
+    return ids, rows, np.asarray(labels, dtype=np.uint32), k, ns
+
+
+def final_nmost(records: list[SummedRecordsResult], n: int) -> SummedRecordsResult:
+    """src/lib.rs:95-103 -> select_nmost_divergent_final (src/records.rs:363-382)"""
+    ids, rows, labels, k, ns = _merge_inputs(records)
+    if len(ids) < n:
+        raise ValueError(f"The number of sequences {len(ids)} is < n {n}")
+    if not ids:
+        raise ValueError("records cannot be empty")
+    ctx = engine.default_context()
+    m = ctx.matrix_from_freqs(np.asarray(rows, dtype=np.float64))
+    try:
+        sel = m.nmost(n, labels=labels)
+        try:
+            return _result(sel, ids, k, ns)
+        finally:
+            sel.close()
+    finally:
+        m.close()
+
+
+def final_max(records: list[SummedRecordsResult], min_size: int, max_size: int,
+              stat: str = "stdev") -> SummedRecordsResult:
+    """src/lib.rs:139-160 -> select_max_divergent_final (src/records.rs:456-507)"""
+    ids, rows, labels, k, ns = _merge_inputs(records)
+    if len(ids) < min_size:
+        raise ValueError(f"The number of sequences {len(ids)} is < n {min_size}")
+    if not ids:
+        raise ValueError("records cannot be empty")
+    ctx = engine.default_context()
+    m = ctx.matrix_from_freqs(np.asarray(rows, dtype=np.float64))
+    try:
+        sel = m.max_divergent(min_size, max_size, stat, labels=labels)
+        try:
+            return _result(sel, ids, k, ns)
+        finally:
+            sel.close()
+    finally:
+        m.close()
+
+
+class SummedRecordsWrapper:
+    """src/records_py.rs:90-125: stateful delta-JSD calculator"""
+
+
+    def __init__(self, records, k: int, num_states: int = 4):
+        _check_k(k)
+        self._k, self._num_states = k, num_states
+        self._ctx = engine.default_context()
+        self._ids = [sid for sid, _ in records]
+        label_of: dict[str, int] = {}
+        labels = np.asarray([label_of.setdefault(sid, len(label_of)) for sid in self._ids],
+                            dtype=np.uint32)
+        self._label_of = label_of
+        self._matrix = self._ctx.build_matrix([seq for _, seq in records], k, num_states)
+        self._sel = self._matrix.as_set(labels=labels)  # make_summed_records, records.rs:509-524
+
+    def delta_jsd(self, seqid: str, seq) -> float:
+        q = self._ctx.build_matrix([bytes(seq)], self._k, self._num_states)
+        try:
+            if int(q.totals()[0]) == 0:
+                raise ValueError(f"delta_jsd('{seqid}') failed: No valid k-mers for '{seqid}'")
+            lab = self._label_of.get(seqid, 0xFFFFFFFF)
+            return float(self._sel.delta_jsd(q, [lab])[0])
+        finally:
+            q.close()
+
+    def get_result(self) -> SummedRecordsResult:
+        return _result(self._sel, self._ids, self._k, self._num_states)
+
+
+def get_delta_jsd_calculator(seqids_seqs, k: int, num_states: int = 4) -> SummedRecordsWrapper:
+    """src/lib.rs:162-171"""
+    return SummedRecordsWrapper(list(seqids_seqs), k, num_states)
+
+
+def mash_sketch(seq_array, k: int, sketch_size: int, num_states: int = 4,
+                mash_canonical: bool = False) -> list[int]:
+    """src/distance.rs:136-182"""
+    from .distance import sketch_batch
+
+    sk, lens = sketch_batch([bytes(seq_array)], k, sketch_size, num_states, mash_canonical)
+    return sk[0, : int(lens[0])].tolist()

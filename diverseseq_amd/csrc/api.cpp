@@ -1,0 +1,292 @@
+// Context, errors, matrix build / accessors of the C ABI (include/dvs_hip.h).
+#include "dvs_internal.h"
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+uint64_t dvs_pow_u64(uint32_t base, uint32_t exp, bool *overflow);
+void dvs_matrix_free_fields(dvs_matrix *m);
+int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs, uint64_t nbytes,
+                           const uint64_t *offsets);
+int dvs_matrix_fill_freq_entropy(dvs_ctx *ctx, dvs_matrix *m);
+
+static std::string g_create_err;
+
+int dvs_set_error(dvs_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_err = buf;
+    return code;
+}
+
+int dvs_hip_fail(dvs_ctx *ctx, hipError_t e, const char *what) {
+    (void)hipGetLastError();  // clear the sticky error
+    const int code = (e == hipErrorOutOfMemory) ? DVS_ERR_NOMEM : DVS_ERR_RUNTIME;
+    return dvs_set_error(ctx, code, "HIP error %d (%s) in %s", int(e), hipGetErrorString(e), what);
+}
+
+extern "C" {
+
+int dvs_abi_version(void) { return DVS_ABI_VERSION; }
+
+int dvs_ctx_create(int device, void *stream, dvs_ctx **out) {
+    if (!out) return dvs_set_error(nullptr, DVS_ERR_VALUE, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return dvs_set_error(nullptr, DVS_ERR_RUNTIME,
+                             "no HIP device available (%s): libdvs_hip has no CPU fallback",
+                             e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0) {
+        e = hipGetDevice(&device);
+        if (e != hipSuccess) return dvs_hip_fail(nullptr, e, "hipGetDevice");
+    }
+    if (device >= ndev)
+        return dvs_set_error(nullptr, DVS_ERR_VALUE, "device %d out of range (%d devices)", device, ndev);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return dvs_hip_fail(nullptr, e, "hipSetDevice");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return dvs_hip_fail(nullptr, e, "hipGetDeviceProperties");
+    dvs_ctx *ctx = new dvs_ctx();
+    ctx->device = device;
+    ctx->n_cu = prop.multiProcessorCount;
+    ctx->lds_per_block = prop.sharedMemPerBlockOptin ? prop.sharedMemPerBlockOptin
+                                                     : prop.sharedMemPerBlock;
+    if (ctx->lds_per_block < prop.sharedMemPerBlock) ctx->lds_per_block = prop.sharedMemPerBlock;
+    if (stream) {
+        ctx->stream = static_cast<hipStream_t>(stream);
+    } else {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            return dvs_hip_fail(nullptr, e, "hipStreamCreate");
+        }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return DVS_OK;
+}
+
+void dvs_ctx_destroy(dvs_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *dvs_last_error(const dvs_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int dvs_ctx_sync(dvs_ctx *ctx) {
+    if (!ctx) return DVS_ERR_VALUE;
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DVS_OK;
+}
+
+int dvs_ctx_set_timing(dvs_ctx *ctx, int on) {
+    if (!ctx) return DVS_ERR_VALUE;
+    ctx->timing = on != 0;
+    return DVS_OK;
+}
+
+int dvs_ctx_device_info(dvs_ctx *ctx, char *name, size_t name_len, int *n_cu, uint64_t *hbm_bytes) {
+    if (!ctx) return DVS_ERR_VALUE;
+    hipDeviceProp_t prop;
+    DVS_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_len) {
+        snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return DVS_OK;
+}
+
+static int matrix_alloc(dvs_ctx *ctx, dvs_matrix *m) {
+    const size_t cells = size_t(m->nrows) * m->nbins;
+    const size_t bytes = cells * (m->kind == 0 ? 4 : 8);
+    size_t free_b = 0, total_b = 0;
+    DVS_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+    if (bytes + size_t(m->nrows) * 12 + (64u << 20) > free_b)
+        return dvs_set_error(ctx, DVS_ERR_NOMEM,
+                             "%u x %llu matrix needs %zu bytes of HBM, %zu free", m->nrows,
+                             (unsigned long long)m->nbins, bytes, free_b);
+    const size_t nr = m->nrows ? m->nrows : 1;
+    if (m->kind == 0) DVS_HIP(ctx, hipMalloc(&m->d_counts, bytes ? bytes : 4));
+    else DVS_HIP(ctx, hipMalloc(&m->d_freqs, bytes ? bytes : 8));
+    DVS_HIP(ctx, hipMalloc(&m->d_totals, nr * 4));
+    DVS_HIP(ctx, hipMalloc(&m->d_entropy, nr * 8));
+    return DVS_OK;
+}
+
+int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, const uint64_t *offsets,
+                     uint32_t nseq, uint32_t k, uint32_t num_states, dvs_matrix **out) {
+    if (!ctx || !offsets || !out || (!seqs && nseq && offsets[nseq] > 0))
+        return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    *out = nullptr;
+    if (k == 0) return dvs_set_error(ctx, DVS_ERR_VALUE, "k cannot be 0");  // record.rs:126
+    if (num_states < 1 || num_states > 255)
+        return dvs_set_error(ctx, DVS_ERR_VALUE, "num_states %u outside 1..255", num_states);
+    if (k > 17) return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "k = %u > 17 is not supported", k);
+    bool ovf = false;
+    const uint64_t B = dvs_pow_u64(num_states, k, &ovf);
+    if (ovf || B > (1ull << 32))
+        return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "%u^%u bins do not fit a dense count row",
+                             num_states, k);
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    dvs_matrix *m = new dvs_matrix();
+    m->kind = 0;
+    m->nrows = nseq;
+    m->nbins = B;
+    m->k = k;
+    m->num_states = num_states;
+    m->device = ctx->device;
+    int rc = matrix_alloc(ctx, m);
+    if (rc) {
+        dvs_matrix_free_fields(m);
+        delete m;
+        return rc;
+    }
+    const uint64_t nbytes = nseq ? offsets[nseq] : 0;
+    uint8_t *d_tmp = nullptr;
+    const uint8_t *d_seqs = seqs;
+    uint64_t readable = nbytes;
+    if (!seqs_on_device) {
+        const uint64_t padded = ((nbytes + 15) & ~15ull) + 16;
+        hipError_t e = hipMalloc(&d_tmp, padded);
+        if (e != hipSuccess) {
+            dvs_matrix_free_fields(m);
+            delete m;
+            return dvs_hip_fail(ctx, e, "hipMalloc(sequences)");
+        }
+        (void)hipMemsetAsync(d_tmp + (nbytes & ~15ull), 0xFF, padded - (nbytes & ~15ull), ctx->stream);
+        if (nbytes)
+            (void)hipMemcpyAsync(d_tmp, seqs, nbytes, hipMemcpyHostToDevice, ctx->stream);
+        d_seqs = d_tmp;
+        readable = padded;
+    } else if (reinterpret_cast<uintptr_t>(seqs) & 15) {
+        dvs_matrix_free_fields(m);
+        delete m;
+        return dvs_set_error(ctx, DVS_ERR_VALUE, "device sequence buffer must be 16-byte aligned");
+    }
+    rc = nseq ? dvs_matrix_fill_counts(ctx, m, d_seqs, seqs_on_device ? nbytes : readable, offsets)
+              : DVS_OK;
+    if (d_tmp) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_tmp);
+    }
+    if (rc) {
+        dvs_matrix_free_fields(m);
+        delete m;
+        return rc;
+    }
+    *out = m;
+    return DVS_OK;
+}
+
+int dvs_matrix_from_freqs(dvs_ctx *ctx, const double *freqs, uint32_t nrows, uint64_t nbins,
+                          dvs_matrix **out) {
+    if (!ctx || !out || (!freqs && nrows)) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    *out = nullptr;
+    if (nbins == 0)  // record.rs:87-89
+        return dvs_set_error(ctx, DVS_ERR_VALUE, "cannot calculate entropy as frequency vector empty");
+    // KmerSeq::new -> entropy(): sum over the non-zero bins, in order, must be within
+    // len * eps of 1 (record.rs:90-104).  Exact on the host: plain sequential adds.
+    const double tol = double(nbins) * DVS_EPS;
+    for (uint32_t r = 0; r < nrows; r++) {
+        const double *row = freqs + uint64_t(r) * nbins;
+        double tot = 0.0;
+        for (uint64_t i = 0; i < nbins; i++)
+            if (row[i] != 0.0) tot += row[i];
+        if (!(std::fabs(tot - 1.0) <= tol))
+            return dvs_set_error(ctx, DVS_ERR_VALUE,
+                                 "cannot calculate entropy as frequency vector total %.17g!=1.0", tot);
+    }
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    dvs_matrix *m = new dvs_matrix();
+    m->kind = 1;
+    m->nrows = nrows;
+    m->nbins = nbins;
+    m->device = ctx->device;
+    int rc = matrix_alloc(ctx, m);
+    if (!rc && nrows) {
+        std::vector<uint32_t> ones(nrows, 1u);
+        hipError_t e = hipMemcpyAsync(m->d_freqs, freqs, size_t(nrows) * nbins * 8,
+                                      hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(m->d_totals, ones.data(), size_t(nrows) * 4, hipMemcpyHostToDevice,
+                               ctx->stream);
+        if (e != hipSuccess) rc = dvs_hip_fail(ctx, e, "hipMemcpyAsync(freqs)");
+        if (!rc) rc = dvs_matrix_fill_freq_entropy(ctx, m);
+        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = dvs_set_error(ctx, DVS_ERR_RUNTIME, "stream sync failed");
+    }
+    if (rc) {
+        dvs_matrix_free_fields(m);
+        delete m;
+        return rc;
+    }
+    *out = m;
+    return DVS_OK;
+}
+
+void dvs_matrix_destroy(dvs_matrix *m) {
+    if (!m) return;
+    dvs_matrix_free_fields(m);
+    delete m;
+}
+
+uint32_t dvs_matrix_nrows(const dvs_matrix *m) { return m ? m->nrows : 0; }
+uint64_t dvs_matrix_nbins(const dvs_matrix *m) { return m ? m->nbins : 0; }
+const void *dvs_matrix_dev_counts(const dvs_matrix *m) { return m ? m->d_counts : nullptr; }
+const void *dvs_matrix_dev_totals(const dvs_matrix *m) { return m ? m->d_totals : nullptr; }
+const void *dvs_matrix_dev_entropy(const dvs_matrix *m) { return m ? m->d_entropy : nullptr; }
+
+int dvs_matrix_get_counts(dvs_ctx *ctx, const dvs_matrix *m, uint32_t row0, uint32_t nrows,
+                          uint32_t *out) {
+    if (!ctx || !m || !out) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (m->kind != 0) return dvs_set_error(ctx, DVS_ERR_VALUE, "not a count matrix");
+    if (uint64_t(row0) + nrows > m->nrows) return dvs_set_error(ctx, DVS_ERR_VALUE, "row range out of bounds");
+    if (!nrows) return DVS_OK;
+    DVS_HIP(ctx, hipMemcpyAsync(out, m->d_counts + uint64_t(row0) * m->nbins,
+                                size_t(nrows) * m->nbins * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DVS_OK;
+}
+
+int dvs_matrix_get_totals(dvs_ctx *ctx, const dvs_matrix *m, uint32_t *out) {
+    if (!ctx || !m || !out) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (!m->nrows) return DVS_OK;
+    DVS_HIP(ctx, hipMemcpyAsync(out, m->d_totals, size_t(m->nrows) * 4, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DVS_OK;
+}
+
+int dvs_matrix_get_entropy(dvs_ctx *ctx, const dvs_matrix *m, double *out) {
+    if (!ctx || !m || !out) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (!m->nrows) return DVS_OK;
+    DVS_HIP(ctx, hipMemcpyAsync(out, m->d_entropy, size_t(m->nrows) * 8, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DVS_OK;
+}
+
+int dvs_kmer_counts(dvs_ctx *ctx, const uint8_t *seqs, const uint64_t *offsets, uint32_t nseq,
+                    uint32_t k, uint32_t num_states, uint32_t *counts_out, uint32_t *totals_out,
+                    double *entropy_out) {
+    dvs_matrix *m = nullptr;
+    int rc = dvs_matrix_build(ctx, seqs, 0, offsets, nseq, k, num_states, &m);
+    if (rc) return rc;
+    if (counts_out) rc = dvs_matrix_get_counts(ctx, m, 0, nseq, counts_out);
+    if (!rc && totals_out) rc = dvs_matrix_get_totals(ctx, m, totals_out);
+    if (!rc && entropy_out) rc = dvs_matrix_get_entropy(ctx, m, entropy_out);
+    dvs_matrix_destroy(m);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// Internal declarations shared by the translation units of libdvs_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/dvs_hip.h"
+
+#define DVS_EPS 2.220446049250313e-16  // f64::EPSILON
+
+struct dvs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cu = 0;
+    size_t lds_per_block = 0;  // max dynamic LDS a block may ask for
+    bool timing = false;
+    std::string err;
+};
+
+int dvs_set_error(dvs_ctx *ctx, int code, const char *fmt, ...);
+int dvs_hip_fail(dvs_ctx *ctx, hipError_t e, const char *what);
+
+#define DVS_HIP(ctx, call)                                        \
+    do {                                                          \
+        hipError_t e__ = (call);                                  \
+        if (e__ != hipSuccess) return dvs_hip_fail(ctx, e__, #call); \
+    } while (0)
+
+// N x B matrix resident in HBM.  kind 0: uint32 counts; kind 1: f64 freqs.
+struct dvs_matrix {
+    int kind = 0;
+    uint32_t nrows = 0;
+    uint64_t nbins = 0;
+    uint32_t k = 0, num_states = 0;
+    uint32_t *d_counts = nullptr;  // kind 0
+    double *d_freqs = nullptr;     // kind 1
+    uint32_t *d_totals = nullptr;  // valid k-mers per row (kind 1: 1 for every row)
+    double *d_entropy = nullptr;   // H(row freq vector), bits
+    int device = 0;
+};
+
+// ---- device helpers -------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ double dvs_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double dvs_wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ unsigned long long dvs_wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// Sum over the block; every thread gets the result.  scratch: >= 17 doubles of LDS.
+// Fixed tree -> the same inputs always give the same bits.
+__device__ __forceinline__ double dvs_block_sum(double v, double *scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwave = (blockDim.x + 63) >> 6;
+    v = dvs_wave_sum(v);
+    __syncthreads();  // scratch may still be read from a previous call
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < nwave; i++) t += scratch[i];
+    return t;
+}
+__device__ __forceinline__ double dvs_block_min(double v, double *scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwave = (blockDim.x + 63) >> 6;
+    v = dvs_wave_min(v);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double t = scratch[0];
+    for (int i = 1; i < nwave; i++) t = fmin(t, scratch[i]);
+    return t;
+}
+#endif

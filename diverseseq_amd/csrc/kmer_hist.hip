@@ -1,0 +1,371 @@
+// k-mer histogram build: sequences (1 byte/base in HBM) -> N x num_states^k
+// uint32 count matrix + per-row total and Shannon entropy.
+//
+// Replaces count_kmers / count_monomers / SeqRecord::to_kcounts / to_kmerseq /
+// entropy of the reference (src/record.rs:31-141).  Semantics restated: bin
+// idx(w) = sum_i w[i] * ns^(k-1-i) is incremented for every length-k window w
+// of the sequence in which every symbol is < num_states (record.rs:47-64 is an
+// incremental way of skipping exactly the windows that contain an invalid
+// symbol; record.rs:72-74 is the rolling form of the same index).
+//
+// Layout / mapping (gfx950):
+//   * one 256-thread workgroup per TILE of k-mer end positions of ONE sequence;
+//     a sequence up to TILE_LEN bases is a single tile and its row is written
+//     once with coalesced 16-B stores; longer sequences (genomes) are split
+//     into tiles whose LDS histograms are merged with global u32 atomics;
+//   * each lane owns 16-byte chunks (global_load_dwordx4, 1 KiB per wave
+//     instruction) plus the previous chunk as the k-1 halo; for num_states == 4
+//     the 32 bases are packed to a 64-bit 2-bit word and a 32-bit invalid mask
+//     with word-wide bit tricks, so every k-mer index is two shifts and a mask
+//     with no serial dependency between positions;
+//   * the histogram lives in LDS (4^k * 4 B: 16 KB at k=6, 64 KB at k=7) and is
+//     filled with ds_add_u32; above 64 KB the row itself (L2-resident) takes the
+//     atomics;
+//   * the row total and entropy are fused into the flush: H = log2 T - (sum c
+//     log2 c)/T, c log2 c from a 256-entry LDS table.
+#include "dvs_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+constexpr int HIST_THREADS = 256;
+constexpr uint32_t TILE_LEN = 32768;  // k-mer end positions per workgroup
+constexpr int CLOG_TBL = 256;
+
+struct KTile {
+    uint64_t begin;      // first k-mer END position (absolute byte offset)
+    uint64_t end;        // one past the last END position
+    uint64_t seq_begin;  // first byte of the sequence
+    uint32_t row;
+    uint32_t single;  // 1: the only tile of its row (plain stores + fused stats)
+};
+
+__device__ __forceinline__ uint4 load16(const uint8_t *base, uint64_t off, uint64_t nbytes) {
+    if (off + 16 <= nbytes) return *reinterpret_cast<const uint4 *>(base + off);
+    uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // invalid filler
+    for (int i = 0; i < 16; i++) {
+        if (off + i < nbytes) {
+            w[i >> 2] &= ~(0xFFu << (8 * (i & 3)));
+            w[i >> 2] |= uint32_t(base[off + i]) << (8 * (i & 3));
+        }
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// 4 bases (little-endian bytes, earliest base in the low byte) -> 8 bits, the
+// earliest base in the TOP two bits.
+__device__ __forceinline__ uint32_t pack4(uint32_t w) {
+    const uint32_t x = w & 0x03030303u;
+    return ((x << 6) | (x >> 4) | (x >> 14) | (x >> 24)) & 0xFFu;
+}
+// 4 bases -> 4 bits, bit set where the byte is >= 4, earliest base in bit 3.
+__device__ __forceinline__ uint32_t inv4(uint32_t w) {
+    uint32_t t = w & 0xFCFCFCFCu;
+    t |= t >> 4;
+    t |= t >> 2;
+    t |= t >> 1;
+    t &= 0x01010101u;
+    return ((t << 3) | (t >> 6) | (t >> 15) | (t >> 24)) & 0xFu;
+}
+__device__ __forceinline__ uint32_t pack16(uint4 v) {
+    return (pack4(v.x) << 24) | (pack4(v.y) << 16) | (pack4(v.z) << 8) | pack4(v.w);
+}
+__device__ __forceinline__ uint32_t inv16(uint4 v) {
+    return (inv4(v.x) << 12) | (inv4(v.y) << 8) | (inv4(v.z) << 4) | inv4(v.w);
+}
+
+template <bool LDS_HIST>
+__device__ __forceinline__ void bump(uint32_t *hist, uint32_t idx) {
+    atomicAdd(&hist[idx], 1u);  // ds_add_u32 / global_atomic_add, no return
+}
+
+__device__ __forceinline__ double clog2c(uint32_t c, const double *tbl) {
+    if (c < CLOG_TBL) return tbl[c];
+    const double d = double(c);
+    return d * log2(d);
+}
+
+// LDS: [hist B u32 (LDS_HIST)] [tbl 256 f64] [scratch 32 f64]
+template <bool NS4, bool LDS_HIST>
+__global__ __launch_bounds__(HIST_THREADS) void kmer_hist_kernel(
+    const uint8_t *__restrict__ seqs, uint64_t nbytes, const KTile *__restrict__ tiles,
+    uint32_t *__restrict__ counts, uint32_t *__restrict__ totals,
+    double *__restrict__ entropy, uint32_t k, uint32_t ns, uint64_t B) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const KTile t = tiles[blockIdx.x];
+    uint32_t *row = counts + uint64_t(t.row) * B;
+    uint32_t *hist = LDS_HIST ? reinterpret_cast<uint32_t *>(smem) : row;
+    double *tbl = reinterpret_cast<double *>(smem + (LDS_HIST ? ((B * 4 + 15) & ~15ull) : 0));
+    double *scratch = tbl + CLOG_TBL;
+    const int tid = threadIdx.x;
+
+    if (LDS_HIST) {
+        if ((B & 3) == 0) {
+            uint4 *h4 = reinterpret_cast<uint4 *>(hist);
+            for (uint64_t i = tid; i < B / 4; i += HIST_THREADS) h4[i] = make_uint4(0, 0, 0, 0);
+        } else {
+            for (uint64_t i = tid; i < B; i += HIST_THREADS) hist[i] = 0;
+        }
+    }
+    if (tid < CLOG_TBL) tbl[tid] = tid ? double(tid) * log2(double(tid)) : 0.0;
+    __syncthreads();
+
+    const uint64_t abase = t.begin & ~15ull;
+    const uint64_t nchunks = (t.end - abase + 15) >> 4;
+    const uint32_t kmask = (k >= 32) ? 0xFFFFFFFFu : ((1u << k) - 1u);
+    const uint32_t bmask = uint32_t(B - 1);  // NS4: B = 4^k, power of two (k = 16 -> 2^32 - 1)
+
+    for (uint64_t c = tid; c < nchunks; c += HIST_THREADS) {
+        const uint64_t A = abase + (c << 4);
+        const uint4 cur = load16(seqs, A, nbytes);
+        const uint4 prev = (A >= 16) ? load16(seqs, A - 16, nbytes)
+                                     : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        // positions q = 0..31 <-> absolute A-16+q ; bases before the sequence start are invalid
+        const int64_t lead = int64_t(t.seq_begin) - (int64_t(A) - 16);
+        if (NS4) {
+            const uint64_t P = (uint64_t(pack16(prev)) << 32) | pack16(cur);
+            uint32_t I = (inv16(prev) << 16) | inv16(cur);  // bit 31-q
+            if (lead > 0) I |= (lead >= 32) ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> lead);
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint64_t p = A + j;
+                const uint32_t idx = uint32_t(P >> (2 * (15 - j))) & bmask;
+                const uint32_t bad = (I >> (15 - j)) & kmask;
+                if (p >= t.begin && p < t.end && bad == 0) bump<LDS_HIST>(hist, idx);
+            }
+        } else {
+            const uint32_t w[8] = {prev.x, prev.y, prev.z, prev.w, cur.x, cur.y, cur.z, cur.w};
+            uint32_t idx = 0, run = 0;
+            const uint32_t Bd = uint32_t(B / ns);  // ns^(k-1)
+#pragma unroll
+            for (int q = 0; q < 32; q++) {
+                const uint32_t b = (w[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+                const bool ok = (b < ns) && (int64_t(q) >= lead);
+                idx = ok ? (idx % Bd) * ns + b : 0u;
+                run = ok ? run + 1 : 0u;
+                if (q >= 16) {
+                    const uint64_t p = A + (q - 16);
+                    if (p >= t.begin && p < t.end && run >= k) bump<LDS_HIST>(hist, idx);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    if (t.single) {
+        double s = 0.0, tot = 0.0;
+        if (LDS_HIST) {
+            if ((B & 3) == 0) {
+                const uint4 *h4 = reinterpret_cast<const uint4 *>(hist);
+                uint4 *r4 = reinterpret_cast<uint4 *>(row);
+                for (uint64_t i = tid; i < B / 4; i += HIST_THREADS) {
+                    const uint4 v = h4[i];
+                    r4[i] = v;
+                    s += clog2c(v.x, tbl) + clog2c(v.y, tbl) + clog2c(v.z, tbl) + clog2c(v.w, tbl);
+                    tot += double(v.x) + double(v.y) + double(v.z) + double(v.w);
+                }
+            } else {
+                for (uint64_t i = tid; i < B; i += HIST_THREADS) {
+                    const uint32_t v = hist[i];
+                    row[i] = v;
+                    s += clog2c(v, tbl);
+                    tot += double(v);
+                }
+            }
+        } else {
+            __threadfence();  // this block's global atomics on `row` are complete and visible to it
+            for (uint64_t i = tid; i < B; i += HIST_THREADS) {
+                const uint32_t v = __hip_atomic_load(&row[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s += clog2c(v, tbl);
+                tot += double(v);
+            }
+        }
+        s = dvs_block_sum(s, scratch);
+        tot = dvs_block_sum(tot, scratch);
+        if (tid == 0) {
+            totals[t.row] = uint32_t(tot);
+            entropy[t.row] = tot > 0.0 ? log2(tot) - s / tot : 0.0;
+        }
+    } else if (LDS_HIST) {
+        for (uint64_t i = tid; i < B; i += HIST_THREADS) {
+            const uint32_t v = hist[i];
+            if (v) atomicAdd(&row[i], v);
+        }
+    }
+}
+
+// rows listed in `rows`: total and entropy from the finished count row
+__global__ __launch_bounds__(HIST_THREADS) void row_stats_kernel(
+    const uint32_t *__restrict__ counts, const uint32_t *__restrict__ rows,
+    uint32_t *__restrict__ totals, double *__restrict__ entropy, uint64_t B) {
+    __shared__ double tbl[CLOG_TBL];
+    __shared__ double scratch[32];
+    const int tid = threadIdx.x;
+    if (tid < CLOG_TBL) tbl[tid] = tid ? double(tid) * log2(double(tid)) : 0.0;
+    __syncthreads();
+    const uint32_t r = rows[blockIdx.x];
+    const uint32_t *row = counts + uint64_t(r) * B;
+    double s = 0.0, tot = 0.0;
+    for (uint64_t i = tid; i < B; i += HIST_THREADS) {
+        const uint32_t v = row[i];
+        s += clog2c(v, tbl);
+        tot += double(v);
+    }
+    s = dvs_block_sum(s, scratch);
+    tot = dvs_block_sum(tot, scratch);
+    if (tid == 0) {
+        totals[r] = uint32_t(tot);
+        entropy[r] = tot > 0.0 ? log2(tot) - s / tot : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(HIST_THREADS) void zero_rows_kernel(uint32_t *__restrict__ counts,
+                                                                const uint32_t *__restrict__ rows,
+                                                                uint64_t B) {
+    uint32_t *row = counts + uint64_t(rows[blockIdx.x]) * B;
+    for (uint64_t i = threadIdx.x; i < B; i += HIST_THREADS) row[i] = 0;
+}
+
+// kind-1 matrices: H(row) = sum_{f != 0} -f log2 f (src/record.rs:86-106)
+__global__ __launch_bounds__(HIST_THREADS) void freq_entropy_kernel(
+    const double *__restrict__ freqs, double *__restrict__ entropy, uint64_t B) {
+    __shared__ double scratch[32];
+    const double *row = freqs + uint64_t(blockIdx.x) * B;
+    double h = 0.0;
+    for (uint64_t i = threadIdx.x; i < B; i += HIST_THREADS) {
+        const double f = row[i];
+        if (f != 0.0) h += -f * log2(f);
+    }
+    h = dvs_block_sum(h, scratch);
+    if (threadIdx.x == 0) entropy[blockIdx.x] = h;
+}
+
+template <typename K>
+int set_dyn_lds(dvs_ctx *ctx, K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        DVS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+    return DVS_OK;
+}
+
+}  // namespace
+
+uint64_t dvs_pow_u64(uint32_t base, uint32_t exp, bool *overflow) {
+    uint64_t r = 1;
+    *overflow = false;
+    for (uint32_t i = 0; i < exp; i++) {
+        if (r > UINT64_MAX / (base ? base : 1)) *overflow = true;
+        r *= base;
+    }
+    return r;
+}
+
+void dvs_matrix_free_fields(dvs_matrix *m) {
+    if (!m) return;
+    if (m->d_counts) (void)hipFree(m->d_counts);
+    if (m->d_freqs) (void)hipFree(m->d_freqs);
+    if (m->d_totals) (void)hipFree(m->d_totals);
+    if (m->d_entropy) (void)hipFree(m->d_entropy);
+    m->d_counts = nullptr;
+    m->d_freqs = nullptr;
+    m->d_totals = nullptr;
+    m->d_entropy = nullptr;
+}
+
+// Launches the histogram build for sequences already in HBM (d_seqs, nbytes
+// readable) into an allocated matrix.  Asynchronous on ctx->stream except for
+// the small tile-list upload.
+int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
+                           uint64_t nbytes, const uint64_t *offsets) {
+    const uint32_t nseq = m->nrows, k = m->k, ns = m->num_states;
+    const uint64_t B = m->nbins;
+    std::vector<KTile> tiles;
+    std::vector<uint32_t> zero_rows, stat_rows;
+    tiles.reserve(nseq);
+    for (uint32_t r = 0; r < nseq; r++) {
+        const uint64_t s0 = offsets[r], s1 = offsets[r + 1];
+        if (s1 < s0 || s1 > nbytes)
+            return dvs_set_error(ctx, DVS_ERR_VALUE, "offsets[%u..%u] = %llu..%llu out of range", r,
+                                 r + 1, (unsigned long long)s0, (unsigned long long)s1);
+        if (s1 - s0 < k) {  // windows(k) empty -> all-zero row (record.rs:57)
+            zero_rows.push_back(r);
+            stat_rows.push_back(r);
+            continue;
+        }
+        const uint64_t first = s0 + k - 1;
+        const uint64_t ntile = (s1 - first + TILE_LEN - 1) / TILE_LEN;
+        if (ntile > 1) {
+            zero_rows.push_back(r);
+            stat_rows.push_back(r);
+        }
+        for (uint64_t i = 0; i < ntile; i++) {
+            KTile t;
+            t.begin = first + i * TILE_LEN;
+            t.end = std::min<uint64_t>(t.begin + TILE_LEN, s1);
+            t.seq_begin = s0;
+            t.row = r;
+            t.single = ntile == 1;
+            tiles.push_back(t);
+        }
+    }
+    const bool lds_hist = B * 4 <= 64 * 1024;
+    const bool ns4 = ns == 4;
+    if (!lds_hist) {  // the rows take the atomics directly: all must start at zero
+        zero_rows.clear();
+        DVS_HIP(ctx, hipMemsetAsync(m->d_counts, 0, size_t(nseq) * B * 4, ctx->stream));
+    }
+    uint32_t *d_rows = nullptr;
+    KTile *d_tiles = nullptr;
+    const size_t nlist = zero_rows.size() + stat_rows.size();
+    if (nlist) {
+        DVS_HIP(ctx, hipMalloc(&d_rows, nlist * sizeof(uint32_t)));
+        if (!zero_rows.empty())
+            DVS_HIP(ctx, hipMemcpyAsync(d_rows, zero_rows.data(), zero_rows.size() * 4,
+                                        hipMemcpyHostToDevice, ctx->stream));
+        if (!stat_rows.empty())
+            DVS_HIP(ctx, hipMemcpyAsync(d_rows + zero_rows.size(), stat_rows.data(),
+                                        stat_rows.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (!zero_rows.empty())
+        hipLaunchKernelGGL(zero_rows_kernel, dim3(uint32_t(zero_rows.size())), dim3(HIST_THREADS), 0,
+                           ctx->stream, m->d_counts, d_rows, B);
+    if (!tiles.empty()) {
+        DVS_HIP(ctx, hipMalloc(&d_tiles, tiles.size() * sizeof(KTile)));
+        DVS_HIP(ctx, hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(KTile),
+                                    hipMemcpyHostToDevice, ctx->stream));
+        const size_t lds = (lds_hist ? ((B * 4 + 15) & ~15ull) : 0) + (CLOG_TBL + 32) * sizeof(double);
+        const dim3 grid{uint32_t(tiles.size())}, block{HIST_THREADS};
+#define DVS_LAUNCH_HIST(NS4, LH)                                                                \
+    do {                                                                                        \
+        int rc__ = set_dyn_lds(ctx, kmer_hist_kernel<NS4, LH>, lds);                            \
+        if (rc__) return rc__;                                                                  \
+        hipLaunchKernelGGL((kmer_hist_kernel<NS4, LH>), grid, block, lds, ctx->stream, d_seqs,  \
+                           nbytes, d_tiles, m->d_counts, m->d_totals, m->d_entropy, k, ns, B);  \
+    } while (0)
+        if (ns4 && lds_hist) DVS_LAUNCH_HIST(true, true);
+        else if (ns4) DVS_LAUNCH_HIST(true, false);
+        else if (lds_hist) DVS_LAUNCH_HIST(false, true);
+        else DVS_LAUNCH_HIST(false, false);
+#undef DVS_LAUNCH_HIST
+        DVS_HIP(ctx, hipGetLastError());
+    }
+    if (!stat_rows.empty()) {
+        hipLaunchKernelGGL(row_stats_kernel, dim3(uint32_t(stat_rows.size())), dim3(HIST_THREADS), 0,
+                           ctx->stream, m->d_counts, d_rows + zero_rows.size(), m->d_totals,
+                           m->d_entropy, B);
+        DVS_HIP(ctx, hipGetLastError());
+    }
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // tile lists are freed below
+    if (d_rows) (void)hipFree(d_rows);
+    if (d_tiles) (void)hipFree(d_tiles);
+    return DVS_OK;
+}
+
+int dvs_matrix_fill_freq_entropy(dvs_ctx *ctx, dvs_matrix *m) {
+    hipLaunchKernelGGL(freq_entropy_kernel, dim3(m->nrows), dim3(HIST_THREADS), 0, ctx->stream,
+                       m->d_freqs, m->d_entropy, m->nbins);
+    DVS_HIP(ctx, hipGetLastError());
+    return DVS_OK;
+}

@@ -1,0 +1,467 @@
+// MinHash bottom-s sketches and pairwise mash / euclidean distances.
+//
+// Replaces, for batches:
+//   murmurhash3_32  src/distance.rs:21-49  (NOT standard murmur3: every BYTE is a
+//                   32-bit block, h starts at seed ^ len, no tail, fmix32 finish)
+//   hash_kmer       :65-87   (mash-canonical = lexicographic min of k-mer / revcomp)
+//   get_kmer_hashes :101-134 (windows holding a symbol >= num_states are skipped)
+//   mash_sketch     :151-182 (the sketch_size smallest DISTINCT hashes, ascending)
+//   mash_distance   diverse_seq/distance.py:230-291, N x N driver :165-173 and the
+//                   strided rows of diverse_seq/cluster.py:640-644
+//   euclidean_distance(s) diverse_seq/distance.py:294-336
+//
+// Device pipeline per sequence:
+//   1. hash_filter_kernel: a tile of windows per workgroup, the tile's bytes staged
+//      in LDS, one window per lane per step; hashes <= a per-sequence threshold T
+//      are appended to that sequence's candidate list (hashes are uniform, so
+//      T = 2^32 * (3 s + 64) / n_windows keeps ~3 s candidates and the rest of the
+//      ~n_windows hashes never leave registers);
+//   2. sort_select_kernel: one workgroup per sequence sorts the candidates in LDS
+//      (bitonic), drops duplicates, writes the first s.  If fewer than s distinct
+//      values survived and T was not the maximum, the host raises T and repeats
+//      for that sequence (bit-exact: the result is the exact bottom-s set).
+#include "dvs_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+constexpr int MASH_THREADS = 256;
+constexpr uint32_t MASH_TILE = 8192;       // windows per workgroup
+constexpr uint32_t SORT_CAP = 16384;       // candidates one workgroup sorts in LDS (64 KB)
+constexpr int MAX_K = 64;
+
+struct MTile {
+    uint64_t begin;  // first window START (absolute byte offset)
+    uint32_t count;  // windows in this tile
+    uint32_t seq;
+};
+
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+__device__ __forceinline__ uint32_t mix_byte(uint32_t h, uint32_t v) {
+    uint32_t k = v * 0xCC9E2D51u;
+    k = rotl32(k, 15);
+    k *= 0x1B873593u;
+    h ^= k;
+    h = rotl32(h, 13);
+    return h * 5u + 0xE6546B64u;
+}
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+// hash of window w[0..k) (bytes in LDS); valid=false if any symbol >= ns
+__device__ __forceinline__ uint32_t hash_window(const uint8_t *w, uint32_t k, uint32_t ns,
+                                                bool canonical, bool *valid) {
+    bool ok = true;
+    bool use_rev = false;
+    if (canonical) {
+        // first position where kmer and revcomp differ decides (distance.rs:69-78)
+        for (uint32_t i = 0; i < k; i++) {
+            const uint32_t a = w[i];
+            const uint32_t b = (uint32_t(w[k - 1 - i]) + 2u) & 3u;  // (base + 2) % 4, reversed
+            if (a < b) break;
+            if (a > b) {
+                use_rev = true;
+                break;
+            }
+        }
+    }
+    uint32_t h = 0x9747B28Cu ^ k;
+    for (uint32_t i = 0; i < k; i++) {
+        const uint32_t a = w[i];
+        ok = ok && (a < ns);
+        const uint32_t v = use_rev ? ((uint32_t(w[k - 1 - i]) + 2u) & 3u) : a;
+        h = mix_byte(h, v);
+    }
+    // NB canonical decision was made on raw bytes; an invalid window is dropped anyway
+    *valid = ok;
+    return fmix32(h);
+}
+
+__global__ __launch_bounds__(MASH_THREADS) void hash_filter_kernel(
+    const uint8_t *__restrict__ seqs, const MTile *__restrict__ tiles, uint32_t k, uint32_t ns,
+    int canonical, const uint32_t *__restrict__ thresh, const uint8_t *__restrict__ active,
+    uint32_t *__restrict__ cand, const uint64_t *__restrict__ cand_off,
+    const uint32_t *__restrict__ cand_cap, uint32_t *__restrict__ cand_cnt,
+    uint32_t *__restrict__ nvalid) {
+    __shared__ uint8_t sbytes[MASH_TILE + MAX_K + 16];
+    __shared__ uint32_t s_valid;
+    const MTile t = tiles[blockIdx.x];
+    if (!active[t.seq]) return;
+    const uint32_t nbytes = t.count + k - 1;
+    for (uint32_t i = threadIdx.x; i < nbytes; i += MASH_THREADS) sbytes[i] = seqs[t.begin + i];
+    if (threadIdx.x == 0) s_valid = 0;
+    __syncthreads();
+    const uint32_t T = thresh[t.seq];
+    const uint32_t cap = cand_cap[t.seq];
+    uint32_t *out = cand + cand_off[t.seq];
+    uint32_t nv = 0;
+    for (uint32_t i = threadIdx.x; i < t.count; i += MASH_THREADS) {
+        bool ok;
+        const uint32_t h = hash_window(sbytes + i, k, ns, canonical != 0, &ok);
+        if (ok) {
+            nv++;
+            if (h <= T) {
+                const uint32_t slot = atomicAdd(&cand_cnt[t.seq], 1u);
+                if (slot < cap) out[slot] = h;
+            }
+        }
+    }
+    if (nv) atomicAdd(&s_valid, nv);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_valid) atomicAdd(&nvalid[t.seq], s_valid);
+}
+
+// One workgroup per listed sequence: bitonic sort of <= SORT_CAP candidates in LDS,
+// unique, first s -> sketch.  status: 0 done, 1 need larger T, 2 overflow (smaller T).
+__global__ __launch_bounds__(1024) void sort_select_kernel(
+    const uint32_t *__restrict__ seq_list, const uint32_t *__restrict__ cand,
+    const uint64_t *__restrict__ cand_off, const uint32_t *__restrict__ cand_cap,
+    const uint32_t *__restrict__ cand_cnt, const uint32_t *__restrict__ thresh, uint32_t s,
+    uint32_t *__restrict__ sketches, uint32_t *__restrict__ lens, uint32_t *__restrict__ status) {
+    extern __shared__ uint32_t keys[];
+    const uint32_t q = seq_list[blockIdx.x];
+    const uint32_t cnt = cand_cnt[q], cap = cand_cap[q];
+    if (cnt > cap) {
+        if (threadIdx.x == 0) status[q] = 2;
+        return;
+    }
+    uint32_t n2 = 1;
+    while (n2 < cnt) n2 <<= 1;
+    const uint32_t *in = cand + cand_off[q];
+    // pad with 0xFFFFFFFF; a genuine 0xFFFFFFFF hash sorts with the padding, so the
+    // number of real entries is tracked separately (cnt)
+    for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) keys[i] = i < cnt ? in[i] : 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t size = 2; size <= n2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t i = threadIdx.x; i < (n2 >> 1); i += blockDim.x) {
+                const uint32_t lo = 2 * i - (i & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint32_t a = keys[lo], b = keys[hi];
+                if ((a > b) == up) {
+                    keys[lo] = b;
+                    keys[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // unique + take s: position of element i among distinct values = number of
+    // "first occurrences" before it; sequential prefix per thread chunk is enough
+    // for <= 16 K entries: thread 0 of each 1024-chunk... keep it simple and exact:
+    // block-wide stable compaction via per-thread contiguous chunks
+    const uint32_t per = (cnt + blockDim.x - 1) / blockDim.x;
+    const uint32_t b0 = min(cnt, threadIdx.x * per), b1 = min(cnt, b0 + per);
+    uint32_t mine = 0;
+    for (uint32_t i = b0; i < b1; i++) mine += (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+    // exclusive scan of `mine` over threads (LDS, Hillis-Steele on 1024 entries)
+    __shared__ uint32_t scan[1024];
+    scan[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t o = 1; o < blockDim.x; o <<= 1) {
+        const uint32_t v = threadIdx.x >= o ? scan[threadIdx.x - o] : 0u;
+        __syncthreads();
+        scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t pos = scan[threadIdx.x] - mine;
+    uint32_t *sk = sketches + uint64_t(q) * s;
+    for (uint32_t i = b0; i < b1; i++) {
+        if (i == 0 || keys[i] != keys[i - 1]) {
+            if (pos < s) sk[pos] = keys[i];
+            pos++;
+        }
+    }
+    if (threadIdx.x == blockDim.x - 1) {
+        const uint32_t distinct = scan[threadIdx.x];
+        const bool all = thresh[q] == 0xFFFFFFFFu;
+        if (distinct >= s || all) {
+            lens[q] = min(distinct, s);
+            status[q] = 0;
+        } else {
+            status[q] = 1;
+        }
+    }
+}
+
+// mash_distance for the pair (i, j < i); one thread per pair
+__global__ __launch_bounds__(256) void mash_pairs_kernel(
+    const uint32_t *__restrict__ sketches, const uint32_t *__restrict__ lens, uint32_t nseq,
+    uint32_t k, uint32_t s, uint32_t stride, uint32_t row_start, uint32_t row_stride, int symmetric,
+    double *__restrict__ dist, uint32_t *__restrict__ zerodiv) {
+    const uint32_t i = row_start + blockIdx.y * row_stride;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nseq || j >= i) return;
+    const uint32_t *L = sketches + uint64_t(i) * stride, *R = sketches + uint64_t(j) * stride;
+    const uint32_t nl = lens[i], nr = lens[j];
+    uint32_t inter = 0, uni = 0, li = 0, ri = 0;
+    while (uni < s && li < nl && ri < nr) {  // distance.py:260-274
+        const uint32_t l = L[li], r = R[ri];
+        li += (l <= r);
+        ri += (r <= l);
+        inter += (l == r);
+        uni++;
+    }
+    if (uni < s) {  // :276-281
+        if (li < nl) uni += nl - li;
+        if (ri < nr) uni += nr - ri;
+        uni = min(uni, s);
+    }
+    double d;
+    if (uni == 0) {
+        atomicExch(zerodiv, 1u);
+        d = NAN;
+    } else if (inter == uni) {
+        d = 0.0;
+    } else if (inter == 0) {
+        d = 1.0;
+    } else {
+        const double jac = double(inter) / double(uni);
+        d = -log(2.0 * jac / (1.0 + jac)) / double(k);
+        if (d > 1.0) d = 1.0;
+    }
+    dist[uint64_t(i) * nseq + j] = d;
+    if (symmetric) dist[uint64_t(j) * nseq + i] = d;
+}
+
+// ||f_i - f_j||_2, one workgroup per pair (i, j<i); f = counts / total
+template <typename T>
+__global__ __launch_bounds__(256) void euclid_kernel(const T *__restrict__ mat,
+                                                    const uint32_t *__restrict__ totals, uint64_t B,
+                                                    uint32_t n, double *__restrict__ dist) {
+    __shared__ double scratch[32];
+    const uint32_t i = blockIdx.y, j = blockIdx.x;
+    if (j >= i) return;
+    const T *a = mat + uint64_t(i) * B, *b = mat + uint64_t(j) * B;
+    const double ta = double(totals[i]), tb = double(totals[j]);
+    double acc = 0.0;
+    for (uint64_t x = threadIdx.x; x < B; x += 256) {
+        const double d = double(a[x]) / ta - double(b[x]) / tb;
+        acc += d * d;
+    }
+    acc = dvs_block_sum(acc, scratch);
+    if (threadIdx.x == 0) {
+        const double d = sqrt(acc);
+        dist[uint64_t(i) * n + j] = d;
+        dist[uint64_t(j) * n + i] = d;
+    }
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    template <typename T>
+    T *as() { return static_cast<T *>(p); }
+};
+
+}  // namespace
+
+extern "C" int dvs_mash_sketch(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device,
+                               const uint64_t *offsets, uint32_t nseq, uint32_t k,
+                               uint32_t sketch_size, uint32_t num_states, int mash_canonical,
+                               uint32_t *sketches_out, uint32_t *lens_out) {
+    if (!ctx || !offsets || !sketches_out || !lens_out)
+        return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (k == 0 || k > MAX_K)
+        return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "mash k = %u outside 1..%d", k, MAX_K);
+    if (sketch_size == 0) {
+        for (uint32_t i = 0; i < nseq; i++) lens_out[i] = 0;
+        return DVS_OK;
+    }
+    if (nseq == 0) return DVS_OK;
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t s = sketch_size;
+    const uint64_t nbytes = offsets[nseq];
+
+    DevBuf d_seq_own;
+    const uint8_t *d_seqs = seqs;
+    if (!seqs_on_device) {
+        DVS_HIP(ctx, hipMalloc(&d_seq_own.p, nbytes ? nbytes : 16));
+        if (nbytes)
+            DVS_HIP(ctx, hipMemcpyAsync(d_seq_own.p, seqs, nbytes, hipMemcpyHostToDevice, ctx->stream));
+        d_seqs = d_seq_own.as<uint8_t>();
+    }
+
+    // tiles, thresholds, candidate capacities
+    std::vector<MTile> tiles;
+    std::vector<uint32_t> thresh(nseq), cap(nseq), nwin(nseq);
+    std::vector<uint64_t> coff(nseq + 1, 0);
+    // expected candidates below T: 1.5 s + 256 (a Poisson count: > 20 sigma above s)
+    const uint64_t want = s + s / 2 + 256;
+    for (uint32_t q = 0; q < nseq; q++) {
+        const uint64_t len = offsets[q + 1] - offsets[q];
+        const uint64_t w = len >= k ? len - k + 1 : 0;
+        if (w > 0xFFFFFFFFull)
+            return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "sequence %u longer than 2^32", q);
+        nwin[q] = uint32_t(w);
+        if (w <= SORT_CAP) {
+            thresh[q] = 0xFFFFFFFFu;  // keep every hash: exact by construction
+            cap[q] = uint32_t(std::max<uint64_t>(w, 1));
+        } else {
+            const long double tv = (long double)want / (long double)w * 4294967296.0L;
+            thresh[q] = tv >= 4294967295.0L ? 0xFFFFFFFFu : uint32_t(tv);
+            cap[q] = SORT_CAP;
+        }
+        coff[q + 1] = coff[q] + cap[q];
+        for (uint64_t b = 0; b < w; b += MASH_TILE) {
+            MTile t;
+            t.begin = offsets[q] + b;
+            t.count = uint32_t(std::min<uint64_t>(MASH_TILE, w - b));
+            t.seq = q;
+            tiles.push_back(t);
+        }
+    }
+    // capacity of a sequence may have to grow to its window count on retries
+    DevBuf d_tiles, d_thresh, d_cap, d_coff, d_cnt, d_nvalid, d_active, d_cand, d_list, d_sk, d_lens,
+        d_status;
+    const size_t ntile = std::max<size_t>(tiles.size(), 1);
+    DVS_HIP(ctx, hipMalloc(&d_tiles.p, ntile * sizeof(MTile)));
+    DVS_HIP(ctx, hipMalloc(&d_thresh.p, nseq * 4));
+    DVS_HIP(ctx, hipMalloc(&d_cap.p, nseq * 4));
+    DVS_HIP(ctx, hipMalloc(&d_coff.p, (nseq + 1) * 8));
+    DVS_HIP(ctx, hipMalloc(&d_cnt.p, nseq * 4));
+    DVS_HIP(ctx, hipMalloc(&d_nvalid.p, nseq * 4));
+    DVS_HIP(ctx, hipMalloc(&d_active.p, nseq));
+    DVS_HIP(ctx, hipMalloc(&d_list.p, nseq * 4));
+    DVS_HIP(ctx, hipMalloc(&d_sk.p, size_t(nseq) * s * 4));
+    DVS_HIP(ctx, hipMalloc(&d_lens.p, nseq * 4));
+    DVS_HIP(ctx, hipMalloc(&d_status.p, nseq * 4));
+    if (!tiles.empty())
+        DVS_HIP(ctx, hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(MTile),
+                                    hipMemcpyHostToDevice, ctx->stream));
+    DVS_HIP(ctx, hipMemsetAsync(d_lens.p, 0, nseq * 4, ctx->stream));
+    DVS_HIP(ctx, hipMemsetAsync(d_sk.p, 0, size_t(nseq) * s * 4, ctx->stream));
+
+    std::vector<uint8_t> active(nseq, 1);
+    std::vector<uint32_t> status(nseq, 0), lens(nseq, 0);
+    for (uint32_t q = 0; q < nseq; q++)
+        if (nwin[q] == 0) active[q] = 0;  // L < k: empty sketch (distance.rs:102-104)
+    const size_t sort_lds = SORT_CAP * 4;
+    DVS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(sort_select_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(sort_lds)));
+
+    for (int round = 0; round < 40; round++) {
+        std::vector<uint32_t> list;
+        for (uint32_t q = 0; q < nseq; q++)
+            if (active[q]) list.push_back(q);
+        if (list.empty()) break;
+        // candidate storage for this round
+        coff[0] = 0;
+        for (uint32_t q = 0; q < nseq; q++) coff[q + 1] = coff[q] + (active[q] ? cap[q] : 0);
+        DevBuf d_round;
+        DVS_HIP(ctx, hipMalloc(&d_round.p, std::max<uint64_t>(coff[nseq], 1) * 4));
+        DVS_HIP(ctx, hipMemcpyAsync(d_thresh.p, thresh.data(), nseq * 4, hipMemcpyHostToDevice, ctx->stream));
+        DVS_HIP(ctx, hipMemcpyAsync(d_cap.p, cap.data(), nseq * 4, hipMemcpyHostToDevice, ctx->stream));
+        DVS_HIP(ctx, hipMemcpyAsync(d_coff.p, coff.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        DVS_HIP(ctx, hipMemcpyAsync(d_active.p, active.data(), nseq, hipMemcpyHostToDevice, ctx->stream));
+        DVS_HIP(ctx, hipMemcpyAsync(d_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        DVS_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, nseq * 4, ctx->stream));
+        DVS_HIP(ctx, hipMemsetAsync(d_nvalid.p, 0, nseq * 4, ctx->stream));
+        hipLaunchKernelGGL(hash_filter_kernel, dim3(uint32_t(tiles.size())), dim3(MASH_THREADS), 0,
+                           ctx->stream, d_seqs, d_tiles.as<MTile>(), k, num_states, mash_canonical,
+                           d_thresh.as<uint32_t>(), d_active.as<uint8_t>(), d_round.as<uint32_t>(),
+                           d_coff.as<uint64_t>(), d_cap.as<uint32_t>(), d_cnt.as<uint32_t>(),
+                           d_nvalid.as<uint32_t>());
+        hipLaunchKernelGGL(sort_select_kernel, dim3(uint32_t(list.size())), dim3(1024), sort_lds,
+                           ctx->stream, d_list.as<uint32_t>(), d_round.as<uint32_t>(),
+                           d_coff.as<uint64_t>(), d_cap.as<uint32_t>(), d_cnt.as<uint32_t>(),
+                           d_thresh.as<uint32_t>(), s, d_sk.as<uint32_t>(), d_lens.as<uint32_t>(),
+                           d_status.as<uint32_t>());
+        DVS_HIP(ctx, hipGetLastError());
+        DVS_HIP(ctx, hipMemcpyAsync(status.data(), d_status.p, nseq * 4, hipMemcpyDeviceToHost, ctx->stream));
+        DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t q : list) {
+            if (status[q] == 0) {
+                active[q] = 0;
+            } else if (status[q] == 1) {  // too few distinct below T: raise T
+                const uint64_t t2 = uint64_t(thresh[q]) * 2 + 1;
+                thresh[q] = t2 >= 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(t2);
+            } else {  // more candidates than one workgroup sorts: lower T
+                if (thresh[q] == 0xFFFFFFFFu || want > SORT_CAP / 2)
+                    return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED,
+                                         "sketch_size %u too large for the device path on sequence %u "
+                                         "(%u windows)", s, q, nwin[q]);
+                thresh[q] = uint32_t(uint64_t(thresh[q]) * 3 / 4);
+            }
+        }
+        if (round == 39)
+            return dvs_set_error(ctx, DVS_ERR_RUNTIME, "mash sketch threshold search did not converge");
+    }
+    DVS_HIP(ctx, hipMemcpyAsync(sketches_out, d_sk.p, size_t(nseq) * s * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DVS_HIP(ctx, hipMemcpyAsync(lens_out, d_lens.p, nseq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DVS_OK;
+}
+
+extern "C" int dvs_mash_distances(dvs_ctx *ctx, const uint32_t *sketches, uint32_t sketch_stride,
+                                  const uint32_t *lens, uint32_t nseq, uint32_t k, uint32_t sketch_size,
+                                  uint32_t row_start, uint32_t row_stride, int symmetric,
+                                  double *dist) {
+    if (!ctx || !lens || !dist || (!sketches && sketch_stride))
+        return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    for (uint32_t i = 0; i < nseq; i++)
+        if (lens[i] > sketch_stride)
+            return dvs_set_error(ctx, DVS_ERR_VALUE, "lens[%u] = %u exceeds the sketch stride %u", i,
+                                 lens[i], sketch_stride);
+    if (nseq < 2 || row_start >= nseq) return DVS_OK;
+    if (row_stride == 0) row_stride = 1;
+    if (k == 0) return dvs_set_error(ctx, DVS_ERR_ZERODIV, "float division by zero");
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t s = std::max<uint32_t>(sketch_stride, 1);
+    DevBuf d_sk, d_lens, d_dist, d_flag;
+    DVS_HIP(ctx, hipMalloc(&d_sk.p, size_t(nseq) * s * 4));
+    DVS_HIP(ctx, hipMalloc(&d_lens.p, nseq * 4));
+    DVS_HIP(ctx, hipMalloc(&d_dist.p, size_t(nseq) * nseq * 8));
+    DVS_HIP(ctx, hipMalloc(&d_flag.p, 4));
+    if (sketch_stride)
+        DVS_HIP(ctx, hipMemcpyAsync(d_sk.p, sketches, size_t(nseq) * s * 4, hipMemcpyHostToDevice, ctx->stream));
+    DVS_HIP(ctx, hipMemcpyAsync(d_lens.p, lens, nseq * 4, hipMemcpyHostToDevice, ctx->stream));
+    DVS_HIP(ctx, hipMemcpyAsync(d_dist.p, dist, size_t(nseq) * nseq * 8, hipMemcpyHostToDevice, ctx->stream));
+    DVS_HIP(ctx, hipMemsetAsync(d_flag.p, 0, 4, ctx->stream));
+    const uint32_t nrows = (nseq - 1 - row_start) / row_stride + 1;
+    const dim3 grid((nseq + 255) / 256, nrows);
+    hipLaunchKernelGGL(mash_pairs_kernel, grid, dim3(256), 0, ctx->stream, d_sk.as<uint32_t>(),
+                       d_lens.as<uint32_t>(), nseq, k, sketch_size, s, row_start, row_stride, symmetric,
+                       d_dist.as<double>(), d_flag.as<uint32_t>());
+    DVS_HIP(ctx, hipGetLastError());
+    uint32_t flag = 0;
+    DVS_HIP(ctx, hipMemcpyAsync(dist, d_dist.p, size_t(nseq) * nseq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    DVS_HIP(ctx, hipMemcpyAsync(&flag, d_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (flag) return dvs_set_error(ctx, DVS_ERR_ZERODIV, "division by zero");  // 0 / 0, distance.py:283
+    return DVS_OK;
+}
+
+extern "C" int dvs_euclidean_distances(dvs_ctx *ctx, const dvs_matrix *m, double *dist) {
+    if (!ctx || !m || !dist) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    const uint32_t n = m->nrows;
+    for (uint64_t i = 0; i < uint64_t(n) * n; i++) dist[i] = 0.0;
+    if (n < 2) return DVS_OK;
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf d_dist;
+    DVS_HIP(ctx, hipMalloc(&d_dist.p, size_t(n) * n * 8));
+    DVS_HIP(ctx, hipMemsetAsync(d_dist.p, 0, size_t(n) * n * 8, ctx->stream));
+    const dim3 grid(n, n);
+    if (m->kind == 0)
+        hipLaunchKernelGGL((euclid_kernel<uint32_t>), grid, dim3(256), 0, ctx->stream, m->d_counts,
+                           m->d_totals, m->nbins, n, d_dist.as<double>());
+    else
+        hipLaunchKernelGGL((euclid_kernel<double>), grid, dim3(256), 0, ctx->stream, m->d_freqs,
+                           m->d_totals, m->nbins, n, d_dist.as<double>());
+    DVS_HIP(ctx, hipGetLastError());
+    DVS_HIP(ctx, hipMemcpyAsync(dist, d_dist.p, size_t(n) * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DVS_OK;
+}

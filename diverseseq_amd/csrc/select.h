@@ -1,0 +1,95 @@
+// Shared between select.hip (device engine) and exact_set.cpp (host tie arbiter).
+#pragma once
+
+#include "dvs_internal.h"
+
+#define SEL_NONE 0xFFFFFFFFFFFFFFFFull
+
+enum : uint32_t { SEL_RUN = 0, SEL_DONE = 1, SEL_ARBITER = 2, SEL_ERROR = 3 };
+enum : uint32_t { ARB_RESOLVE = 1, ARB_FINALIZE = 2 };
+enum : uint32_t { FORCE_NONE = 0, FORCE_ACCEPT = 1, FORCE_REJECT = 2, FORCE_COMMIT = 3, FORCE_ROLLBACK = 4 };
+
+// Device-resident control block: the engine's cursor, the pending event and the
+// scalar part of the SummedRecords state (src/records.rs:10-24).
+struct SelCtl {
+    unsigned long long cursor;     // next stream position to score
+    unsigned long long npos;       // stream length
+    unsigned long long event_pos;  // first position of the window whose score clears thr - band
+    unsigned long long arb_pos;
+    unsigned long long rows_scored, rows_rechecked;
+    uint32_t window, window_min, window_max;
+    uint32_t status, arb_stage, forced, forced_lowest;
+    uint32_t size, lowest, mode, max_size, stat;
+    uint32_t ev_kind;   // 0 none, 1 set changed (replace / initial), 2 tentative push (MODE_MAX)
+    uint32_t ev_n;      // members taking part in the pending leave-one-out pass
+    uint32_t ev_risky;  // a sum-to-one check is too close to call on the device
+    uint32_t n_windows, n_events, n_accepts;
+    double total_jsd, sum_entropy;      // records.rs: total_jsd, summed_entropies
+    double thr, band;                   // total_jsd + eps ; width of the undecidable zone
+    double he_base;                     // summed_entropies - H(lowest)
+    double mean_delta, std_delta, cov_delta;
+    double t_total_jsd, t_sum_entropy;  // tentative (MODE_MAX push) values
+    double last_jsd;
+};
+
+// Device pointers of one selection (passed to kernels by value).
+struct SelDev {
+    SelCtl *ctl = nullptr;
+    uint64_t B = 0;
+    uint32_t nlabels = 0;
+    // candidate stream
+    const uint32_t *order = nullptr;   // position -> matrix row (NULL: identity)
+    const uint32_t *labels = nullptr;  // position -> identity label (NULL: row)
+    const uint32_t *totals = nullptr;  // matrix row totals
+    const double *rowH = nullptr;      // matrix row entropies
+    // set state
+    double *S = nullptr;       // summed_kfreqs
+    double *Stmp = nullptr;    // tentative summed_kfreqs (MODE_MAX push)
+    double *base = nullptr;    // (S - lowest) / size, what the scan adds candidates to
+    double *cand = nullptr;    // frequency row of the candidate being resolved
+    double *M = nullptr;       // member frequency rows, cap x B, by slot
+    double *mH = nullptr;      // member entropies, by slot
+    double *mDelta = nullptr;  // member delta_jsd, by member order
+    double *dtmp = nullptr;    // leave-one-out results of the pending event, by member order
+    double *dsum = nullptr;    // sum of each leave-one-out mean vector (tolerance check)
+    uint32_t *mLabel = nullptr;
+    unsigned long long *mPos = nullptr;  // stream position each member came from, by slot
+    uint32_t *ord = nullptr;             // member order -> slot (Vec::remove / push order)
+    uint8_t *inset = nullptr;            // label -> currently a member
+    uint32_t *wg_rows = nullptr;         // rows actually read by each scan workgroup (last launch)
+};
+
+struct SelEvent {  // host log for the arbiter: what changed the set, in order
+    uint64_t pos;
+    uint32_t kind;  // 1 replace_lowest, 2 push (kept)
+};
+
+struct dvs_select {
+    dvs_select_params params{};
+    const dvs_matrix *mat = nullptr;
+    int mat_kind = 0;
+    uint64_t npos = 0;
+    uint32_t cap = 0;
+    SelDev dev;
+    SelCtl *h_ctl = nullptr;  // pinned mirror
+    std::vector<uint32_t> h_order, h_labels;
+    std::vector<uint64_t> seed_positions;
+    // launch geometry
+    uint32_t scan_grid = 0, loo_grid = 0;
+    size_t scan_lds = 0;
+    bool base_in_lds = true;
+    int batch = 16;
+    // timing
+    bool time_scan = false;
+    std::vector<hipEvent_t> ev_pool;  // pairs (start, stop), one per scan launch
+    size_t ev_used = 0;
+    double scan_ms = 0.0;
+    uint64_t scan_launches = 0;
+    uint32_t n_arbitrated = 0;
+    void *arbiter = nullptr;  // ExactSet*, created on first use
+};
+
+// exact_set.cpp: resolve the decision the device stopped at (h_ctl is current)
+// and write the forced outcome + status RUN back to the device control block.
+int dvs_select_arbitrate(dvs_ctx *ctx, dvs_select *s);
+void dvs_select_arbiter_free(dvs_select *s);

@@ -1,0 +1,924 @@
+// Greedy delta-JSD selection over the N x B count matrix, entirely on the GPU.
+//
+// Replaces SummedRecords and the selectors of the reference (src/records.rs):
+//   delta_jsd :70-84, increases_jsd :86-92, drop_lowest :94-109, replace_lowest
+//   :111-118, push :120-147, stats :153-172, clone :182-189 (= new, :27-68),
+//   get_lowest_record_index :220-252, updated_mean_freqs :276-286,
+//   select_nmost_divergent :311-342, select_max_divergent :390-454 and the
+//   *_final merges :363-382 / :456-507.
+//
+// The reference walks the candidates one by one; candidate i is tested against
+// the set as modified by every accepted j < i.  Here a WINDOW of candidates is
+// scored in parallel against the current state (scan_kernel, the HBM-bound hot
+// kernel: one wavefront per 4^k-bin row), the FIRST position whose score clears
+// the threshold is the only one acted on, and the scan restarts right after it:
+// every candidate before it was rejected under exactly the state the sequential
+// code would have used, so the selected ids are the reference's.  The state
+// update (resolve -> leave-one-out -> finalize kernels) runs on the device too;
+// the cursor, window and event live in device memory, so the host enqueues
+// launch batches blindly and only polls the control block between batches.
+//
+// Decisions the device cannot separate from the reference's own rounding noise
+// (|jsd - threshold| <= band, band ~ 4 B eps H) are handed to the host tie
+// arbiter (exact_set.cpp), which replays the event log in the reference's exact
+// f64 operation order.
+#include "dvs_internal.h"
+#include "select.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;   // 4 waves, one row per wave at a time
+constexpr int WIDE_THREADS = 1024;  // single-block state kernels
+constexpr int LOO_THREADS = 256;
+
+// sum_{x>0} -x log2 x over the bins a thread owns, plus what the reference's
+// entropy() (src/record.rs:86-106) is sensitive to: a negative bin (log2 -> NaN)
+// and the sum of the bins (the |sum - 1| <= len * eps check).
+struct Ent {
+    double h = 0.0, sum = 0.0, mn = 0.0;
+    __device__ __forceinline__ void add(double x) {
+        if (x > 0.0) h -= x * log2(x);
+        sum += x;
+        mn = fmin(mn, x);
+    }
+};
+
+__device__ __forceinline__ uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+
+// Width of the zone in which the device's score and the reference's (sequential
+// f64 sum over B bins, src/record.rs:92-98) cannot be told apart: the reference's
+// own worst-case summation error is ~ B * eps/2 * H.
+__device__ __forceinline__ double sel_band(double hmean, uint64_t B) {
+    return 4.0 * double(B) * DVS_EPS * fmax(1.0, fabs(hmean));
+}
+
+__device__ __forceinline__ double row_value(const uint32_t *row, uint64_t i) { return double(row[i]); }
+__device__ __forceinline__ double row_value(const double *row, uint64_t i) { return row[i]; }
+
+// ---------------------------------------------------------------- scan kernel
+// One wavefront per candidate row; lane l owns bins 4*(j*64 + l) .. +3 so that a
+// wave instruction reads 1 KiB (16 B per lane) of the row.  The per-state vector
+// b_i = (S_i - low_i) / size is staged once per workgroup in LDS.
+//   x_i = b_i + c_i / (total * size)      (reference: (S_i - low_i + f_i) / size)
+//   jsd = sum_i -x_i log2 x_i - (sumH - H_low + H_c) / size
+// Event <=> jsd > thr - band (NaN compares false: the reference rejects too).
+template <typename T>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(
+    SelCtl *__restrict__ ctl, const T *__restrict__ mat, const uint32_t *__restrict__ totals,
+    const double *__restrict__ rowH, const uint32_t *__restrict__ order,
+    const uint32_t *__restrict__ labels, const uint8_t *__restrict__ inset, uint32_t nlabels,
+    const double *__restrict__ base, uint32_t *__restrict__ wg_rows, uint64_t B, int base_in_lds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t s_rows;
+    double *sb = reinterpret_cast<double *>(smem);
+    if (ctl->status != SEL_RUN) return;
+    const uint64_t cursor = ctl->cursor;
+    const uint64_t end = umin64(cursor + uint64_t(ctl->window), ctl->npos);
+    if (cursor >= end) return;
+    const uint64_t nrows = end - cursor;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t wpb = SCAN_THREADS / 64;
+    if (uint64_t(blockIdx.x) * wpb >= nrows) return;  // whole workgroup idle
+    const double *bvec = base;
+    if (threadIdx.x == 0) s_rows = 0;
+    if (base_in_lds) {
+        if ((B & 1) == 0) {
+            const double2 *s2 = reinterpret_cast<const double2 *>(base);
+            double2 *d2 = reinterpret_cast<double2 *>(sb);
+            for (uint64_t i = threadIdx.x; i < B / 2; i += SCAN_THREADS) d2[i] = s2[i];
+        } else {
+            for (uint64_t i = threadIdx.x; i < B; i += SCAN_THREADS) sb[i] = base[i];
+        }
+        bvec = sb;
+    }
+    __syncthreads();
+    const double thr_lo = ctl->thr - ctl->band;
+    const double he_base = ctl->he_base;
+    const double dsize = double(ctl->size);
+    const uint64_t nwaves = uint64_t(gridDim.x) * wpb;
+    uint32_t nread = 0;
+    for (uint64_t r = uint64_t(blockIdx.x) * wpb + wave; r < nrows; r += nwaves) {
+        const uint64_t p = cursor + r;
+        // an earlier event already ends this window: later rows are void
+        if (__hip_atomic_load(&ctl->event_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p) break;
+        const uint32_t row = order ? order[p] : uint32_t(p);
+        const uint32_t tot = totals[row];
+        if (tot == 0) continue;  // "No valid k-mers": skipped (src/records.rs:332-335)
+        const uint32_t lab = labels ? labels[p] : row;
+        if (lab < nlabels && inset[lab]) continue;  // id already in the set (:87-89)
+        const T *rp = mat + uint64_t(row) * B;
+        const double rinv = 1.0 / (double(tot) * dsize);
+        nread++;
+        Ent e;
+        if ((B & 255) == 0) {
+            for (uint64_t i0 = 0; i0 < B; i0 += 256) {
+                const uint64_t i = i0 + lane * 4;
+                double v0, v1, v2, v3;
+                if constexpr (sizeof(T) == 4) {
+                    const uint4 c = *reinterpret_cast<const uint4 *>(rp + i);
+                    v0 = double(c.x); v1 = double(c.y); v2 = double(c.z); v3 = double(c.w);
+                } else {
+                    const double2 a = *reinterpret_cast<const double2 *>(rp + i);
+                    const double2 b = *reinterpret_cast<const double2 *>(rp + i + 2);
+                    v0 = a.x; v1 = a.y; v2 = b.x; v3 = b.y;
+                }
+                const double2 b01 = *reinterpret_cast<const double2 *>(bvec + i);
+                const double2 b23 = *reinterpret_cast<const double2 *>(bvec + i + 2);
+                e.add(fma(v0, rinv, b01.x));
+                e.add(fma(v1, rinv, b01.y));
+                e.add(fma(v2, rinv, b23.x));
+                e.add(fma(v3, rinv, b23.y));
+            }
+        } else {
+            for (uint64_t i = lane; i < B; i += 64) e.add(fma(row_value(rp, i), rinv, bvec[i]));
+        }
+        const double h = dvs_wave_sum(e.h);
+        const double mn = dvs_wave_min(e.mn);
+        if (lane == 0) {
+            const double mean_entropy = (he_base + rowH[row]) / dsize;
+            const double jsd = (mn < 0.0) ? NAN : h - mean_entropy;
+            if (jsd > thr_lo) atomicMin(&ctl->event_pos, (unsigned long long)p);
+        }
+    }
+    if (lane == 0 && nread) atomicAdd(&s_rows, nread);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_rows) wg_rows[blockIdx.x] = s_rows;  // summed + cleared by resolve
+}
+
+// ------------------------------------------------------------- state kernels
+__device__ __forceinline__ double cand_freq(const uint32_t *row, uint64_t i, double tot) {
+    return double(row[i]) / tot;  // record.rs:139, correctly rounded
+}
+__device__ __forceinline__ double cand_freq(const double *row, uint64_t i, double) { return row[i]; }
+
+// JSD of the set with `lowest` swapped for the candidate in d.cand
+// (src/records.rs:70-84), all threads of the block get the result.
+__device__ double block_delta_jsd(const SelDev &d, const SelCtl *ctl, double cand_H,
+                                  double *scratch, double *sum_out) {
+    const uint32_t low_slot = d.ord[ctl->lowest];
+    const double *low = d.M + uint64_t(low_slot) * d.B;
+    const double dsize = double(ctl->size);
+    Ent e;
+    for (uint64_t i = threadIdx.x; i < d.B; i += blockDim.x)
+        e.add((d.S[i] - low[i] + d.cand[i]) / dsize);
+    const double h = dvs_block_sum(e.h, scratch);
+    const double mn = dvs_block_min(e.mn, scratch);
+    const double sm = dvs_block_sum(e.sum, scratch);
+    if (sum_out) *sum_out = sm;
+    const double mean_entropy = (ctl->sum_entropy - d.mH[low_slot] + cand_H) / dsize;
+    return (mn < 0.0) ? NAN : h - mean_entropy;
+}
+
+// H(vec / div) over the block, plus sum for the tolerance check
+__device__ double block_entropy_div(const double *vec, double div, uint64_t B, double *scratch,
+                                    double *sum_out) {
+    Ent e;
+    for (uint64_t i = threadIdx.x; i < B; i += blockDim.x) e.add(vec[i] / div);
+    const double h = dvs_block_sum(e.h, scratch);
+    const double mn = dvs_block_min(e.mn, scratch);
+    const double sm = dvs_block_sum(e.sum, scratch);
+    if (sum_out) *sum_out = sm;
+    return (mn < 0.0) ? NAN : h;
+}
+
+__device__ __forceinline__ void ctl_next_window(SelCtl *ctl) {
+    // accept probability at stream position i is ~ size / i: widen the window as
+    // events thin out (bounded by what one launch covers)
+    uint64_t w = ctl->cursor / (2ull * max(1u, ctl->size));
+    w = max<uint64_t>(w, ctl->window_min);
+    w = min<uint64_t>(w, ctl->window_max);
+    ctl->window = uint32_t(w);
+}
+
+// sum-to-one guard of entropy() (record.rs:99-104): the device cannot decide a
+// borderline case, so anything past a quarter of the tolerance goes to the arbiter
+__device__ __forceinline__ bool sum_risky(double sum, uint64_t B) {
+    return !(fabs(sum - 1.0) <= 0.25 * double(B) * DVS_EPS);
+}
+
+// Resolves the first event of the window: fetch the candidate, re-evaluate its
+// score with the reference's per-bin operation order, decide, and apply
+// replace_lowest (or stage a tentative push for MODE_MAX).  One 1024-thread block.
+template <typename T>
+__global__ __launch_bounds__(WIDE_THREADS) void resolve_kernel(SelDev d, const T *__restrict__ mat,
+                                                            uint32_t scan_grid) {
+    __shared__ double scratch[32];
+    __shared__ int s_action;  // 0 reject, 1 replace, 2 tentative push, 3 stop
+    SelCtl *ctl = d.ctl;
+    if (ctl->status != SEL_RUN) return;
+    const int tid = threadIdx.x;
+    const uint64_t p = ctl->event_pos;
+    if (ctl->ev_kind != 0) return;  // a finalize is pending (arbiter re-entry)
+    {   // rows the scan launch actually read (an arbiter re-entry finds zeros)
+        double cnt = 0.0;
+        for (uint32_t i = tid; i < scan_grid; i += WIDE_THREADS) {
+            cnt += double(d.wg_rows[i]);
+            d.wg_rows[i] = 0;
+        }
+        cnt = dvs_block_sum(cnt, scratch);
+        if (tid == 0) ctl->rows_scored += (unsigned long long)cnt;
+    }
+    if (p == SEL_NONE) {
+        if (tid == 0) {
+            const uint64_t end = umin64(ctl->cursor + uint64_t(ctl->window), ctl->npos);
+            ctl->n_windows++;
+            ctl->cursor = end;
+            if (end >= ctl->npos) ctl->status = SEL_DONE;
+            ctl_next_window(ctl);
+        }
+        return;
+    }
+    const uint32_t row = d.order ? d.order[p] : uint32_t(p);
+    const uint32_t lab = d.labels ? d.labels[p] : row;
+    const double tot = double(d.totals[row]);
+    const double cand_H = d.rowH[row];
+    const T *rp = mat + uint64_t(row) * d.B;
+    for (uint64_t i = tid; i < d.B; i += WIDE_THREADS) d.cand[i] = cand_freq(rp, i, tot);
+    __syncthreads();
+    double sm;
+    const double jsd = block_delta_jsd(d, ctl, cand_H, scratch, &sm);
+    if (tid == 0) {
+        int action;
+        const uint32_t forced = ctl->forced;
+        if (forced == FORCE_ACCEPT || forced == FORCE_REJECT) {
+            action = forced == FORCE_ACCEPT ? 1 : 0;
+            ctl->forced = FORCE_NONE;
+        } else if (sum_risky(sm, d.B) || fabs(jsd - ctl->thr) <= ctl->band) {
+            ctl->status = SEL_ARBITER;
+            ctl->arb_stage = ARB_RESOLVE;
+            ctl->arb_pos = p;
+            action = 3;
+        } else {
+            action = (jsd > ctl->thr) ? 1 : 0;  // NaN -> reject (records.rs:91)
+        }
+        if (action == 1 && ctl->mode == DVS_MODE_MAX && ctl->size < ctl->max_size) action = 2;
+        if (action != 3) {
+            ctl->n_windows++;
+            ctl->n_events++;
+            ctl->cursor = p + 1;
+            ctl->event_pos = SEL_NONE;
+            ctl->last_jsd = jsd;
+            if (action == 0 && ctl->cursor >= ctl->npos) ctl->status = SEL_DONE;
+        }
+        s_action = action;
+    }
+    __syncthreads();
+    const int action = s_action;
+    if (action == 0 || action == 3) return;
+
+    if (action == 1) {
+        // replace_lowest = drop_lowest (records.rs:94-109) + push (:120-147)
+        const uint32_t li = ctl->lowest, n = ctl->size;
+        const uint32_t s = d.ord[li];
+        double *mrow = d.M + uint64_t(s) * d.B;
+        for (uint64_t i = tid; i < d.B; i += WIDE_THREADS) {
+            double v = d.S[i] - mrow[i];
+            if (v <= DVS_EPS) v = 0.0;
+            const double f = d.cand[i];
+            d.S[i] = v + f;
+            mrow[i] = f;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double sh = ctl->sum_entropy - d.mH[s];
+            sh += cand_H;
+            ctl->sum_entropy = sh;
+            const uint32_t old_lab = d.mLabel[s];
+            if (old_lab < d.nlabels) d.inset[old_lab] = 0;
+            if (lab < d.nlabels) d.inset[lab] = 1;
+            for (uint32_t i = li; i + 1 < n; i++) d.ord[i] = d.ord[i + 1];  // Vec::remove
+            d.ord[n - 1] = s;                                              // push
+            d.mH[s] = cand_H;
+            d.mLabel[s] = lab;
+            d.mPos[s] = p;
+            ctl->n_accepts++;
+        }
+        __syncthreads();
+        double sm2;
+        const double hm = block_entropy_div(d.S, double(n), d.B, scratch, &sm2);
+        if (tid == 0) {
+            ctl->total_jsd = hm - ctl->sum_entropy / double(n);
+            ctl->ev_kind = 1;
+            ctl->ev_n = n;
+            if (sum_risky(sm2, d.B) || !(hm == hm)) ctl->ev_risky = 1;
+        }
+    } else {
+        // MODE_MAX with room: clone (= new over the members, records.rs:27-68,182-189)
+        // then push the candidate; kept only if the stat rises (finalize decides)
+        const uint32_t n = ctl->size;
+        double *mrow = d.M + uint64_t(n) * d.B;  // slot n is free
+        for (uint64_t i = tid; i < d.B; i += WIDE_THREADS) {
+            double acc = 0.0;
+            for (uint32_t r = 0; r < n; r++) acc += d.M[uint64_t(d.ord[r]) * d.B + i];
+            const double f = d.cand[i];
+            d.Stmp[i] = acc + f;
+            mrow[i] = f;
+        }
+        if (tid == 0) {
+            double sh = 0.0;
+            for (uint32_t r = 0; r < n; r++) sh += d.mH[d.ord[r]];
+            sh += cand_H;
+            ctl->t_sum_entropy = sh;
+            d.mH[n] = cand_H;
+            d.mLabel[n] = lab;
+            d.mPos[n] = p;
+        }
+        __syncthreads();
+        double sm2;
+        const double hm = block_entropy_div(d.Stmp, double(n + 1), d.B, scratch, &sm2);
+        if (tid == 0) {
+            ctl->t_total_jsd = hm - ctl->t_sum_entropy / double(n + 1);
+            ctl->ev_kind = 2;
+            ctl->ev_n = n + 1;
+            if (sum_risky(sm2, d.B) || !(hm == hm)) ctl->ev_risky = 1;
+        }
+    }
+}
+
+// Initial set: S = sum of the member rows in member order, sumH likewise,
+// total_jsd (SummedRecords::new, records.rs:36-47).  Members were written by
+// seed_kernel.  One block.
+__global__ __launch_bounds__(WIDE_THREADS) void rebuild_kernel(SelDev d) {
+    __shared__ double scratch[32];
+    SelCtl *ctl = d.ctl;
+    const uint32_t n = ctl->size;
+    for (uint64_t i = threadIdx.x; i < d.B; i += WIDE_THREADS) {
+        double acc = 0.0;
+        for (uint32_t r = 0; r < n; r++) acc += d.M[uint64_t(d.ord[r]) * d.B + i];
+        d.S[i] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sh = 0.0;
+        for (uint32_t r = 0; r < n; r++) sh += d.mH[d.ord[r]];
+        ctl->sum_entropy = sh;
+    }
+    __syncthreads();
+    double sm;
+    const double hm = block_entropy_div(d.S, double(n), d.B, scratch, &sm);
+    if (threadIdx.x == 0) {
+        ctl->total_jsd = hm - ctl->sum_entropy / double(n);
+        ctl->ev_kind = 1;
+        ctl->ev_n = n;
+        if (sum_risky(sm, d.B) || !(hm == hm)) ctl->ev_risky = 1;
+    }
+}
+
+// member j <- matrix row of stream position seed_pos[j]
+template <typename T>
+__global__ __launch_bounds__(LOO_THREADS) void seed_kernel(SelDev d, const T *__restrict__ mat,
+                                                         const uint64_t *__restrict__ seed_pos) {
+    const uint32_t j = blockIdx.x;
+    const uint64_t p = seed_pos[j];
+    const uint32_t row = d.order ? d.order[p] : uint32_t(p);
+    const uint32_t lab = d.labels ? d.labels[p] : row;
+    const double tot = double(d.totals[row]);
+    const T *rp = mat + uint64_t(row) * d.B;
+    double *mrow = d.M + uint64_t(j) * d.B;
+    for (uint64_t i = threadIdx.x; i < d.B; i += LOO_THREADS) mrow[i] = cand_freq(rp, i, tot);
+    if (threadIdx.x == 0) {
+        d.ord[j] = j;
+        d.mH[j] = d.rowH[row];
+        d.mLabel[j] = lab;
+        d.mPos[j] = p;
+        if (lab < d.nlabels) d.inset[lab] = 1;
+    }
+}
+
+// Leave-one-out pass (get_lowest_record_index, records.rs:220-252): block r
+// computes delta_jsd of the r-th member of the (possibly tentative) set.
+__global__ __launch_bounds__(LOO_THREADS) void loo_kernel(SelDev d) {
+    __shared__ double scratch[32];
+    const SelCtl *ctl = d.ctl;
+    const uint32_t kind = ctl->ev_kind;
+    if (kind == 0 || ctl->status != SEL_RUN) return;
+    const uint32_t n = ctl->ev_n;
+    const uint32_t r = blockIdx.x;
+    if (r >= n) return;
+    const bool tent = kind == 2;
+    const uint32_t slot = (tent && r == n - 1) ? n - 1 : d.ord[r];
+    const double *Sv = tent ? d.Stmp : d.S;
+    const double sumH = tent ? ctl->t_sum_entropy : ctl->sum_entropy;
+    const double tj = tent ? ctl->t_total_jsd : ctl->total_jsd;
+    const double div = double(n) - 1.0;
+    const double *mrow = d.M + uint64_t(slot) * d.B;
+    Ent e;
+    for (uint64_t i = threadIdx.x; i < d.B; i += LOO_THREADS) {
+        double v = (Sv[i] - mrow[i]) / div;  // updated_mean_freqs, records.rs:276-286
+        if (v <= DVS_EPS) v = 0.0;
+        e.add(v);
+    }
+    const double h = dvs_block_sum(e.h, scratch);
+    const double sm = dvs_block_sum(e.sum, scratch);
+    if (threadIdx.x == 0) {
+        const double mean_entropy = (sumH - d.mH[slot]) / div;
+        const double jsd = h - mean_entropy;
+        d.dtmp[r] = tj - jsd;
+        d.dsum[r] = sm;
+    }
+}
+
+// argmin / stats / commit-or-rollback / next scan state.  One block.
+__global__ __launch_bounds__(WIDE_THREADS) void finalize_kernel(SelDev d) {
+    __shared__ double scratch[32];
+    __shared__ int s_go;
+    SelCtl *ctl = d.ctl;
+    const uint32_t kind = ctl->ev_kind;
+    if (kind == 0 || ctl->status != SEL_RUN) return;
+    const int tid = threadIdx.x;
+    const uint32_t n = ctl->ev_n;
+
+    // argmin with strict '<' from 1e6, earliest index on ties (records.rs:231,246-249);
+    // NaN never wins a '<'.  Three fixed-tree reductions: min value, its first
+    // index, and the runner-up (for the ambiguity check).
+    bool risky = false;
+    double best = 1e6;
+    for (uint32_t r = tid; r < n; r += WIDE_THREADS) {
+        const double v = d.dtmp[r];
+        if (sum_risky(d.dsum[r], d.B)) risky = true;
+        if (v < best) best = v;
+    }
+    const double dmin = dvs_block_min(best, scratch);
+    double fi = 4294967295.0;
+    for (uint32_t r = tid; r < n; r += WIDE_THREADS)
+        if (dmin < 1e6 && d.dtmp[r] == dmin) fi = fmin(fi, double(r));
+    const double dfirst = dvs_block_min(fi, scratch);
+    uint32_t lowest = (dfirst < 4294967295.0) ? uint32_t(dfirst) : 0u;  // nothing below 1e6 -> 0
+    double second = 1e6;
+    for (uint32_t r = tid; r < n; r += WIDE_THREADS) {
+        const double v = d.dtmp[r];
+        if (r != lowest && v < second) second = v;
+    }
+    const double dsecond = dvs_block_min(second, scratch);
+    const int any_risky = __syncthreads_or(risky ? 1 : 0);
+
+    // mean / std / cov of delta_jsd (records.rs:156-172)
+    double acc = 0.0;
+    for (uint32_t r = tid; r < n; r += WIDE_THREADS) acc += d.dtmp[r];
+    const double mean = dvs_block_sum(acc, scratch) / double(n);
+    acc = 0.0;
+    for (uint32_t r = tid; r < n; r += WIDE_THREADS) {
+        const double t = d.dtmp[r] - mean;
+        acc += t * t;
+    }
+    const double sd = sqrt(dvs_block_sum(acc, scratch) / (double(n) - 1.0));
+    const double cov = sd / mean;
+
+    if (tid == 0) {
+        int go = 1;  // 1 commit, 0 rollback, -1 stop for the arbiter
+        const uint32_t forced = ctl->forced;
+        const double band = sel_band(kind == 2 ? ctl->t_total_jsd + ctl->t_sum_entropy / double(n)
+                                               : ctl->total_jsd + ctl->sum_entropy / double(n),
+                                     d.B);
+        const bool forced_fin = forced == FORCE_COMMIT || forced == FORCE_ROLLBACK;
+        if (forced_fin) {
+            go = forced == FORCE_COMMIT ? 1 : 0;
+            if (ctl->forced_lowest != 0xFFFFFFFFu) lowest = ctl->forced_lowest;
+            ctl->forced = FORCE_NONE;
+            ctl->forced_lowest = 0xFFFFFFFFu;
+        } else {
+            bool tie = any_risky || ctl->ev_risky;
+            if (n > 1 && dsecond - dmin <= band && dsecond < 1e6) tie = true;  // argmin ambiguous
+            if (kind == 2) {
+                const double a = ctl->stat == DVS_STAT_STDEV ? sd : cov;
+                const double b = ctl->stat == DVS_STAT_STDEV ? ctl->std_delta : ctl->cov_delta;
+                // every delta_jsd carries an error <= band, so std moves by <= ~band and
+                // cov = std / mean by ~ band (1 + |cov|) / |mean|; NaN compares false
+                const double mm = fmin(fabs(mean), fabs(ctl->mean_delta));
+                const double sband = ctl->stat == DVS_STAT_STDEV
+                                         ? 4.0 * band
+                                         : 4.0 * band * (1.0 + fmax(fabs(a), fabs(b))) / fmax(mm, 1e-300);
+                if (fabs(a - b) <= sband) tie = true;
+                go = (a > b) ? 1 : 0;
+            }
+            if (tie) {
+                ctl->status = SEL_ARBITER;
+                ctl->arb_stage = ARB_FINALIZE;
+                ctl->arb_pos = ctl->cursor - 1;
+                go = -1;
+            }
+        }
+        if (go == 1) {
+            if (kind == 2) {
+                ctl->sum_entropy = ctl->t_sum_entropy;
+                ctl->total_jsd = ctl->t_total_jsd;
+                d.ord[n - 1] = n - 1;
+                const uint32_t lab = d.mLabel[n - 1];
+                if (lab < d.nlabels) d.inset[lab] = 1;
+                ctl->size = n;
+                ctl->n_accepts++;
+            }
+            ctl->lowest = lowest;
+            ctl->mean_delta = mean;
+            ctl->std_delta = sd;
+            ctl->cov_delta = cov;
+            ctl->band = band;
+        }
+        s_go = go;
+    }
+    __syncthreads();
+    const int go = s_go;
+    if (go < 0) return;
+    if (go == 1) {
+        for (uint32_t r = tid; r < n; r += WIDE_THREADS) d.mDelta[r] = d.dtmp[r];
+        if (kind == 2)
+            for (uint64_t i = tid; i < d.B; i += WIDE_THREADS) d.S[i] = d.Stmp[i];
+    }
+    __syncthreads();
+    // state for the next scan: b_i = (S_i - low_i) / size, thresholds
+    const uint32_t sz = ctl->size;
+    const uint32_t low_slot = d.ord[ctl->lowest];
+    const double *low = d.M + uint64_t(low_slot) * d.B;
+    const double dsize = double(sz);
+    for (uint64_t i = tid; i < d.B; i += WIDE_THREADS) d.base[i] = (d.S[i] - low[i]) / dsize;
+    if (tid == 0) {
+        ctl->he_base = ctl->sum_entropy - d.mH[low_slot];
+        ctl->thr = ctl->total_jsd + DVS_EPS;
+        ctl->ev_kind = 0;
+        ctl->ev_risky = 0;
+        ctl->event_pos = SEL_NONE;
+        if (ctl->cursor >= ctl->npos) ctl->status = SEL_DONE;
+        ctl_next_window(ctl);
+    }
+}
+
+// delta_jsd of every query row against the set (SummedRecordsWrapper.delta_jsd,
+// src/records_py.rs:111-120 -> records.rs:70-84).  One block per query.
+template <typename T>
+__global__ __launch_bounds__(LOO_THREADS) void score_kernel(SelDev d, const T *__restrict__ qmat,
+                                                          const uint32_t *__restrict__ qtotals,
+                                                          const double *__restrict__ qH,
+                                                          const uint32_t *__restrict__ qlabels,
+                                                          double *__restrict__ out) {
+    __shared__ double scratch[32];
+    const SelCtl *ctl = d.ctl;
+    const uint32_t q = blockIdx.x;
+    const uint32_t tot_u = qtotals[q];
+    if (tot_u == 0) {
+        if (threadIdx.x == 0) out[q] = NAN;
+        return;
+    }
+    if (qlabels) {
+        const uint32_t lab = qlabels[q];
+        if (lab < d.nlabels && d.inset[lab]) {
+            if (threadIdx.x == 0) out[q] = 0.0;
+            return;
+        }
+    }
+    const double tot = double(tot_u);
+    const T *rp = qmat + uint64_t(q) * d.B;
+    const uint32_t low_slot = d.ord[ctl->lowest];
+    const double *low = d.M + uint64_t(low_slot) * d.B;
+    const double dsize = double(ctl->size);
+    Ent e;
+    for (uint64_t i = threadIdx.x; i < d.B; i += LOO_THREADS)
+        e.add((d.S[i] - low[i] + cand_freq(rp, i, tot)) / dsize);
+    const double h = dvs_block_sum(e.h, scratch);
+    const double mn = dvs_block_min(e.mn, scratch);
+    if (threadIdx.x == 0) {
+        const double mean_entropy = (ctl->sum_entropy - d.mH[low_slot] + qH[q]) / dsize;
+        out[q] = (mn < 0.0) ? NAN : h - mean_entropy;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ host side
+static void sel_free(dvs_select *s) {
+    if (!s) return;
+    void *ptrs[] = {s->dev.ctl, s->dev.S, s->dev.Stmp, s->dev.base, s->dev.cand, s->dev.M,
+                    s->dev.mH, s->dev.mDelta, s->dev.dtmp, s->dev.dsum, s->dev.mLabel, s->dev.mPos,
+                    s->dev.ord, s->dev.inset, s->dev.wg_rows, (void *)s->dev.order, (void *)s->dev.labels};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (s->h_ctl) (void)hipHostFree(s->h_ctl);
+    for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
+    dvs_select_arbiter_free(s);
+    delete s;
+}
+
+template <typename T>
+static void launch_iteration(dvs_ctx *ctx, dvs_select *s, const T *mat, bool with_scan) {
+    const SelDev &d = s->dev;
+    if (with_scan) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (s->time_scan) {
+            if (s->ev_used + 2 > s->ev_pool.size()) {
+                hipEvent_t a = nullptr, b = nullptr;
+                (void)hipEventCreate(&a);
+                (void)hipEventCreate(&b);
+                s->ev_pool.push_back(a);
+                s->ev_pool.push_back(b);
+            }
+            e0 = s->ev_pool[s->ev_used];
+            e1 = s->ev_pool[s->ev_used + 1];
+            s->ev_used += 2;
+            (void)hipEventRecord(e0, ctx->stream);
+        }
+        hipLaunchKernelGGL((scan_kernel<T>), dim3(s->scan_grid), dim3(SCAN_THREADS), s->scan_lds,
+                           ctx->stream, d.ctl, mat, d.totals, d.rowH, d.order, d.labels, d.inset,
+                           d.nlabels, d.base, d.wg_rows, d.B, s->base_in_lds ? 1 : 0);
+        if (s->time_scan) (void)hipEventRecord(e1, ctx->stream);
+        hipLaunchKernelGGL((resolve_kernel<T>), dim3(1), dim3(WIDE_THREADS), 0, ctx->stream, d, mat,
+                           s->scan_grid);
+    }
+    hipLaunchKernelGGL(loo_kernel, dim3(s->loo_grid), dim3(LOO_THREADS), 0, ctx->stream, d);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(WIDE_THREADS), 0, ctx->stream, d);
+}
+
+static int sel_poll(dvs_ctx *ctx, dvs_select *s) {
+    DVS_HIP(ctx, hipMemcpyAsync(s->h_ctl, s->dev.ctl, sizeof(SelCtl), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DVS_OK;
+}
+
+template <typename T>
+static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat) {
+    // the loo grid must cover the largest set a batch can reach
+    for (;;) {
+        int rc = sel_poll(ctx, s);
+        if (rc) return rc;
+        const SelCtl &c = *s->h_ctl;
+        if (s->time_scan && s->ev_used) {  // the poll synchronised the stream: events are complete
+            for (size_t i = 0; i + 1 < s->ev_used; i += 2) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, s->ev_pool[i], s->ev_pool[i + 1]) == hipSuccess)
+                    s->scan_ms += ms;
+                s->scan_launches++;
+            }
+            s->ev_used = 0;
+        }
+        if (c.status == SEL_DONE) return DVS_OK;
+        if (c.status == SEL_ARBITER) {
+            if (s->params.flags & DVS_SELECT_NO_ARBITER)
+                return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED,
+                                     "ambiguous decision at stream position %llu (stage %u): "
+                                     "|score - threshold| within the rounding band",
+                                     (unsigned long long)c.arb_pos, c.arb_stage);
+            rc = dvs_select_arbitrate(ctx, s);
+            if (rc) return rc;
+            if (s->mat_kind == 0)
+                launch_iteration<T>(ctx, s, mat, s->h_ctl->arb_stage == ARB_RESOLVE);
+            continue;
+        }
+        if (c.status != SEL_RUN)
+            return dvs_set_error(ctx, DVS_ERR_RUNTIME, "selection engine in state %u", c.status);
+        for (int i = 0; i < s->batch; i++) launch_iteration<T>(ctx, s, mat, true);
+        DVS_HIP(ctx, hipGetLastError());
+    }
+}
+
+template <typename T>
+static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat, const std::vector<uint64_t> &seeds) {
+    uint64_t *d_seed = nullptr;
+    DVS_HIP(ctx, hipMalloc(&d_seed, seeds.size() * sizeof(uint64_t)));
+    DVS_HIP(ctx, hipMemcpyAsync(d_seed, seeds.data(), seeds.size() * sizeof(uint64_t),
+                                hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL((seed_kernel<T>), dim3(uint32_t(seeds.size())), dim3(LOO_THREADS), 0,
+                       ctx->stream, s->dev, mat, d_seed);
+    hipLaunchKernelGGL(rebuild_kernel, dim3(1), dim3(WIDE_THREADS), 0, ctx->stream, s->dev);
+    launch_iteration<T>(ctx, s, mat, false);  // loo + finalize of the initial set
+    DVS_HIP(ctx, hipGetLastError());
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_seed);
+    return sel_run_loop<T>(ctx, s, mat);
+}
+
+extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t *order,
+                              const uint32_t *labels, uint64_t npos,
+                              const dvs_select_params *params, dvs_select **out) {
+    if (!ctx || !m || !params || !out) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    *out = nullptr;
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t B = m->nbins;
+    if (!order && npos > m->nrows)
+        return dvs_set_error(ctx, DVS_ERR_VALUE, "npos %llu exceeds the matrix rows %u",
+                             (unsigned long long)npos, m->nrows);
+    uint32_t n_seed = params->n_seed;
+    uint32_t max_size = params->max_size;
+    if (params->mode == DVS_MODE_SET) n_seed = uint32_t(npos);
+    // src/records.rs:323-325, 404-410, 369-371, 464-469
+    if (npos < n_seed)
+        return dvs_set_error(ctx, DVS_ERR_VALUE, "The number of sequences %llu is < n %u",
+                             (unsigned long long)npos, n_seed);
+    if (params->mode == DVS_MODE_MAX && npos <= max_size) max_size = uint32_t(npos);  // :412-416
+    if (params->mode != DVS_MODE_MAX) max_size = n_seed;
+
+    // usable seeds: rows with at least one valid k-mer (records.rs:299-306)
+    std::vector<uint32_t> h_totals(m->nrows);
+    DVS_HIP(ctx, hipMemcpyAsync(h_totals.data(), m->d_totals, size_t(m->nrows) * 4,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t nlabels = 0;
+    for (uint64_t p = 0; p < npos; p++) {
+        const uint32_t row = order ? order[p] : uint32_t(p);
+        if (row >= m->nrows)
+            return dvs_set_error(ctx, DVS_ERR_VALUE, "order[%llu] = %u out of range",
+                                 (unsigned long long)p, row);
+        const uint32_t lab = labels ? labels[p] : row;
+        if (lab != 0xFFFFFFFFu) nlabels = std::max(nlabels, lab + 1);
+    }
+    std::vector<uint64_t> seeds;
+    for (uint64_t p = 0; p < n_seed; p++) {
+        const uint32_t row = order ? order[p] : uint32_t(p);
+        if (h_totals[row] > 0) seeds.push_back(p);
+    }
+    if (seeds.empty()) return dvs_set_error(ctx, DVS_ERR_VALUE, "records cannot be empty");  // :28-30
+    if (seeds.size() < 2) return dvs_set_error(ctx, DVS_ERR_VALUE, "must have > 1 KmerSeq");  // :227-230
+
+    dvs_select *s = new dvs_select();
+    s->params = *params;
+    s->params.n_seed = n_seed;
+    s->params.max_size = max_size;
+    s->mat = m;
+    s->mat_kind = m->kind;
+    s->npos = npos;
+    s->h_order.assign(order ? order : nullptr, order ? order + npos : nullptr);
+    s->h_labels.assign(labels ? labels : nullptr, labels ? labels + npos : nullptr);
+    SelDev &d = s->dev;
+    d.B = B;
+    d.nlabels = nlabels;
+    d.totals = m->d_totals;
+    d.rowH = m->d_entropy;
+    const uint32_t cap = std::max<uint32_t>(std::max<uint32_t>(max_size, uint32_t(seeds.size())) + 1, 2);
+    s->cap = cap;
+    const size_t need = size_t(cap) * B * 8 + 5 * B * 8 + size_t(npos) * 8 + nlabels + (1 << 20);
+    size_t free_b = 0, total_b = 0;
+    DVS_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+    if (need > free_b) {
+        delete s;
+        return dvs_set_error(ctx, DVS_ERR_NOMEM, "selection state needs %zu bytes, %zu free", need,
+                             free_b);
+    }
+    // launch geometry
+    s->base_in_lds = B * 8 <= 128 * 1024 && B * 8 + 1024 <= ctx->lds_per_block;
+    s->scan_lds = s->base_in_lds ? B * 8 : 0;
+    const uint32_t wg_per_cu = s->base_in_lds ? std::max<uint32_t>(1, uint32_t((160 * 1024) / (B * 8 + 512))) : 8;
+    s->scan_grid = std::max<uint32_t>(1, uint32_t(ctx->n_cu) * std::min<uint32_t>(wg_per_cu, 5));
+    s->loo_grid = cap;
+    s->batch = 16;
+    s->time_scan = ctx->timing;
+    if (s->scan_lds > 48 * 1024) {
+        const void *fn = m->kind == 0 ? reinterpret_cast<const void *>(scan_kernel<uint32_t>)
+                                      : reinterpret_cast<const void *>(scan_kernel<double>);
+        DVS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         int(s->scan_lds)));
+    }
+
+#define SEL_ALLOC(ptr, bytes)                                        \
+    do {                                                             \
+        hipError_t e__ = hipMalloc((void **)&(ptr), (bytes));        \
+        if (e__ != hipSuccess) {                                     \
+            sel_free(s);                                             \
+            return dvs_hip_fail(ctx, e__, "hipMalloc(" #ptr ")");    \
+        }                                                            \
+    } while (0)
+    SEL_ALLOC(d.ctl, sizeof(SelCtl));
+    SEL_ALLOC(d.S, B * 8);
+    SEL_ALLOC(d.Stmp, B * 8);
+    SEL_ALLOC(d.base, B * 8);
+    SEL_ALLOC(d.cand, B * 8);
+    SEL_ALLOC(d.M, size_t(cap) * B * 8);
+    SEL_ALLOC(d.mH, size_t(cap) * 8);
+    SEL_ALLOC(d.mDelta, size_t(cap) * 8);
+    SEL_ALLOC(d.dtmp, size_t(cap) * 8);
+    SEL_ALLOC(d.dsum, size_t(cap) * 8);
+    SEL_ALLOC(d.mLabel, size_t(cap) * 4);
+    SEL_ALLOC(d.mPos, size_t(cap) * 8);
+    SEL_ALLOC(d.ord, size_t(cap) * 4);
+    SEL_ALLOC(d.inset, std::max<size_t>(nlabels, 1));
+    SEL_ALLOC(d.wg_rows, size_t(s->scan_grid) * 4);
+    if (order) {
+        SEL_ALLOC(d.order, size_t(npos) * 4);
+        DVS_HIP(ctx, hipMemcpyAsync((void *)d.order, order, size_t(npos) * 4, hipMemcpyHostToDevice,
+                                    ctx->stream));
+    }
+    if (labels) {
+        SEL_ALLOC(d.labels, size_t(npos) * 4);
+        DVS_HIP(ctx, hipMemcpyAsync((void *)d.labels, labels, size_t(npos) * 4,
+                                    hipMemcpyHostToDevice, ctx->stream));
+    }
+#undef SEL_ALLOC
+    DVS_HIP(ctx, hipMemsetAsync(d.inset, 0, std::max<size_t>(nlabels, 1), ctx->stream));
+    DVS_HIP(ctx, hipMemsetAsync(d.wg_rows, 0, size_t(s->scan_grid) * 4, ctx->stream));
+    hipError_t he = hipHostMalloc((void **)&s->h_ctl, sizeof(SelCtl), hipHostMallocDefault);
+    if (he != hipSuccess) {
+        sel_free(s);
+        return dvs_hip_fail(ctx, he, "hipHostMalloc(ctl)");
+    }
+
+    SelCtl c;
+    std::memset(&c, 0, sizeof c);
+    c.cursor = n_seed;
+    c.npos = npos;
+    c.event_pos = SEL_NONE;
+    const uint32_t wdef = params->window ? params->window : 4096;
+    c.window_min = wdef;
+    c.window_max = std::max<uint32_t>(wdef, s->scan_grid * (SCAN_THREADS / 64) * 8);
+    c.window = wdef;
+    c.status = (npos > n_seed) ? SEL_RUN : SEL_RUN;  // finalize flips to DONE when cursor >= npos
+    c.size = uint32_t(seeds.size());
+    c.mode = params->mode;
+    c.max_size = max_size;
+    c.stat = params->stat;
+    c.forced = FORCE_NONE;
+    c.forced_lowest = 0xFFFFFFFFu;
+    c.band = 0.0;
+    DVS_HIP(ctx, hipMemcpyAsync(d.ctl, &c, sizeof c, hipMemcpyHostToDevice, ctx->stream));
+    s->seed_positions = seeds;
+
+    int rc = (m->kind == 0) ? sel_start<uint32_t>(ctx, s, m->d_counts, seeds)
+                            : sel_start<double>(ctx, s, m->d_freqs, seeds);
+    if (rc) {
+        sel_free(s);
+        return rc;
+    }
+    *out = s;
+    return DVS_OK;
+}
+
+extern "C" void dvs_select_destroy(dvs_select *s) { sel_free(s); }
+
+extern "C" int dvs_select_get_summary(dvs_ctx *ctx, const dvs_select *s, dvs_select_summary *out) {
+    if (!s || !out) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    const SelCtl &c = *s->h_ctl;
+    std::memset(out, 0, sizeof *out);
+    out->size = c.size;
+    out->lowest_index = c.lowest;
+    out->total_jsd = c.total_jsd;
+    out->mean_delta_jsd = c.mean_delta;
+    out->std_delta_jsd = c.std_delta;
+    out->cov_delta_jsd = c.cov_delta;
+    out->summed_entropies = c.sum_entropy;
+    out->rows_scored = c.rows_scored;
+    out->rows_rechecked = c.rows_rechecked;
+    out->n_windows = c.n_windows;
+    out->n_events = c.n_events;
+    out->n_accepts = c.n_accepts;
+    out->n_arbitrated = s->n_arbitrated;
+    out->scan_ms = s->scan_ms;
+    out->scan_launches = s->scan_launches;
+    return DVS_OK;
+}
+
+extern "C" int dvs_select_get_members(dvs_ctx *ctx, const dvs_select *s, uint64_t *positions,
+                                      uint32_t *labels, double *delta_jsd, double *entropy,
+                                      double *freqs) {
+    if (!s) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    const uint32_t n = s->h_ctl->size;
+    const uint64_t B = s->dev.B;
+    std::vector<uint32_t> ord(n), lab(s->cap);
+    std::vector<uint64_t> pos(s->cap);
+    std::vector<double> mh(s->cap);
+    DVS_HIP(ctx, hipMemcpy(ord.data(), s->dev.ord, size_t(n) * 4, hipMemcpyDeviceToHost));
+    DVS_HIP(ctx, hipMemcpy(lab.data(), s->dev.mLabel, size_t(s->cap) * 4, hipMemcpyDeviceToHost));
+    DVS_HIP(ctx, hipMemcpy(pos.data(), s->dev.mPos, size_t(s->cap) * 8, hipMemcpyDeviceToHost));
+    DVS_HIP(ctx, hipMemcpy(mh.data(), s->dev.mH, size_t(s->cap) * 8, hipMemcpyDeviceToHost));
+    if (delta_jsd)  // mDelta is indexed by member order already
+        DVS_HIP(ctx, hipMemcpy(delta_jsd, s->dev.mDelta, size_t(n) * 8, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t sl = ord[i];
+        if (positions) positions[i] = pos[sl];
+        if (labels) labels[i] = lab[sl];
+        if (entropy) entropy[i] = mh[sl];
+        if (freqs)
+            DVS_HIP(ctx, hipMemcpy(freqs + uint64_t(i) * B, s->dev.M + uint64_t(sl) * B, B * 8,
+                                   hipMemcpyDeviceToHost));
+    }
+    return DVS_OK;
+}
+
+extern "C" int dvs_select_delta_jsd(dvs_ctx *ctx, const dvs_select *s, const dvs_matrix *q,
+                                    const uint32_t *qlabels, double *out) {
+    if (!s || !q || !out) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (q->nbins != s->dev.B)
+        return dvs_set_error(ctx, DVS_ERR_VALUE, "query matrix has %llu bins, the set %llu",
+                             (unsigned long long)q->nbins, (unsigned long long)s->dev.B);
+    if (q->nrows == 0) return DVS_OK;
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    double *d_out = nullptr;
+    uint32_t *d_lab = nullptr;
+    DVS_HIP(ctx, hipMalloc(&d_out, size_t(q->nrows) * 8));
+    if (qlabels) {
+        DVS_HIP(ctx, hipMalloc(&d_lab, size_t(q->nrows) * 4));
+        DVS_HIP(ctx, hipMemcpyAsync(d_lab, qlabels, size_t(q->nrows) * 4, hipMemcpyHostToDevice,
+                                    ctx->stream));
+    }
+    if (q->kind == 0)
+        hipLaunchKernelGGL((score_kernel<uint32_t>), dim3(q->nrows), dim3(LOO_THREADS), 0, ctx->stream,
+                           s->dev, q->d_counts, q->d_totals, q->d_entropy, d_lab, d_out);
+    else
+        hipLaunchKernelGGL((score_kernel<double>), dim3(q->nrows), dim3(LOO_THREADS), 0, ctx->stream,
+                           s->dev, q->d_freqs, q->d_totals, q->d_entropy, d_lab, d_out);
+    DVS_HIP(ctx, hipGetLastError());
+    DVS_HIP(ctx, hipMemcpyAsync(out, d_out, size_t(q->nrows) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_out);
+    if (d_lab) (void)hipFree(d_lab);
+    return DVS_OK;
+}

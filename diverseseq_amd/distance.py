@@ -1,0 +1,92 @@
+"""Host side of the distance path: mirrors diverse_seq/distance.py's functions
+(mash_sketches :178-227, mash_distances :119-175, mash_distance :230-291,
+euclidean_distances :294-332) and the strided chunks of
+diverse_seq/cluster.py:607-644, with the arithmetic in libdvs_hip.so."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, engine
+
+_U32_MAX = 0xFFFFFFFF
+
+
+def sketch_batch(seqs, k: int, sketch_size: int, num_states: int = 4,
+                 mash_canonical: bool = False, ctx: engine.Context | None = None):
+    """bottom-`sketch_size` sketches of a batch -> (uint32 [n, stride], lens uint32 [n]);
+    stride = min(sketch_size, longest possible sketch)"""
+    ctx = ctx or engine.default_context()
+    data, offsets = engine.concat(seqs)
+    n = len(seqs)
+    lens_in = np.diff(offsets.astype(np.int64)) if n else np.zeros(0, dtype=np.int64)
+    longest = int(max(0, (lens_in.max() if n else 0) - k + 1))
+    if sketch_size < 0 or sketch_size > _U32_MAX:
+        raise OverflowError("sketch_size out of range for u32")  # pyo3 usize/u32 extraction
+    stride = max(1, min(int(sketch_size), longest))
+    sk = np.zeros((n, stride), dtype=np.uint32)
+    lens = np.zeros(n, dtype=np.uint32)
+    if n and sketch_size:
+        ctx.check(ctx._L.dvs_mash_sketch(ctx._h, data.ctypes.data_as(C.c_void_p), 0,
+                                         _lib.ptr(offsets, C.c_uint64), n, k, stride, num_states,
+                                         int(bool(mash_canonical)), _lib.ptr(sk, C.c_uint32),
+                                         _lib.ptr(lens, C.c_uint32)))
+    return sk, lens
+
+
+def mash_sketches(seqs, k: int, sketch_size: int, num_states: int = 4,
+                  mash_canonical: bool = False) -> list[list[int]]:
+    sk, lens = sketch_batch(seqs, k, sketch_size, num_states, mash_canonical)
+    return [sk[i, : int(lens[i])].tolist() for i in range(len(seqs))]
+
+
+def distances_from_sketches(sk: np.ndarray, lens: np.ndarray, k: int, sketch_size: int, *,
+                            row_start: int = 0, row_stride: int = 1, symmetric: bool = True,
+                            out: np.ndarray | None = None,
+                            ctx: engine.Context | None = None) -> np.ndarray:
+    """lower-triangle mash distances for rows row_start, row_start+row_stride, ...
+    (compute_mash_chunk_distances, diverse_seq/cluster.py:640-644)"""
+    ctx = ctx or engine.default_context()
+    sk = np.ascontiguousarray(sk, dtype=np.uint32)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    n = sk.shape[0]
+    dist = np.zeros((n, n), dtype=np.float64) if out is None else out
+    ctx.check(ctx._L.dvs_mash_distances(ctx._h, _lib.ptr(sk, C.c_uint32), sk.shape[1],
+                                        _lib.ptr(lens, C.c_uint32), n, k,
+                                        min(int(sketch_size), _U32_MAX), row_start, row_stride,
+                                        int(symmetric), _lib.ptr(dist, C.c_double)))
+    return dist
+
+
+def mash_distance(left_sketch, right_sketch, k: int, sketch_size: int) -> float:
+    """diverse_seq/distance.py:230-291 for one pair"""
+    l = np.asarray(left_sketch, dtype=np.uint32)
+    r = np.asarray(right_sketch, dtype=np.uint32)
+    stride = max(1, l.size, r.size)
+    sk = np.zeros((2, stride), dtype=np.uint32)
+    sk[1, : l.size] = l  # pair (i=1, j=0): left is row i
+    sk[0, : r.size] = r
+    d = distances_from_sketches(sk, np.array([r.size, l.size], dtype=np.uint32), k, sketch_size)
+    return float(d[1, 0])
+
+
+def mash_distances(seqs, k: int, sketch_size: int, num_states: int = 4,
+                   mash_canonical: bool = False) -> np.ndarray:
+    """diverse_seq/distance.py:119-175: sketches, then the symmetric N x N matrix"""
+    sk, lens = sketch_batch(seqs, k, sketch_size, num_states, mash_canonical)
+    return distances_from_sketches(sk, lens, k, sketch_size)
+
+
+def euclidean_distances(seqs, k: int, num_states: int = 4,
+                        ctx: engine.Context | None = None) -> np.ndarray:
+    """diverse_seq/distance.py:294-332: ||kfreqs_i - kfreqs_j||_2"""
+    ctx = ctx or engine.default_context()
+    m = ctx.build_matrix(seqs, k, num_states)
+    try:
+        dist = np.zeros((m.nrows, m.nrows), dtype=np.float64)
+        ctx.check(ctx._L.dvs_euclidean_distances(ctx._h, m._h, _lib.ptr(dist, C.c_double)))
+        return dist
+    finally:
+        m.close()

@@ -1,0 +1,241 @@
+"""Thin object layer over the C ABI: device context, count matrix, selection.
+
+Host-side plumbing only; every number comes out of libdvs_hip.so.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+
+
+def concat(seqs) -> tuple[np.ndarray, np.ndarray]:
+    """list of byte-like / uint8 arrays -> (concatenated uint8, uint64 offsets[n+1])"""
+    arrs = []
+    for s in seqs:
+        if isinstance(s, (bytes, bytearray, memoryview)):
+            arrs.append(np.frombuffer(s, dtype=np.uint8))
+        else:
+            arrs.append(np.ascontiguousarray(s, dtype=np.uint8).reshape(-1))
+    offsets = np.zeros(len(arrs) + 1, dtype=np.uint64)
+    if arrs:
+        offsets[1:] = np.cumsum([a.size for a in arrs], dtype=np.uint64)
+    total = int(offsets[-1])
+    data = np.concatenate(arrs) if total else np.zeros(16, dtype=np.uint8)
+    return np.ascontiguousarray(data), offsets
+
+
+class Context:
+    """one per process per GPU (dvs_ctx)"""
+
+    def __init__(self, device: int = -1, stream: int | None = None):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        rc = self._L.dvs_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc:
+            _lib.raise_for(rc, None)
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dvs_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int):
+        _lib.raise_for(rc, self._h)
+
+    def sync(self):
+        self.check(self._L.dvs_ctx_sync(self._h))
+
+    def set_timing(self, on: bool):
+        self.check(self._L.dvs_ctx_set_timing(self._h, int(on)))
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(256)
+        ncu, mem = C.c_int(), C.c_uint64()
+        self.check(self._L.dvs_ctx_device_info(self._h, name, 256, C.byref(ncu), C.byref(mem)))
+        return {"name": name.value.decode(), "n_cu": ncu.value, "hbm_bytes": mem.value}
+
+    # ---- matrices -----------------------------------------------------------
+    def build_matrix(self, seqs, k: int, num_states: int = 4) -> "CountMatrix":
+        """k-mer count matrix of host sequences (list of uint8 arrays / bytes)"""
+        data, offsets = concat(seqs)
+        return self.build_matrix_concat(data, offsets, k, num_states)
+
+    def build_matrix_concat(self, data: np.ndarray, offsets: np.ndarray, k: int,
+                            num_states: int = 4) -> "CountMatrix":
+        h = C.c_void_p()
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.check(self._L.dvs_matrix_build(self._h, data.ctypes.data_as(C.c_void_p), 0,
+                                            _lib.ptr(offsets, C.c_uint64), offsets.size - 1, k,
+                                            num_states, C.byref(h)))
+        return CountMatrix(self, h, k, num_states)
+
+    def build_matrix_device(self, dev_ptr: int, offsets: np.ndarray, k: int,
+                            num_states: int = 4) -> "CountMatrix":
+        """sequences already resident in HBM (e.g. a torch uint8 tensor's data_ptr())"""
+        h = C.c_void_p()
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.check(self._L.dvs_matrix_build(self._h, C.c_void_p(dev_ptr), 1,
+                                            _lib.ptr(offsets, C.c_uint64), offsets.size - 1, k,
+                                            num_states, C.byref(h)))
+        return CountMatrix(self, h, k, num_states)
+
+    def matrix_from_freqs(self, freqs: np.ndarray) -> "CountMatrix":
+        f = np.ascontiguousarray(freqs, dtype=np.float64)
+        if f.ndim != 2:
+            raise ValueError("freqs must be 2-D")
+        h = C.c_void_p()
+        self.check(self._L.dvs_matrix_from_freqs(self._h, _lib.ptr(f, C.c_double), f.shape[0],
+                                                 f.shape[1], C.byref(h)))
+        return CountMatrix(self, h, 0, 0)
+
+    def kmer_counts(self, seqs, k: int, num_states: int = 4):
+        """-> (counts uint32 [n, ns^k], totals uint32 [n], entropy f64 [n])"""
+        m = self.build_matrix(seqs, k, num_states)
+        try:
+            return m.counts(), m.totals(), m.entropy()
+        finally:
+            m.close()
+
+
+class CountMatrix:
+    """N x num_states^k matrix resident in HBM (dvs_matrix)"""
+
+    def __init__(self, ctx: Context, handle, k: int, num_states: int):
+        self.ctx, self._h, self.k, self.num_states = ctx, handle, k, num_states
+        L = ctx._L
+        self.nrows = int(L.dvs_matrix_nrows(handle))
+        self.nbins = int(L.dvs_matrix_nbins(handle))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._L.dvs_matrix_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def counts(self, row0: int = 0, nrows: int | None = None) -> np.ndarray:
+        nrows = self.nrows - row0 if nrows is None else nrows
+        out = np.zeros((nrows, self.nbins), dtype=np.uint32)
+        self.ctx.check(self.ctx._L.dvs_matrix_get_counts(self.ctx._h, self._h, row0, nrows,
+                                                         _lib.ptr(out, C.c_uint32)))
+        return out
+
+    def totals(self) -> np.ndarray:
+        out = np.zeros(self.nrows, dtype=np.uint32)
+        self.ctx.check(self.ctx._L.dvs_matrix_get_totals(self.ctx._h, self._h,
+                                                         _lib.ptr(out, C.c_uint32)))
+        return out
+
+    def entropy(self) -> np.ndarray:
+        out = np.zeros(self.nrows, dtype=np.float64)
+        self.ctx.check(self.ctx._L.dvs_matrix_get_entropy(self.ctx._h, self._h,
+                                                          _lib.ptr(out, C.c_double)))
+        return out
+
+    def dev_counts(self) -> int:
+        return int(self.ctx._L.dvs_matrix_dev_counts(self._h) or 0)
+
+    # ---- selection -----------------------------------------------------------
+    def select(self, mode: int, n_seed: int, *, max_size: int = 0, stat: int = _lib.STAT_STDEV,
+               order=None, labels=None, npos: int | None = None, window: int = 0,
+               flags: int = 0) -> "Selection":
+        order_a = None if order is None else np.ascontiguousarray(order, dtype=np.uint32)
+        labels_a = None if labels is None else np.ascontiguousarray(labels, dtype=np.uint32)
+        if npos is None:
+            npos = order_a.size if order_a is not None else self.nrows
+        p = _lib.SelectParams(mode, n_seed, max_size, stat, window, flags)
+        h = C.c_void_p()
+        self.ctx.check(self.ctx._L.dvs_select_run(self.ctx._h, self._h,
+                                                  _lib.ptr(order_a, C.c_uint32),
+                                                  _lib.ptr(labels_a, C.c_uint32), npos,
+                                                  C.byref(p), C.byref(h)))
+        return Selection(self, h)
+
+    def nmost(self, n: int, **kw) -> "Selection":
+        return self.select(_lib.MODE_NMOST, n, **kw)
+
+    def max_divergent(self, min_size: int, max_size: int, stat: str = "stdev", **kw) -> "Selection":
+        st = _lib.STAT_STDEV if stat == "stdev" else _lib.STAT_COV  # src/lib.rs:116-120
+        return self.select(_lib.MODE_MAX, min_size, max_size=max_size, stat=st, **kw)
+
+    def as_set(self, **kw) -> "Selection":
+        return self.select(_lib.MODE_SET, 0, **kw)
+
+
+@dataclass
+class Members:
+    positions: np.ndarray
+    labels: np.ndarray
+    delta_jsd: np.ndarray
+    entropy: np.ndarray
+    kfreqs: np.ndarray | None
+
+
+class Selection:
+    """a SummedRecords set living on the device (dvs_select)"""
+
+    def __init__(self, matrix: CountMatrix, handle):
+        self.matrix, self.ctx, self._h = matrix, matrix.ctx, handle
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._L.dvs_select_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def summary(self) -> _lib.SelectSummary:
+        s = _lib.SelectSummary()
+        self.ctx.check(self.ctx._L.dvs_select_get_summary(self.ctx._h, self._h, C.byref(s)))
+        return s
+
+    def members(self, with_freqs: bool = True) -> Members:
+        n = self.summary().size
+        pos = np.zeros(n, dtype=np.uint64)
+        lab = np.zeros(n, dtype=np.uint32)
+        dl = np.zeros(n, dtype=np.float64)
+        en = np.zeros(n, dtype=np.float64)
+        fr = np.zeros((n, self.matrix.nbins), dtype=np.float64) if with_freqs else None
+        self.ctx.check(self.ctx._L.dvs_select_get_members(
+            self.ctx._h, self._h, _lib.ptr(pos, C.c_uint64), _lib.ptr(lab, C.c_uint32),
+            _lib.ptr(dl, C.c_double), _lib.ptr(en, C.c_double), _lib.ptr(fr, C.c_double)))
+        return Members(pos, lab, dl, en, fr)
+
+    def delta_jsd(self, queries: CountMatrix, qlabels=None) -> np.ndarray:
+        out = np.zeros(queries.nrows, dtype=np.float64)
+        ql = None if qlabels is None else np.ascontiguousarray(qlabels, dtype=np.uint32)
+        self.ctx.check(self.ctx._L.dvs_select_delta_jsd(self.ctx._h, self._h, queries._h,
+                                                        _lib.ptr(ql, C.c_uint32),
+                                                        _lib.ptr(out, C.c_double)))
+        return out
+
+
+_default_ctx: Context | None = None
+
+
+def default_context() -> Context:
+    """process-wide context on the current device (created on first use)"""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx

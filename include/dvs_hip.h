@@ -1,0 +1,181 @@
+/*
+ * dvs_hip.h -- C ABI of libdvs_hip.so: the MI355X (gfx950) implementation of
+ * DiverseSeq's k-mer / delta-JSD / mash hot path.
+ *
+ * This is the drop-in boundary.  It replaces the PyO3 extension module
+ * `diverse_seq._dvs` (reference src/lib.rs:175-189): every entry point below
+ * names the reference interface it stands in for.  Plain pointers and sizes
+ * only; no torch / HIP types in the signatures (a HIP stream crosses as
+ * void*).  All functions return 0 (DVS_OK) or a DVS_ERR_* code;
+ * dvs_last_error() returns the message (for DVS_ERR_VALUE it is the
+ * reference's panic text, which src/lib.rs:36-57 turns into ValueError).
+ *
+ * Data convention (reference diverse_seq/util.py:41-45, src/distance.rs:6-8):
+ * a sequence is one byte per base holding the cogent3 alphabet index
+ * (DNA: T0 C1 A2 G3); any byte >= num_states is a gap/ambiguity and
+ * invalidates every k-mer window that contains it.  A batch of sequences is
+ * one concatenated byte buffer plus nseq+1 uint64 offsets.
+ *
+ * Threading: one dvs_ctx per process per GPU; a ctx is not thread-safe.
+ */
+#ifndef DVS_HIP_H
+#define DVS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVS_ABI_VERSION 1
+
+#define DVS_OK 0
+#define DVS_ERR_VALUE 1       /* the reference would panic -> python ValueError */
+#define DVS_ERR_RUNTIME 2     /* HIP failure / no device */
+#define DVS_ERR_NOMEM 3
+#define DVS_ERR_UNSUPPORTED 4 /* shape outside what the device path handles */
+#define DVS_ERR_ZERODIV 5     /* python ZeroDivisionError (distance.py:283) */
+
+typedef struct dvs_ctx dvs_ctx;       /* device, stream, scratch */
+typedef struct dvs_matrix dvs_matrix; /* N x num_states^k count (or freq) matrix in HBM */
+typedef struct dvs_select dvs_select; /* a SummedRecords set + the greedy engine */
+
+/* ---- context ------------------------------------------------------------ */
+int dvs_abi_version(void);
+/* device < 0: current device.  stream: a hipStream_t to launch on, or NULL for
+ * a stream owned by the ctx. */
+int dvs_ctx_create(int device, void *stream, dvs_ctx **out);
+void dvs_ctx_destroy(dvs_ctx *ctx);
+/* message of the last failing call on ctx (ctx == NULL: last ctx_create failure) */
+const char *dvs_last_error(const dvs_ctx *ctx);
+int dvs_ctx_sync(dvs_ctx *ctx);
+/* name, CU count and HBM bytes of the ctx's device */
+int dvs_ctx_device_info(dvs_ctx *ctx, char *name, size_t name_len, int *n_cu,
+                        uint64_t *hbm_bytes);
+
+/* ---- k-mer count matrix ------------------------------------------------- *
+ * replaces SeqRecord::to_kcounts / to_kmerseq (src/record.rs:124-141),
+ * count_kmers (:41-84), count_monomers (:31-39), entropy (:86-106) and
+ * LazySeq.get_kcounts / get_kfreqs (:247-262).
+ *
+ * Builds, on the device, row r = the k-mer histogram of sequence r (uint32),
+ * plus per-row total (number of valid k-mers) and Shannon entropy (bits) of
+ * the row's frequency vector.  `seqs` is a HOST pointer when seqs_on_device
+ * is 0 (it is copied to HBM), else a 16-byte-aligned DEVICE pointer that must
+ * stay valid until the call returns; `offsets` is always a host array. */
+int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device,
+                     const uint64_t *offsets, uint32_t nseq, uint32_t k,
+                     uint32_t num_states, dvs_matrix **out);
+/* rows are frequency vectors (the members of SummedRecordsResult objects being
+ * merged: get_kmerseqs_and_init_summed_records, src/records.rs:344-360).
+ * DVS_ERR_VALUE if a row fails the reference's sum-to-one check
+ * (src/record.rs:99-104). */
+int dvs_matrix_from_freqs(dvs_ctx *ctx, const double *freqs, uint32_t nrows,
+                          uint64_t nbins, dvs_matrix **out);
+void dvs_matrix_destroy(dvs_matrix *m);
+uint32_t dvs_matrix_nrows(const dvs_matrix *m);
+uint64_t dvs_matrix_nbins(const dvs_matrix *m);
+/* device pointers (for zero-copy hand-off to the host framework) */
+const void *dvs_matrix_dev_counts(const dvs_matrix *m);  /* uint32 [nrows x nbins] or NULL */
+const void *dvs_matrix_dev_totals(const dvs_matrix *m);  /* uint32 [nrows] */
+const void *dvs_matrix_dev_entropy(const dvs_matrix *m); /* double [nrows] */
+/* copies to host: counts rows [row0, row0+nrows) */
+int dvs_matrix_get_counts(dvs_ctx *ctx, const dvs_matrix *m, uint32_t row0,
+                          uint32_t nrows, uint32_t *out);
+int dvs_matrix_get_totals(dvs_ctx *ctx, const dvs_matrix *m, uint32_t *out);
+int dvs_matrix_get_entropy(dvs_ctx *ctx, const dvs_matrix *m, double *out);
+/* host one-shot: counts for a batch of host sequences (LazySeq.get_kcounts) */
+int dvs_kmer_counts(dvs_ctx *ctx, const uint8_t *seqs, const uint64_t *offsets,
+                    uint32_t nseq, uint32_t k, uint32_t num_states,
+                    uint32_t *counts_out, uint32_t *totals_out, double *entropy_out);
+
+/* ---- greedy delta-JSD selection ------------------------------------------ *
+ * replaces SummedRecords (src/records.rs:10-216), get_lowest_record_index
+ * (:220-252) and the selectors select_nmost_divergent (:311-342),
+ * select_nmost_divergent_final (:363-382), select_max_divergent (:390-454),
+ * select_max_divergent_final (:456-507), make_summed_records (:509-524), i.e.
+ * the bodies of _dvs.nmost_divergent / final_nmost / max_divergent /
+ * final_max / get_delta_jsd_calculator (src/lib.rs:59-171).
+ *
+ * The candidate stream is `npos` positions; position p refers to matrix row
+ * order[p] (order == NULL: row p) and carries identity label labels[p]
+ * (labels == NULL: label = row index; equal labels == equal seqid, which the
+ * reference ignores when already in the set, src/records.rs:71-73,87-89).
+ * The first `n_seed` positions seed the set (rows without valid k-mers are
+ * skipped, src/records.rs:299-306); the rest are streamed in order. */
+#define DVS_MODE_NMOST 0 /* fixed size: replace_lowest on every JSD increase */
+#define DVS_MODE_MAX 1   /* grow to max_size while std/cov of delta-JSD rises */
+#define DVS_MODE_SET 2   /* build the set from all positions, stream nothing */
+#define DVS_STAT_STDEV 0
+#define DVS_STAT_COV 1
+
+typedef struct dvs_select_params {
+    uint32_t mode;     /* DVS_MODE_* */
+    uint32_t n_seed;   /* n (nmost) or min_size (max); ignored for MODE_SET */
+    uint32_t max_size; /* MODE_MAX only (already capped to npos by the caller or not) */
+    uint32_t stat;     /* DVS_STAT_*, MODE_MAX only */
+    uint32_t window;   /* rows scored per scan launch; 0 = library default */
+    uint32_t flags;    /* DVS_SELECT_* */
+} dvs_select_params;
+#define DVS_SELECT_NO_ARBITER 1u /* fail with DVS_ERR_UNSUPPORTED instead of host tie arbitration */
+
+typedef struct dvs_select_summary {
+    uint32_t size;
+    uint32_t lowest_index;
+    double total_jsd, mean_delta_jsd, std_delta_jsd, cov_delta_jsd, summed_entropies;
+    /* engine statistics */
+    uint64_t rows_scored;    /* candidate rows read by the scan kernel (re-scans included) */
+    uint64_t rows_rechecked; /* rows the scan re-evaluated in full f64 */
+    uint32_t n_windows, n_events, n_accepts, n_arbitrated;
+    double scan_ms;          /* sum of scan-kernel durations (HIP events) when timing is on, else 0 */
+    uint64_t scan_launches;  /* scan-kernel launches the events bracket (no-op launches included) */
+} dvs_select_summary;
+
+int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t *order,
+                   const uint32_t *labels, uint64_t npos,
+                   const dvs_select_params *params, dvs_select **out);
+void dvs_select_destroy(dvs_select *s);
+int dvs_select_get_summary(dvs_ctx *ctx, const dvs_select *s, dvs_select_summary *out);
+/* members in set order (SummedRecords::get_raw_kseqs, src/records.rs:175-180):
+ * stream position, label, delta_jsd, entropy and (if freqs != NULL) the
+ * size x nbins frequency rows.  Any output pointer may be NULL. */
+int dvs_select_get_members(dvs_ctx *ctx, const dvs_select *s, uint64_t *positions,
+                           uint32_t *labels, double *delta_jsd, double *entropy,
+                           double *freqs);
+/* SummedRecords::delta_jsd (src/records.rs:70-84) for every row of `queries`
+ * against the set: 0.0 when qlabels[i] is a member's label, NaN for a row
+ * without valid k-mers (the python layer raises, src/records_py.rs:111-120). */
+int dvs_select_delta_jsd(dvs_ctx *ctx, const dvs_select *s, const dvs_matrix *queries,
+                         const uint32_t *qlabels, double *out);
+/* when on, every scan launch is bracketed by a pair of HIP events recorded on the
+ * ctx stream (no extra host sync); they are read once the selection has finished
+ * and summed into dvs_select_summary.scan_ms / scan_launches */
+int dvs_ctx_set_timing(dvs_ctx *ctx, int on);
+
+/* ---- mash ----------------------------------------------------------------- *
+ * dvs_mash_sketch replaces _dvs.mash_sketch (src/distance.rs:136-182) for a
+ * batch: sketches_out is nseq x sketch_size (ascending, first lens_out[i]
+ * entries valid).  dvs_mash_distances (sketch i at sketches + i * sketch_stride;
+ * sketch_size is the value the distance formula uses) replaces diverse_seq/distance.py
+ * mash_distance (:230-291) over the pairs (i, j<i) for i = row_start,
+ * row_start+row_stride, ... (compute_mash_chunk_distances,
+ * diverse_seq/cluster.py:640-644); dist is nseq x nseq row-major, only the
+ * visited lower-triangle cells (and their mirror when symmetric != 0) are
+ * written.  DVS_ERR_ZERODIV when a visited pair has two empty sketches. */
+int dvs_mash_sketch(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device,
+                    const uint64_t *offsets, uint32_t nseq, uint32_t k,
+                    uint32_t sketch_size, uint32_t num_states, int mash_canonical,
+                    uint32_t *sketches_out, uint32_t *lens_out);
+int dvs_mash_distances(dvs_ctx *ctx, const uint32_t *sketches, uint32_t sketch_stride,
+                       const uint32_t *lens, uint32_t nseq, uint32_t k, uint32_t sketch_size,
+                       uint32_t row_start, uint32_t row_stride, int symmetric,
+                       double *dist);
+/* euclidean_distances (diverse_seq/distance.py:294-336): ||f_i - f_j||_2 over
+ * the rows of m, full symmetric nrows x nrows matrix */
+int dvs_euclidean_distances(dvs_ctx *ctx, const dvs_matrix *m, double *dist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVS_HIP_H */

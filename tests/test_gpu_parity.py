@@ -1,0 +1,480 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.
+Bit-exact for k-mer counts, sketches and selected ids; 1e-6 relative (the
+north-star tolerance; in practice ~1e-13) for JSD / entropy / distance floats."""
+import math
+import pickle
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import str2arr, synth_seqs
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6   # BASELINE.json north_star: "within 1e-6 relative for JSD/entropy floats"
+TIGHT = 1e-11  # what the f64 kernels actually deliver
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from diverseseq_amd import engine
+
+    return engine.default_context()
+
+
+def _oracle_counts(seqs, ns, k):
+    return np.stack([oracle.count_kmers(s, ns, k) for s in seqs]).astype(np.uint64)
+
+
+def _check_matrix(ctx, seqs, k, ns=4):
+    m = ctx.build_matrix(seqs, k, ns)
+    got = m.counts().astype(np.uint64)
+    exp = _oracle_counts(seqs, ns, k)
+    assert got.shape == exp.shape
+    assert (got == exp).all(), f"k-mer counts differ (k={k}, ns={ns})"
+    tot = m.totals()
+    assert (tot == exp.sum(axis=1)).all()
+    H = m.entropy()
+    for i, s in enumerate(seqs):
+        if tot[i]:
+            _, h = oracle.to_kfreqs(s, ns, k)
+            assert abs(H[i] - h) <= TIGHT * max(1.0, abs(h)), (i, H[i], h)
+    m.close()
+
+
+# ------------------------------------------------------------------ k-mer counts
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 6, 7])
+def test_counts_brca1(ctx, brca1, k):
+    _check_matrix(ctx, list(brca1.values()), k)
+
+
+def test_counts_rust_vector(ctx, rust_vectors):
+    v = rust_vectors["kmer_count"]
+    c, _, _ = ctx.kmer_counts([np.array(v["seq"], dtype=np.uint8)], v["k"], v["num_states"])
+    assert c[0].tolist() == v["counts"]
+
+
+def test_counts_edge_cases(ctx):
+    rng = np.random.default_rng(3)
+    seqs = synth_seqs(40, 700, 11, invalid_frac=0.01, ragged=True)
+    seqs += [np.zeros(0, dtype=np.uint8),                       # empty
+             np.array([1, 2], dtype=np.uint8),                  # L < k
+             np.full(50, 4, dtype=np.uint8),                    # all invalid
+             np.array([4] + [0, 1, 2, 3] * 5 + [4], dtype=np.uint8),  # invalid at both edges
+             np.array([0, 1, 2, 3, 0, 1], dtype=np.uint8),      # L == k (k=6)
+             rng.integers(0, 4, size=17, dtype=np.uint8),
+             rng.integers(0, 4, size=16, dtype=np.uint8),
+             rng.integers(0, 4, size=15, dtype=np.uint8)]
+    for s in seqs[:10]:
+        if s.size > 40:
+            s[[0, 5, s.size - 1]] = 4  # invalid symbols at window edges
+    for k in (1, 2, 5, 6):
+        _check_matrix(ctx, seqs, k)
+
+
+def test_counts_long_sequences_multi_tile(ctx):
+    """genome-like rows: many tiles per sequence merged with global atomics"""
+    rng = np.random.default_rng(5)
+    seqs = [rng.integers(0, 4, size=n, dtype=np.uint8) for n in (200_000, 32_768 + 5, 32_773, 70_001)]
+    seqs[0][rng.integers(0, 200_000, size=200)] = 4
+    seqs.append(rng.integers(0, 4, size=900, dtype=np.uint8))
+    _check_matrix(ctx, seqs, 6)
+    _check_matrix(ctx, seqs, 3)
+
+
+def test_counts_large_k_global_histogram(ctx):
+    """4^k * 4 B > 64 KB: the row in L2 takes the atomics (k = 8, 9)"""
+    seqs = synth_seqs(6, 5000, 21, invalid_frac=0.002)
+    seqs.append(np.random.default_rng(2).integers(0, 4, size=90_000, dtype=np.uint8))
+    _check_matrix(ctx, seqs, 8)
+    _check_matrix(ctx, seqs[:3], 9)
+
+
+@pytest.mark.parametrize("ns,k", [(20, 2), (5, 3), (3, 4), (2, 7), (20, 3)])
+def test_counts_other_alphabets(ctx, ns, k):
+    rng = np.random.default_rng(ns * 10 + k)
+    seqs = [rng.integers(0, ns + 1, size=int(rng.integers(5, 3000)), dtype=np.uint8) for _ in range(12)]
+    _check_matrix(ctx, seqs, k, ns)
+
+
+def test_counts_errors(ctx):
+    with pytest.raises(ValueError, match="k cannot be 0"):
+        ctx.build_matrix([np.array([0, 1, 2, 0], dtype=np.uint8)], 0, 4)
+
+
+def test_counts_device_resident_input(ctx):
+    """sequences already in HBM as a torch tensor (zero-copy hand-off)"""
+    torch = pytest.importorskip("torch")
+    seqs = synth_seqs(50, 1200, 9, ragged=True)
+    data, offs = oracle.concat(seqs)
+    t = torch.from_numpy(data).to("cuda:0")
+    torch.cuda.synchronize()
+    m = ctx.build_matrix_device(t.data_ptr(), offs, 5, 4)
+    assert (m.counts().astype(np.uint64) == _oracle_counts(seqs, 4, 5)).all()
+
+
+# -------------------------------------------------------------------- selection
+def _assert_selection(sel, exp, rtol=RTOL):
+    got = sel.members(with_freqs=True)
+    s = sel.summary()
+    elab, edelta, eent, efreq = exp.members(with_freqs=True)
+    assert s.size == exp.size
+    assert got.positions.tolist() == elab.tolist(), "selected ids / member order differ"
+    np.testing.assert_allclose(got.delta_jsd, edelta, rtol=rtol, atol=1e-13)
+    np.testing.assert_allclose(got.entropy, eent, rtol=rtol)
+    assert (got.kfreqs == efreq).all(), "member frequency rows must be bit-exact (count / total)"
+    for name in ("total_jsd", "mean_delta_jsd", "std_delta_jsd", "cov_delta_jsd"):
+        g, e = getattr(s, name), getattr(exp, name)
+        assert abs(g - e) <= rtol * max(abs(e), 1e-300) + 1e-13, (name, g, e)
+    assert s.lowest_index == exp.lowest_index
+    return s
+
+
+def test_set_rust_golden(ctx, rust_vectors):
+    """src/records.rs:588-621,676-685 through MODE_SET"""
+    v = rust_vectors["summed"]
+    seqs = [np.array(s, dtype=np.uint8) for s in v["seqs"].values()]
+    m = ctx.build_matrix(seqs, v["k"], v["num_states"])
+    sel = m.as_set()
+    s = sel.summary()
+    mem = sel.members()
+    assert s.size == v["size"]
+    np.testing.assert_allclose(s.total_jsd, v["total_jsd"], rtol=TIGHT)
+    np.testing.assert_allclose(mem.entropy, v["entropies"], rtol=TIGHT)
+    np.testing.assert_allclose(s.summed_entropies, v["summed_entropies"], rtol=TIGHT)
+    np.testing.assert_allclose(mem.delta_jsd, v["delta_jsds"], rtol=1e-10)
+    np.testing.assert_allclose(s.mean_delta_jsd, v["mean_delta_jsd"], rtol=1e-10)
+    np.testing.assert_allclose(s.std_delta_jsd, v["std_delta_jsd"], rtol=1e-10)
+    # candidate scores: better increases JSD, a member scores 0.0 (records.rs:629-649)
+    q = ctx.build_matrix([np.array(v["better"]["seq"], dtype=np.uint8), seqs[0]], 1, 4)
+    d = sel.delta_jsd(q, [99, 0])
+    assert d[0] > s.total_jsd + 2.3e-16 and d[1] == 0.0
+    oset = oracle.SummedRecords.from_seqs(seqs, 1, 4)
+    f, h = oracle.to_kfreqs(v["better"]["seq"], 4, 1)
+    np.testing.assert_allclose(d[0], oset.delta_jsd(f, h, 99), rtol=TIGHT)
+
+
+def test_selector_rust_golden(ctx, rust_vectors):
+    """src/records.rs:694-812"""
+    v = rust_vectors["selector"]
+    names = [n for n, _ in v["seqs"]]
+    seqs = [np.array(s, dtype=np.uint8) for _, s in v["seqs"]]
+    order_in = v["fxhash_consistent_order"]
+    stream = [seqs[names.index(n)] for n in order_in]
+    m = ctx.build_matrix(stream, 1, 4)
+    sel = m.nmost(3)
+    assert [order_in[int(p)] for p in sel.members().positions] == v["summed234_order"]
+    _assert_selection(sel, oracle.nmost(stream, 3, 1, 4))
+    # insertion order, an invalid sequence in the stream, duplicate ids
+    inv = np.array(v["invalid"][1], dtype=np.uint8)
+    m2 = ctx.build_matrix(seqs + [inv], 1, 4)
+    sel2 = m2.nmost(3)
+    assert {names[int(p)] for p in sel2.members().positions} == set(v["nmost_n3_members"])
+    _assert_selection(sel2, oracle.nmost(seqs + [inv], 3, 1, 4))
+    lab = [0, 1, 2, 3, 4, 1]
+    m3 = ctx.build_matrix(seqs + [seqs[1]], 1, 4)
+    _assert_selection(m3.nmost(3, labels=lab), oracle.nmost(seqs + [seqs[1]], 3, 1, 4, labels=lab))
+    with pytest.raises(ValueError, match="The number of sequences 5 is < n 20"):
+        ctx.build_matrix(seqs, 1, 4).nmost(20)
+    for stat in ("stdev", "cov"):
+        sel4 = m2.max_divergent(3, 4, stat)
+        _assert_selection(sel4, oracle.max_divergent(seqs + [inv], 3, 4, 1, 4, stat))
+    sel5 = m2.max_divergent(3, 10, "stdev")
+    _assert_selection(sel5, oracle.max_divergent(seqs + [inv], 3, 10, 1, 4, "stdev"))
+
+
+def test_seed_panics(ctx):
+    inv = np.full(4, 4, dtype=np.uint8)
+    ok = np.array([0, 1, 2, 3], dtype=np.uint8)
+    with pytest.raises(ValueError, match="records cannot be empty"):
+        ctx.build_matrix([inv, inv, ok], 1, 4).nmost(2)
+    with pytest.raises(ValueError, match="must have > 1 KmerSeq"):
+        ctx.build_matrix([ok, inv, ok], 1, 4).nmost(2)
+
+
+@pytest.mark.parametrize("k,n", [(4, 10), (2, 5), (6, 7), (1, 5)])
+def test_nmost_brca1(ctx, brca1, k, n):
+    """config C1 on the device: BRCA1 demo, k=4, n=10 (and neighbours)"""
+    seqs = list(brca1.values())
+    m = ctx.build_matrix(seqs, k, 4)
+    _assert_selection(m.nmost(n), oracle.nmost(seqs, n, k, 4))
+
+
+@pytest.mark.parametrize("stat", ["stdev", "cov"])
+@pytest.mark.parametrize("k,lo,hi", [(3, 5, 30), (4, 3, 8), (2, 7, 55), (5, 10, 12)])
+def test_max_brca1(ctx, brca1, stat, k, lo, hi):
+    seqs = list(brca1.values())
+    rng = np.random.default_rng(k * 100 + lo)
+    perm = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in perm]
+    m = ctx.build_matrix(seqs, k, 4)
+    _assert_selection(m.max_divergent(lo, hi, stat), oracle.max_divergent(seqs, lo, hi, k, 4, stat))
+
+
+@pytest.mark.parametrize("nseq,length,k,n,window", [(3000, 400, 3, 10, 64), (2000, 600, 6, 20, 256),
+                                                   (1500, 300, 4, 50, 0), (4000, 200, 2, 5, 1024),
+                                                   (800, 2500, 7, 12, 128)])
+def test_nmost_synthetic(ctx, nseq, length, k, n, window):
+    seqs = synth_seqs(nseq, length, nseq + k, invalid_frac=0.001, ragged=True)
+    m = ctx.build_matrix(seqs, k, 4)
+    s = _assert_selection(m.nmost(n, window=window), oracle.nmost(seqs, n, k, 4))
+    assert s.n_accepts > 0 and s.rows_scored >= nseq - n - 5
+
+
+def test_nmost_structured_families(ctx):
+    """a few divergent families (paper/nbks/synthetic_known.py:16-25 style) so accepts are common"""
+    rng = np.random.default_rng(77)
+    seqs = []
+    for fam in range(6):
+        p = rng.dirichlet(np.ones(4) * 0.7)
+        for _ in range(150):
+            seqs.append(rng.choice(4, size=int(rng.integers(400, 900)), p=p).astype(np.uint8))
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    for k, n in ((3, 6), (5, 12)):
+        m = ctx.build_matrix(seqs, k, 4)
+        _assert_selection(m.nmost(n, window=128), oracle.nmost(seqs, n, k, 4))
+        _assert_selection(m.max_divergent(4, 25, "stdev", window=128),
+                          oracle.max_divergent(seqs, 4, 25, k, 4, "stdev"))
+
+
+def test_explicit_order_and_labels(ctx):
+    seqs = synth_seqs(300, 500, 4, ragged=True)
+    rng = np.random.default_rng(0)
+    order = rng.permutation(300).astype(np.uint32)
+    order = np.concatenate([order, order[:40]])  # ids repeated later in the stream
+    m = ctx.build_matrix(seqs, 4, 4)
+    got = m.nmost(9, order=order, labels=order)
+    exp = oracle.nmost([seqs[i] for i in order], 9, 4, 4, labels=order)
+    gm = got.members(False)
+    assert [int(order[p]) for p in gm.positions] == exp.members()[0].tolist()
+    np.testing.assert_allclose(gm.delta_jsd, exp.members()[1], rtol=RTOL, atol=1e-13)
+
+
+def test_final_merges(ctx, brca1):
+    """chunk + merge: records.py:225-245 -> records.rs:363-382 / 456-507"""
+    seqs = list(brca1.values())
+    chunks = [seqs[:20], seqs[20:40], seqs[40:]]
+    rows, labels, base = [], [], 0
+    for ch in chunks:
+        r = oracle.nmost(ch, 6, 3, 4)
+        l, _, _, f = r.members(with_freqs=True)
+        rows.append(f)
+        labels.append(l + base)
+        base += len(ch)
+    rows, labels = np.vstack(rows), np.concatenate(labels)
+    m = ctx.matrix_from_freqs(rows)
+    got = m.nmost(6, labels=labels)
+    exp = oracle.final_nmost(rows, 6, labels=labels)
+    gm = got.members()
+    assert [int(labels[p]) for p in gm.positions] == exp.members()[0].tolist()
+    np.testing.assert_allclose(gm.delta_jsd, exp.members()[1], rtol=RTOL, atol=1e-13)
+    np.testing.assert_allclose(got.summary().total_jsd, exp.total_jsd, rtol=RTOL)
+    for stat in ("stdev", "cov"):
+        got = m.max_divergent(4, 9, stat, labels=labels)
+        exp = oracle.final_max(rows, 4, 9, stat, labels=labels)
+        assert [int(labels[p]) for p in got.members().positions] == exp.members()[0].tolist()
+    bad = rows.copy()
+    bad[3] *= 1.001
+    with pytest.raises(ValueError, match="cannot calculate entropy"):
+        ctx.matrix_from_freqs(bad)
+
+
+def test_delta_jsd_calculator(ctx, brca1):
+    names = list(brca1)
+    refs = [brca1[n][1500:1650] for n in names[:4]]
+    queries = [brca1[n][1500:1650] for n in names[4:]]
+    m = ctx.build_matrix(refs, 3, 4)
+    sel = m.as_set()
+    oset = oracle.SummedRecords.from_seqs(refs, 3, 4)
+    q = ctx.build_matrix(queries, 3, 4)
+    got = sel.delta_jsd(q)
+    for i, s in enumerate(queries):
+        f, h = oracle.to_kfreqs(s, 4, 3)
+        np.testing.assert_allclose(got[i], oset.delta_jsd(f, h), rtol=TIGHT)
+    assert sel.delta_jsd(ctx.build_matrix(refs[:1], 3, 4), [0])[0] == 0.0
+
+
+# ------------------------------------------------------- full BASELINE sizes
+def test_config_c2_full_size(ctx):
+    """C2: 10k x 2 kb, k=6, nmost -- full comparison with the oracle (~1 s of CPU)"""
+    rng = np.random.default_rng(20260423)
+    data = rng.integers(0, 4, size=10_000 * 2_000, dtype=np.uint8)
+    offs = np.arange(10_001, dtype=np.uint64) * 2_000
+    m = ctx.build_matrix_concat(data, offs, 6, 4)
+    for n in (10, 100):
+        exp, _ = oracle.nmost_concat(data, offs, n, 6, 4)
+        s = _assert_selection(m.nmost(n), exp)
+        assert s.n_arbitrated == 0
+    # size-independent property: every row's counts sum to L - k + 1
+    assert (m.totals() == 2_000 - 5).all()
+
+
+def test_north_star_shape_properties(ctx):
+    """100k x 5 kb, k=6: count-matrix checksums + idempotence of the selection"""
+    rng = np.random.default_rng(20260424)
+    n, L = 100_000, 5_000
+    data = rng.integers(0, 4, size=n * L, dtype=np.uint8)
+    data[rng.integers(0, n * L, size=n * L // 1000)] = 4  # 0.1 % invalid symbols
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    m = ctx.build_matrix_concat(data, offs, 6, 4)
+    tot = m.totals()
+    sample = rng.integers(0, n, size=64)
+    for i in sample:
+        c = oracle.count_kmers(data[i * L:(i + 1) * L], 4, 6)
+        assert int(tot[i]) == int(c.sum())
+        assert (m.counts(int(i), 1)[0] == c).all()
+    a = m.nmost(10)
+    b = m.nmost(10, window=1 << 14)  # a different window partition must not change the answer
+    assert a.members(False).positions.tolist() == b.members(False).positions.tolist()
+    np.testing.assert_array_equal(a.members(False).delta_jsd, b.members(False).delta_jsd)
+    exp, _ = oracle.nmost_concat(data, offs, 10, 6, 4)
+    _assert_selection(a, exp)
+
+
+# ------------------------------------------------------------------------ mash
+def _assert_sketches(seqs, k, s, ns=4, canonical=False):
+    from diverseseq_amd import distance
+
+    sk, lens = distance.sketch_batch(seqs, k, s, ns, canonical)
+    for i, q in enumerate(seqs):
+        exp = oracle.mash_sketch(q, k, s, ns, canonical)
+        assert lens[i] == exp.size, (i, lens[i], exp.size)
+        assert (sk[i, : lens[i]] == exp).all(), f"sketch {i} differs"
+    return sk, lens
+
+
+@pytest.mark.parametrize("canonical", [False, True])
+def test_sketch_brca1(brca1, canonical):
+    seqs = list(brca1.values())
+    _assert_sketches(seqs, 16, 400, 4, canonical)
+    _assert_sketches(seqs[:8], 12, 3000, 4, canonical)       # sketch longer than the sequence
+    _assert_sketches(seqs[:8], 5, 4_000_000_000, 4, canonical)  # tests/test_ctree.py: sketch 4e9
+
+
+def test_sketch_edge_cases():
+    rng = np.random.default_rng(8)
+    seqs = synth_seqs(20, 900, 5, invalid_frac=0.02, ragged=True)
+    seqs += [np.zeros(0, dtype=np.uint8), np.array([1, 2, 3], dtype=np.uint8),
+             np.full(40, 4, dtype=np.uint8), np.zeros(300, dtype=np.uint8)]  # homopolymer: 1 distinct
+    for k, s in ((8, 50), (4, 10), (21, 100), (1, 3)):
+        _assert_sketches(seqs, k, s, 4, False)
+        _assert_sketches(seqs, k, s, 4, True)
+
+
+def test_sketch_long_sequences_threshold_path():
+    """genome-like: only hashes under the per-sequence threshold ever leave the hash kernel"""
+    rng = np.random.default_rng(13)
+    seqs = [rng.integers(0, 4, size=n, dtype=np.uint8) for n in (400_000, 250_000, 20_000)]
+    seqs[1][rng.integers(0, 250_000, size=100)] = 4
+    seqs.append(np.tile(rng.integers(0, 4, size=500, dtype=np.uint8), 200))  # 100 kb of repeats
+    for canonical in (False, True):
+        _assert_sketches(seqs, 12, 3000, 4, canonical)
+        _assert_sketches(seqs, 16, 400, 4, canonical)
+
+
+def test_mash_distance_golden(mash_vectors):
+    """vectors captured from the reference's pure-python mash_distance"""
+    from diverseseq_amd import distance
+
+    for c in mash_vectors["mash_distance"]:
+        if c["distance"] == "ZeroDivisionError":
+            with pytest.raises(ZeroDivisionError):
+                distance.mash_distance(c["left"], c["right"], c["k"], c["sketch_size"])
+            continue
+        got = distance.mash_distance(c["left"], c["right"], c["k"], c["sketch_size"])
+        assert abs(got - c["distance"]) <= RTOL * abs(c["distance"]), c
+        assert abs(got - c["distance"]) <= 1e-14 * max(1.0, abs(c["distance"]))
+
+
+def test_mash_distances_matrix(brca1):
+    from diverseseq_amd import distance
+
+    names = ["Human", "Chimpanzee", "Manatee", "Dugong", "Rhesus"]
+    seqs = [brca1[n] for n in names]
+    d = distance.mash_distances(seqs, 16, 400, 4, True)
+    sk = [oracle.mash_sketch(s, 16, 400, 4, True) for s in seqs]
+    np.testing.assert_allclose(d, oracle.mash_distances(sk, 16, 400), rtol=1e-13)
+    D = {(a, b): d[i, j] for i, a in enumerate(names) for j, b in enumerate(names)}
+    # the reference's own assertions (tests/test_distance.py:119-138)
+    assert D["Human", "Chimpanzee"] < D["Human", "Dugong"]
+    assert D["Human", "Rhesus"] < D["Human", "Manatee"]
+    assert D["Chimpanzee", "Rhesus"] < D["Chimpanzee", "Dugong"]
+    assert D["Manatee", "Dugong"] < D["Manatee", "Rhesus"]
+    # strided chunks (cluster.py:640-644) tile the same lower triangle
+    skb, lens = distance.sketch_batch(seqs, 16, 400, 4, True)
+    acc = np.zeros((5, 5))
+    for start in range(3):
+        distance.distances_from_sketches(skb, lens, 16, 400, row_start=start, row_stride=3,
+                                         symmetric=False, out=acc)
+    np.testing.assert_array_equal(acc + acc.T, d)
+
+
+def test_euclidean(brca1):
+    from diverseseq_amd import distance
+
+    names = ["Human", "Chimpanzee", "Manatee", "Dugong", "Rhesus"]
+    seqs = [brca1[n] for n in names]
+    d = distance.euclidean_distances(seqs, 5, 4)
+    for i in range(5):
+        for j in range(5):
+            fi, fj = oracle.to_kfreqs(seqs[i], 4, 5)[0], oracle.to_kfreqs(seqs[j], 4, 5)[0]
+            np.testing.assert_allclose(d[i, j], np.linalg.norm(fi - fj), rtol=1e-12, atol=1e-15)
+    assert d[0, 1] < d[0, 3]  # tests/test_distance.py:37-39
+
+
+# ------------------------------------------------------------ _dvs drop-in level
+def test_dvs_module_like_reference_tests(brca1):
+    """reference tests/test_records.py through the drop-in module"""
+    from diverseseq_amd import _dvs as dvs
+
+    data = {"a": "AAAA", "b": "AAAA", "c": "TTTT", "d": "ACGT"}
+    st = dvs.make_zarr_store()
+    for n, s in data.items():
+        st.write(n, str2arr(s).tobytes())
+    assert st.unique_seqids == ["b", "c", "d"]
+    for k in (1, 2):  # test_total_jsd
+        lz = [st.get_lazyseq(n, num_states=4) for n in st.unique_seqids]
+        sr = dvs.get_delta_jsd_calculator([(s.seqid, s.get_seq()) for s in lz], k=k,
+                                          num_states=4).get_result()
+        freqs = np.array([s.get_kfreqs(k) for s in lz])
+
+        def H(p):
+            p = p[p > 0]
+            return float(-(p * np.log2(p)).sum())
+
+        np.testing.assert_allclose(sr.total_jsd, H(freqs.mean(0)) - np.mean([H(f) for f in freqs]))
+    got = dvs.max_divergent(st, min_size=2, max_size=2, k=1)
+    assert got.size == 2
+    got = dvs.nmost_divergent(st, n=3, k=1)
+    assert got.size == 3 and set(got.record_names) == set(st.unique_seqids)
+    assert pickle.loads(pickle.dumps(got)).size == 3
+    with pytest.raises(ValueError):
+        dvs.nmost_divergent(st, n=30, k=1)
+    # brca1: chunk + merge (test_merge_summed_records)
+    store = dvs.make_zarr_store()
+    for n, s in brca1.items():
+        store.write(n, s.tobytes())
+    names = store.unique_seqids
+    sr1 = dvs.nmost_divergent(store, n=5, k=1, seqids=names[:10])
+    sr2 = dvs.nmost_divergent(store, n=5, k=1, seqids=names[10:20])
+    merged = dvs.final_nmost([sr1, sr2], n=5)
+    assert len(merged.record_names) == 5
+    assert (merged.k, merged.num_states) == (4, 1)  # records.rs:353 swaps them
+    with pytest.raises(ValueError):
+        dvs.final_nmost([sr1, sr2], n=500)
+    mx = dvs.max_divergent(store, min_size=4, max_size=5, k=1, seqids=names[:10])
+    with pytest.raises(ValueError):
+        dvs.final_max([mx], min_size=10, max_size=20, stat="stdev")
+    # calculator edge cases (test_jsd_calc*)
+    recs = [(n, brca1[n][1500:1650].tobytes()) for n in names[:4]]
+    calc = dvs.get_delta_jsd_calculator(recs, k=3, num_states=4)
+    assert calc.get_result().total_jsd > 0
+    assert np.allclose(calc.delta_jsd(*recs[0]), 0.0)
+    with pytest.raises(ValueError, match="failed: No valid k-mers"):
+        calc.delta_jsd("blah", b"")
+    sk = dvs.mash_sketch(brca1["Human"].tobytes(), 16, 400, 4, True)
+    assert sk == oracle.mash_sketch(brca1["Human"], 16, 400, 4, True).tolist()
+    lz = store.get_lazyseq("Human", 4)
+    assert lz.get_kcounts(3) == oracle.count_kmers(brca1["Human"], 4, 3).tolist()
