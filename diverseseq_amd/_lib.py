@@ -57,6 +57,34 @@ _lib = None
 _lock = threading.Lock()
 
 
+def _preload_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so.7 / libhsa-runtime64 (same SONAMEs as /opt/rocm's); if this
+    library pulled in the system copy first, a later `import torch` would find no
+    GPU, and device pointers could not be shared between the two.  So when torch
+    is installed, its copy is loaded (RTLD_GLOBAL) before libdvs_hip.so, whose
+    NEEDED libamdhip64.so.7 then resolves to it.  torch itself is not imported."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return  # already loaded its runtime
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = pathlib.Path(list(spec.submodule_search_locations)[0]) / "lib"
+    for name in ("libhsa-runtime64.so", "libamd_comgr.so", "libamdhip64.so"):
+        p = libdir / name
+        if p.exists():
+            try:
+                C.CDLL(str(p), mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load() -> C.CDLL:
     """dlopen libdvs_hip.so and declare the ABI; raises if it has not been built"""
     global _lib
@@ -67,6 +95,7 @@ def load() -> C.CDLL:
             raise DvsLibraryMissing(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        _preload_torch_hip_runtime()
         L = C.CDLL(str(LIB_PATH))
         vp, u8p, u32p, u64p, f64p = (C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32),
                                      C.POINTER(C.c_uint64), C.POINTER(C.c_double))

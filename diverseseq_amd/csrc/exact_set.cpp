@@ -1,10 +1,313 @@
-// Host tie arbiter -- placeholder until the exact replay lands.
+// Host tie arbiter of the selection engine.
+//
+// The device scores candidates with tree reductions and its own log2; the
+// reference sums 4^k terms sequentially with libm's log2 (src/record.rs:92-98).
+// Both are the same number up to rounding noise of ~ B * eps * H, so a decision
+// whose margin is inside that band (select.hip: sel_band) cannot be attributed
+// on the device.  Those -- and only those -- decisions come here: the accepted
+// events logged by the device are replayed in the reference's exact f64
+// operation order (this file restates src/records.rs:27-147,153-189,220-286 for
+// that purpose), the open decision is evaluated exactly, and the outcome is
+// written back as a forced decision.  Degenerate inputs (identical sequences,
+// k = 1 toy sets) are where this runs; on the benchmark workloads it never does
+// (dvs_select_summary.n_arbitrated counts it).
+#include <cmath>
+#include <cstring>
+#include <memory>
+
 #include "select.h"
+
+namespace {
+
+struct ExactRow {
+    uint64_t pos = 0;
+    uint32_t label = 0;
+    std::vector<double> f;
+    double H = 0.0;
+    double delta = 0.0;
+};
+
+class ExactSet {
+   public:
+    size_t B = 0;
+    std::vector<ExactRow> recs;
+    std::vector<double> S, work;
+    double sumH = 0.0, total_jsd = 0.0;
+    uint32_t lowest = 0;
+    std::string err;
+
+    // src/record.rs:86-106
+    bool entropy(const double *f, size_t n, double &out) {
+        if (n == 0) {
+            err = "cannot calculate entropy as frequency vector empty";
+            return false;
+        }
+        double e = 0.0, tot = 0.0;
+        for (size_t i = 0; i < n; i++) {
+            const double x = f[i];
+            if (x == 0.0) continue;
+            e += -x * std::log2(x);
+            tot += x;
+        }
+        if (std::fabs(tot - 1.0) > double(n) * DVS_EPS) {
+            char buf[128];
+            snprintf(buf, sizeof buf, "cannot calculate entropy as frequency vector total %.17g!=1.0", tot);
+            err = buf;
+            return false;
+        }
+        out = e;
+        return true;
+    }
+
+    bool contains(uint32_t label) const {
+        for (const ExactRow &r : recs)
+            if (r.label == label) return true;
+        return false;
+    }
+
+    // src/records.rs:220-252 (+ updated_mean_freqs :276-286)
+    bool lowest_index() {
+        const double div = double(recs.size()) - 1.0;
+        if (div <= 0.0) {
+            err = "must have > 1 KmerSeq";
+            return false;
+        }
+        double min_delta = 1e6;
+        uint32_t low = 0;
+        for (size_t i = 0; i < recs.size(); i++) {
+            ExactRow &r = recs[i];
+            const double mean_entropy = (sumH - r.H) / div;
+            for (size_t j = 0; j < B; j++) {
+                work[j] = (S[j] - r.f[j]) / div;
+                if (work[j] <= DVS_EPS) work[j] = 0.0;
+            }
+            double eom;
+            if (!entropy(work.data(), B, eom)) return false;
+            const double jsd = eom - mean_entropy;
+            r.delta = total_jsd - jsd;
+            if (r.delta < min_delta) {
+                min_delta = r.delta;
+                low = uint32_t(i);
+            }
+        }
+        lowest = low;
+        return true;
+    }
+
+    // src/records.rs:27-68
+    bool init(std::vector<ExactRow> &&rows, size_t nbins) {
+        B = nbins;
+        recs = std::move(rows);
+        if (recs.empty()) {
+            err = "records cannot be empty";
+            return false;
+        }
+        S.assign(B, 0.0);
+        work.assign(B, 0.0);
+        sumH = 0.0;
+        for (const ExactRow &r : recs) {
+            for (size_t j = 0; j < B; j++) S[j] += r.f[j];
+            sumH += r.H;
+        }
+        const double n = double(recs.size());
+        for (size_t j = 0; j < B; j++) work[j] = S[j] / n;
+        double eom;
+        if (!entropy(work.data(), B, eom)) return false;
+        total_jsd = eom - sumH / n;
+        return lowest_index();
+    }
+
+    // src/records.rs:70-84
+    bool delta_jsd(const ExactRow &c, double &out) {
+        if (contains(c.label)) {
+            out = 0.0;
+            return true;
+        }
+        const ExactRow &low = recs[lowest];
+        const double n = double(recs.size());
+        const double mean_entropy = (sumH - low.H + c.H) / n;
+        for (size_t j = 0; j < B; j++) work[j] = (S[j] - low.f[j] + c.f[j]) / n;
+        double eom;
+        if (!entropy(work.data(), B, eom)) return false;
+        out = eom - mean_entropy;
+        return true;
+    }
+
+    // src/records.rs:86-92
+    bool increases(const ExactRow &c, bool &out) {
+        if (contains(c.label)) {
+            out = false;
+            return true;
+        }
+        double jsd;
+        if (!delta_jsd(c, jsd)) return false;
+        out = jsd > total_jsd + DVS_EPS;
+        return true;
+    }
+
+    // src/records.rs:120-147
+    bool push(ExactRow &&c) {
+        if (contains(c.label)) return true;
+        sumH += c.H;
+        for (size_t j = 0; j < B; j++) S[j] += c.f[j];
+        recs.push_back(std::move(c));
+        const double n = double(recs.size());
+        for (size_t j = 0; j < B; j++) work[j] = S[j] / n;
+        double eom;
+        if (!entropy(work.data(), B, eom)) return false;
+        total_jsd = eom - sumH / n;
+        return lowest_index();
+    }
+
+    // src/records.rs:94-118
+    bool replace_lowest(ExactRow &&c) {
+        if (contains(c.label)) return true;
+        ExactRow old = std::move(recs[lowest]);
+        recs.erase(recs.begin() + lowest);
+        sumH -= old.H;
+        for (size_t j = 0; j < B; j++) {
+            S[j] -= old.f[j];
+            if (S[j] <= DVS_EPS) S[j] = 0.0;
+        }
+        return push(std::move(c));
+    }
+
+    // src/records.rs:182-189: clone re-runs new()
+    bool clone_from(const ExactSet &o) {
+        std::vector<ExactRow> rows = o.recs;
+        for (ExactRow &r : rows) r.delta = 0.0;
+        return init(std::move(rows), o.B);
+    }
+
+    // src/records.rs:156-172
+    double mean_delta() const {
+        double s = 0.0;
+        for (const ExactRow &r : recs) s += r.delta;
+        return s / double(recs.size());
+    }
+    double std_delta() const {
+        const double m = mean_delta();
+        double s = 0.0;
+        for (const ExactRow &r : recs) {
+            const double d = r.delta - m;
+            s += d * d;
+        }
+        return std::sqrt(s / (double(recs.size()) - 1.0));
+    }
+    double cov_delta() const { return std_delta() / mean_delta(); }
+};
+
+struct Arbiter {
+    ExactSet set;
+    bool built = false;
+    uint32_t replayed = 0;  // event-log entries already applied
+};
+
+// frequency row of stream position p, exactly as the reference builds it
+int fetch_row(dvs_ctx *ctx, const dvs_select *s, uint64_t p, ExactSet &scratch, ExactRow &out) {
+    const dvs_matrix *m = s->mat;
+    const uint64_t B = m->nbins;
+    const uint32_t row = s->h_order.empty() ? uint32_t(p) : s->h_order[p];
+    out.pos = p;
+    out.label = s->h_labels.empty() ? row : s->h_labels[p];
+    out.f.resize(B);
+    if (m->kind == 0) {
+        std::vector<uint32_t> c(B);
+        uint32_t tot = 0;
+        DVS_HIP(ctx, hipMemcpy(c.data(), m->d_counts + uint64_t(row) * B, B * 4, hipMemcpyDeviceToHost));
+        DVS_HIP(ctx, hipMemcpy(&tot, m->d_totals + row, 4, hipMemcpyDeviceToHost));
+        const double total = double(tot);  // record.rs:135-139
+        for (uint64_t i = 0; i < B; i++) out.f[i] = double(c[i]) / total;
+    } else {
+        DVS_HIP(ctx, hipMemcpy(out.f.data(), m->d_freqs + uint64_t(row) * B, B * 8, hipMemcpyDeviceToHost));
+    }
+    if (!scratch.entropy(out.f.data(), B, out.H))  // KmerSeq::new, record.rs:157-159
+        return dvs_set_error(ctx, DVS_ERR_VALUE, "%s", scratch.err.c_str());
+    return DVS_OK;
+}
+
+int write_forced(dvs_ctx *ctx, dvs_select *s, uint32_t forced, uint32_t forced_lowest) {
+    SelCtl *d = s->dev.ctl;
+    const uint32_t run = SEL_RUN;
+    DVS_HIP(ctx, hipMemcpy(&d->forced, &forced, 4, hipMemcpyHostToDevice));
+    DVS_HIP(ctx, hipMemcpy(&d->forced_lowest, &forced_lowest, 4, hipMemcpyHostToDevice));
+    DVS_HIP(ctx, hipMemcpy(&d->status, &run, 4, hipMemcpyHostToDevice));
+    return DVS_OK;
+}
+
+}  // namespace
 
 int dvs_select_arbitrate(dvs_ctx *ctx, dvs_select *s) {
     const SelCtl &c = *s->h_ctl;
-    return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED,
-                         "ambiguous decision at stream position %llu (stage %u) and no arbiter built",
-                         (unsigned long long)c.arb_pos, c.arb_stage);
+    const uint64_t B = s->dev.B;
+    if (!s->arbiter) s->arbiter = new Arbiter();
+    Arbiter &a = *static_cast<Arbiter *>(s->arbiter);
+    ExactSet &set = a.set;
+    set.B = B;
+    if (set.work.size() != B) set.work.assign(B, 0.0);
+    int rc;
+    if (!a.built) {  // SummedRecords::new over the usable seeds (records.rs:288-308)
+        std::vector<ExactRow> rows(s->seed_positions.size());
+        for (size_t i = 0; i < rows.size(); i++)
+            if ((rc = fetch_row(ctx, s, s->seed_positions[i], set, rows[i]))) return rc;
+        if (!set.init(std::move(rows), B)) return dvs_set_error(ctx, DVS_ERR_VALUE, "%s", set.err.c_str());
+        a.built = true;
+    }
+    // replay what the device has committed since the last arbitration
+    const uint32_t n_logged = c.n_logged;
+    if (n_logged > a.replayed) {
+        const uint32_t cnt = n_logged - a.replayed;
+        std::vector<unsigned long long> pos(cnt);
+        std::vector<uint32_t> kind(cnt);
+        DVS_HIP(ctx, hipMemcpy(pos.data(), s->dev.evlog_pos + a.replayed, size_t(cnt) * 8, hipMemcpyDeviceToHost));
+        DVS_HIP(ctx, hipMemcpy(kind.data(), s->dev.evlog_kind + a.replayed, size_t(cnt) * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < cnt; i++) {
+            ExactRow r;
+            if ((rc = fetch_row(ctx, s, pos[i], set, r))) return rc;
+            bool ok;
+            if (kind[i] == 1) {
+                ok = set.replace_lowest(std::move(r));
+            } else {  // records.rs:438-450: the kept object is clone + push
+                ExactSet grown;
+                ok = grown.clone_from(set) && grown.push(std::move(r));
+                if (ok) set = std::move(grown);
+                else set.err = grown.err;
+            }
+            if (!ok) return dvs_set_error(ctx, DVS_ERR_VALUE, "%s", set.err.c_str());
+        }
+        a.replayed = n_logged;
+    }
+    s->n_arbitrated++;
+
+    if (c.arb_stage == ARB_RESOLVE) {
+        ExactRow cand;
+        if ((rc = fetch_row(ctx, s, c.arb_pos, set, cand))) return rc;
+        bool inc;
+        if (!set.increases(cand, inc)) return dvs_set_error(ctx, DVS_ERR_VALUE, "%s", set.err.c_str());
+        return write_forced(ctx, s, inc ? FORCE_ACCEPT : FORCE_REJECT, 0xFFFFFFFFu);
+    }
+    // ARB_FINALIZE
+    if (c.ev_kind == 1) {
+        // the set already changed (its event is in the log and was replayed above, or it is
+        // the initial set): only the argmin is open
+        if (set.recs.size() != c.ev_n)
+            return dvs_set_error(ctx, DVS_ERR_RUNTIME, "arbiter out of sync: %zu members vs %u", set.recs.size(), c.ev_n);
+        return write_forced(ctx, s, FORCE_COMMIT, set.lowest);
+    }
+    // tentative push of the candidate at arb_pos (records.rs:438-450)
+    ExactRow cand;
+    if ((rc = fetch_row(ctx, s, c.arb_pos, set, cand))) return rc;
+    ExactSet grown;
+    if (!grown.clone_from(set) || !grown.push(std::move(cand)))
+        return dvs_set_error(ctx, DVS_ERR_VALUE, "%s", grown.err.c_str());
+    const bool better = (c.stat == DVS_STAT_STDEV) ? (grown.std_delta() > set.std_delta())
+                                                   : (grown.cov_delta() > set.cov_delta());
+    return write_forced(ctx, s, better ? FORCE_COMMIT : FORCE_ROLLBACK, better ? grown.lowest : 0xFFFFFFFFu);
 }
-void dvs_select_arbiter_free(dvs_select *) {}
+
+void dvs_select_arbiter_free(dvs_select *s) {
+    if (s && s->arbiter) {
+        delete static_cast<Arbiter *>(s->arbiter);
+        s->arbiter = nullptr;
+    }
+}

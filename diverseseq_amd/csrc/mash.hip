@@ -12,14 +12,16 @@
 //
 // Device pipeline per sequence:
 //   1. hash_filter_kernel: a tile of windows per workgroup, the tile's bytes staged
-//      in LDS, one window per lane per step; hashes <= a per-sequence threshold T
-//      are appended to that sequence's candidate list (hashes are uniform, so
-//      T = 2^32 * (3 s + 64) / n_windows keeps ~3 s candidates and the rest of the
-//      ~n_windows hashes never leave registers);
+//      in LDS, one window per lane per step; hashes inside the sequence's current
+//      range (lo, hi] that the tile has not produced before (LDS hash set) are
+//      appended to the sequence's candidate list.  Hashes are ~uniform, so
+//      hi = 2^32 * (1.5 s + 256) / n_windows keeps ~1.5 s candidates and the other
+//      ~n_windows hashes never leave registers;
 //   2. sort_select_kernel: one workgroup per sequence sorts the candidates in LDS
-//      (bitonic), drops duplicates, writes the first s.  If fewer than s distinct
-//      values survived and T was not the maximum, the host raises T and repeats
-//      for that sequence (bit-exact: the result is the exact bottom-s set).
+//      (bitonic), drops duplicates and appends them to the sketch.  If the sketch
+//      is still short and hi < 2^32 - 1 the host moves the range up and repeats
+//      for that sequence; if a range holds more than SORT_CAP candidates it is
+//      halved.  The result is the exact bottom-s set of distinct hashes.
 #include "dvs_internal.h"
 
 #include <algorithm>
@@ -86,48 +88,66 @@ __device__ __forceinline__ uint32_t hash_window(const uint8_t *w, uint32_t k, ui
     return fmix32(h);
 }
 
+// LDS hash set over one tile: returns true if h was not yet present
+__device__ __forceinline__ bool tile_insert(uint32_t *tbl, uint32_t mask, uint32_t h) {
+    uint32_t slot = (h * 0x9E3779B1u) & mask;
+    for (;;) {
+        const uint32_t old = atomicCAS(&tbl[slot], 0xFFFFFFFFu, h);
+        if (old == 0xFFFFFFFFu) return true;
+        if (old == h) return false;
+        slot = (slot + 1) & mask;
+    }
+}
+
+// Hashes every window of a tile; hashes h with lo < h <= hi (lo as int64, -1 = none)
+// that were not seen before IN THIS TILE are appended to the sequence's candidate
+// list.  The tile-level dedup bounds the copies of any value by the number of
+// tiles, so repeats / homopolymers cannot flood the candidate list.
 __global__ __launch_bounds__(MASH_THREADS) void hash_filter_kernel(
     const uint8_t *__restrict__ seqs, const MTile *__restrict__ tiles, uint32_t k, uint32_t ns,
-    int canonical, const uint32_t *__restrict__ thresh, const uint8_t *__restrict__ active,
-    uint32_t *__restrict__ cand, const uint64_t *__restrict__ cand_off,
-    const uint32_t *__restrict__ cand_cap, uint32_t *__restrict__ cand_cnt,
-    uint32_t *__restrict__ nvalid) {
+    int canonical, const long long *__restrict__ lo, const uint32_t *__restrict__ hi,
+    const uint8_t *__restrict__ active, uint32_t *__restrict__ cand,
+    const uint64_t *__restrict__ cand_off, const uint32_t *__restrict__ cand_cap,
+    uint32_t *__restrict__ cand_cnt) {
     __shared__ uint8_t sbytes[MASH_TILE + MAX_K + 16];
-    __shared__ uint32_t s_valid;
+    __shared__ uint32_t tbl[2 * MASH_TILE];
+    __shared__ uint32_t s_max_seen;  // a genuine 0xFFFFFFFF hash (the table's empty marker)
     const MTile t = tiles[blockIdx.x];
     if (!active[t.seq]) return;
     const uint32_t nbytes = t.count + k - 1;
     for (uint32_t i = threadIdx.x; i < nbytes; i += MASH_THREADS) sbytes[i] = seqs[t.begin + i];
-    if (threadIdx.x == 0) s_valid = 0;
+    for (uint32_t i = threadIdx.x; i < 2 * MASH_TILE; i += MASH_THREADS) tbl[i] = 0xFFFFFFFFu;
+    if (threadIdx.x == 0) s_max_seen = 0;
     __syncthreads();
-    const uint32_t T = thresh[t.seq];
+    const long long lo_q = lo[t.seq];
+    const uint32_t hi_q = hi[t.seq];
     const uint32_t cap = cand_cap[t.seq];
     uint32_t *out = cand + cand_off[t.seq];
-    uint32_t nv = 0;
     for (uint32_t i = threadIdx.x; i < t.count; i += MASH_THREADS) {
         bool ok;
         const uint32_t h = hash_window(sbytes + i, k, ns, canonical != 0, &ok);
-        if (ok) {
-            nv++;
-            if (h <= T) {
+        if (ok && (long long)h > lo_q && h <= hi_q) {
+            bool fresh;
+            if (h == 0xFFFFFFFFu) fresh = atomicExch(&s_max_seen, 1u) == 0u;
+            else fresh = tile_insert(tbl, 2 * MASH_TILE - 1, h);
+            if (fresh) {
                 const uint32_t slot = atomicAdd(&cand_cnt[t.seq], 1u);
                 if (slot < cap) out[slot] = h;
             }
         }
     }
-    if (nv) atomicAdd(&s_valid, nv);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_valid) atomicAdd(&nvalid[t.seq], s_valid);
 }
 
 // One workgroup per listed sequence: bitonic sort of <= SORT_CAP candidates in LDS,
-// unique, first s -> sketch.  status: 0 done, 1 need larger T, 2 overflow (smaller T).
+// unique, append after the lens[q] entries already final (they are all smaller).
+// status: 0 sketch complete, 1 range exhausted and more needed, 2 overflow.
 __global__ __launch_bounds__(1024) void sort_select_kernel(
     const uint32_t *__restrict__ seq_list, const uint32_t *__restrict__ cand,
     const uint64_t *__restrict__ cand_off, const uint32_t *__restrict__ cand_cap,
-    const uint32_t *__restrict__ cand_cnt, const uint32_t *__restrict__ thresh, uint32_t s,
+    const uint32_t *__restrict__ cand_cnt, const uint32_t *__restrict__ hi, uint32_t s,
     uint32_t *__restrict__ sketches, uint32_t *__restrict__ lens, uint32_t *__restrict__ status) {
     extern __shared__ uint32_t keys[];
+    __shared__ uint32_t scan[1024];
     const uint32_t q = seq_list[blockIdx.x];
     const uint32_t cnt = cand_cnt[q], cap = cand_cap[q];
     if (cnt > cap) {
@@ -137,35 +157,29 @@ __global__ __launch_bounds__(1024) void sort_select_kernel(
     uint32_t n2 = 1;
     while (n2 < cnt) n2 <<= 1;
     const uint32_t *in = cand + cand_off[q];
-    // pad with 0xFFFFFFFF; a genuine 0xFFFFFFFF hash sorts with the padding, so the
-    // number of real entries is tracked separately (cnt)
+    // pad with 0xFFFFFFFF: padding and a genuine 0xFFFFFFFF are interchangeable at the tail
     for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) keys[i] = i < cnt ? in[i] : 0xFFFFFFFFu;
     __syncthreads();
     for (uint32_t size = 2; size <= n2; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
             for (uint32_t i = threadIdx.x; i < (n2 >> 1); i += blockDim.x) {
                 const uint32_t lo = 2 * i - (i & (stride - 1));
-                const uint32_t hi = lo + stride;
+                const uint32_t hi2 = lo + stride;
                 const bool up = (lo & size) == 0;
-                const uint32_t a = keys[lo], b = keys[hi];
+                const uint32_t a = keys[lo], b = keys[hi2];
                 if ((a > b) == up) {
                     keys[lo] = b;
-                    keys[hi] = a;
+                    keys[hi2] = a;
                 }
             }
             __syncthreads();
         }
     }
-    // unique + take s: position of element i among distinct values = number of
-    // "first occurrences" before it; sequential prefix per thread chunk is enough
-    // for <= 16 K entries: thread 0 of each 1024-chunk... keep it simple and exact:
-    // block-wide stable compaction via per-thread contiguous chunks
+    // stable compaction of first occurrences: per-thread contiguous chunks + block scan
     const uint32_t per = (cnt + blockDim.x - 1) / blockDim.x;
     const uint32_t b0 = min(cnt, threadIdx.x * per), b1 = min(cnt, b0 + per);
     uint32_t mine = 0;
     for (uint32_t i = b0; i < b1; i++) mine += (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
-    // exclusive scan of `mine` over threads (LDS, Hillis-Steele on 1024 entries)
-    __shared__ uint32_t scan[1024];
     scan[threadIdx.x] = mine;
     __syncthreads();
     for (uint32_t o = 1; o < blockDim.x; o <<= 1) {
@@ -174,7 +188,8 @@ __global__ __launch_bounds__(1024) void sort_select_kernel(
         scan[threadIdx.x] += v;
         __syncthreads();
     }
-    uint32_t pos = scan[threadIdx.x] - mine;
+    const uint32_t have = lens[q];
+    uint32_t pos = have + scan[threadIdx.x] - mine;
     uint32_t *sk = sketches + uint64_t(q) * s;
     for (uint32_t i = b0; i < b1; i++) {
         if (i == 0 || keys[i] != keys[i - 1]) {
@@ -182,15 +197,11 @@ __global__ __launch_bounds__(1024) void sort_select_kernel(
             pos++;
         }
     }
+    __syncthreads();  // every thread has read lens[q]
     if (threadIdx.x == blockDim.x - 1) {
-        const uint32_t distinct = scan[threadIdx.x];
-        const bool all = thresh[q] == 0xFFFFFFFFu;
-        if (distinct >= s || all) {
-            lens[q] = min(distinct, s);
-            status[q] = 0;
-        } else {
-            status[q] = 1;
-        }
+        const uint32_t total = have + scan[threadIdx.x];
+        lens[q] = min(total, s);
+        status[q] = (total >= s || hi[q] == 0xFFFFFFFFu) ? 0u : 1u;
     }
 }
 
@@ -294,25 +305,26 @@ extern "C" int dvs_mash_sketch(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_de
         d_seqs = d_seq_own.as<uint8_t>();
     }
 
-    // tiles, thresholds, candidate capacities
+    // tiles and the first hash range (lo, hi] per sequence: hashes are ~uniform, so
+    // hi = 2^32 * (1.5 s + 256) / n_windows holds ~1.5 s candidates; a sequence of
+    // at most SORT_CAP windows takes the whole range at once
     std::vector<MTile> tiles;
-    std::vector<uint32_t> thresh(nseq), cap(nseq), nwin(nseq);
+    std::vector<long long> lo(nseq, -1);
+    std::vector<uint32_t> hi(nseq), cap(nseq), nwin(nseq);
     std::vector<uint64_t> coff(nseq + 1, 0);
-    // expected candidates below T: 1.5 s + 256 (a Poisson count: > 20 sigma above s)
-    const uint64_t want = s + s / 2 + 256;
+    const uint64_t want = uint64_t(s) + s / 2 + 256;
     for (uint32_t q = 0; q < nseq; q++) {
         const uint64_t len = offsets[q + 1] - offsets[q];
         const uint64_t w = len >= k ? len - k + 1 : 0;
         if (w > 0xFFFFFFFFull)
             return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "sequence %u longer than 2^32", q);
         nwin[q] = uint32_t(w);
+        cap[q] = uint32_t(std::min<uint64_t>(std::max<uint64_t>(w, 1), SORT_CAP));
         if (w <= SORT_CAP) {
-            thresh[q] = 0xFFFFFFFFu;  // keep every hash: exact by construction
-            cap[q] = uint32_t(std::max<uint64_t>(w, 1));
+            hi[q] = 0xFFFFFFFFu;
         } else {
-            const long double tv = (long double)want / (long double)w * 4294967296.0L;
-            thresh[q] = tv >= 4294967295.0L ? 0xFFFFFFFFu : uint32_t(tv);
-            cap[q] = SORT_CAP;
+            const long double tv = (long double)std::min<uint64_t>(want, SORT_CAP / 2) / (long double)w * 4294967296.0L;
+            hi[q] = tv >= 4294967295.0L ? 0xFFFFFFFFu : uint32_t(tv);
         }
         coff[q + 1] = coff[q] + cap[q];
         for (uint64_t b = 0; b < w; b += MASH_TILE) {
@@ -323,17 +335,16 @@ extern "C" int dvs_mash_sketch(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_de
             tiles.push_back(t);
         }
     }
-    // capacity of a sequence may have to grow to its window count on retries
-    DevBuf d_tiles, d_thresh, d_cap, d_coff, d_cnt, d_nvalid, d_active, d_cand, d_list, d_sk, d_lens,
-        d_status;
+    DevBuf d_tiles, d_lo, d_hi, d_cap, d_coff, d_cnt, d_active, d_cand, d_list, d_sk, d_lens, d_status;
     const size_t ntile = std::max<size_t>(tiles.size(), 1);
     DVS_HIP(ctx, hipMalloc(&d_tiles.p, ntile * sizeof(MTile)));
-    DVS_HIP(ctx, hipMalloc(&d_thresh.p, nseq * 4));
+    DVS_HIP(ctx, hipMalloc(&d_lo.p, nseq * 8));
+    DVS_HIP(ctx, hipMalloc(&d_hi.p, nseq * 4));
     DVS_HIP(ctx, hipMalloc(&d_cap.p, nseq * 4));
     DVS_HIP(ctx, hipMalloc(&d_coff.p, (nseq + 1) * 8));
     DVS_HIP(ctx, hipMalloc(&d_cnt.p, nseq * 4));
-    DVS_HIP(ctx, hipMalloc(&d_nvalid.p, nseq * 4));
     DVS_HIP(ctx, hipMalloc(&d_active.p, nseq));
+    DVS_HIP(ctx, hipMalloc(&d_cand.p, std::max<uint64_t>(coff[nseq], 1) * 4));
     DVS_HIP(ctx, hipMalloc(&d_list.p, nseq * 4));
     DVS_HIP(ctx, hipMalloc(&d_sk.p, size_t(nseq) * s * 4));
     DVS_HIP(ctx, hipMalloc(&d_lens.p, nseq * 4));
@@ -341,6 +352,8 @@ extern "C" int dvs_mash_sketch(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_de
     if (!tiles.empty())
         DVS_HIP(ctx, hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(MTile),
                                     hipMemcpyHostToDevice, ctx->stream));
+    DVS_HIP(ctx, hipMemcpyAsync(d_cap.p, cap.data(), nseq * 4, hipMemcpyHostToDevice, ctx->stream));
+    DVS_HIP(ctx, hipMemcpyAsync(d_coff.p, coff.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     DVS_HIP(ctx, hipMemsetAsync(d_lens.p, 0, nseq * 4, ctx->stream));
     DVS_HIP(ctx, hipMemsetAsync(d_sk.p, 0, size_t(nseq) * s * 4, ctx->stream));
 
@@ -352,52 +365,53 @@ extern "C" int dvs_mash_sketch(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_de
     DVS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(sort_select_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(sort_lds)));
 
-    for (int round = 0; round < 40; round++) {
+    for (int round = 0;; round++) {
         std::vector<uint32_t> list;
         for (uint32_t q = 0; q < nseq; q++)
             if (active[q]) list.push_back(q);
         if (list.empty()) break;
-        // candidate storage for this round
-        coff[0] = 0;
-        for (uint32_t q = 0; q < nseq; q++) coff[q + 1] = coff[q] + (active[q] ? cap[q] : 0);
-        DevBuf d_round;
-        DVS_HIP(ctx, hipMalloc(&d_round.p, std::max<uint64_t>(coff[nseq], 1) * 4));
-        DVS_HIP(ctx, hipMemcpyAsync(d_thresh.p, thresh.data(), nseq * 4, hipMemcpyHostToDevice, ctx->stream));
-        DVS_HIP(ctx, hipMemcpyAsync(d_cap.p, cap.data(), nseq * 4, hipMemcpyHostToDevice, ctx->stream));
-        DVS_HIP(ctx, hipMemcpyAsync(d_coff.p, coff.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (round >= 200)
+            return dvs_set_error(ctx, DVS_ERR_RUNTIME, "mash sketch range search did not converge");
+        DVS_HIP(ctx, hipMemcpyAsync(d_lo.p, lo.data(), nseq * 8, hipMemcpyHostToDevice, ctx->stream));
+        DVS_HIP(ctx, hipMemcpyAsync(d_hi.p, hi.data(), nseq * 4, hipMemcpyHostToDevice, ctx->stream));
         DVS_HIP(ctx, hipMemcpyAsync(d_active.p, active.data(), nseq, hipMemcpyHostToDevice, ctx->stream));
         DVS_HIP(ctx, hipMemcpyAsync(d_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         DVS_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, nseq * 4, ctx->stream));
-        DVS_HIP(ctx, hipMemsetAsync(d_nvalid.p, 0, nseq * 4, ctx->stream));
         hipLaunchKernelGGL(hash_filter_kernel, dim3(uint32_t(tiles.size())), dim3(MASH_THREADS), 0,
                            ctx->stream, d_seqs, d_tiles.as<MTile>(), k, num_states, mash_canonical,
-                           d_thresh.as<uint32_t>(), d_active.as<uint8_t>(), d_round.as<uint32_t>(),
-                           d_coff.as<uint64_t>(), d_cap.as<uint32_t>(), d_cnt.as<uint32_t>(),
-                           d_nvalid.as<uint32_t>());
+                           d_lo.as<long long>(), d_hi.as<uint32_t>(), d_active.as<uint8_t>(),
+                           d_cand.as<uint32_t>(), d_coff.as<uint64_t>(), d_cap.as<uint32_t>(),
+                           d_cnt.as<uint32_t>());
         hipLaunchKernelGGL(sort_select_kernel, dim3(uint32_t(list.size())), dim3(1024), sort_lds,
-                           ctx->stream, d_list.as<uint32_t>(), d_round.as<uint32_t>(),
+                           ctx->stream, d_list.as<uint32_t>(), d_cand.as<uint32_t>(),
                            d_coff.as<uint64_t>(), d_cap.as<uint32_t>(), d_cnt.as<uint32_t>(),
-                           d_thresh.as<uint32_t>(), s, d_sk.as<uint32_t>(), d_lens.as<uint32_t>(),
+                           d_hi.as<uint32_t>(), s, d_sk.as<uint32_t>(), d_lens.as<uint32_t>(),
                            d_status.as<uint32_t>());
         DVS_HIP(ctx, hipGetLastError());
         DVS_HIP(ctx, hipMemcpyAsync(status.data(), d_status.p, nseq * 4, hipMemcpyDeviceToHost, ctx->stream));
+        DVS_HIP(ctx, hipMemcpyAsync(lens.data(), d_lens.p, nseq * 4, hipMemcpyDeviceToHost, ctx->stream));
         DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (uint32_t q : list) {
+            const uint64_t width = uint64_t((long long)hi[q] - lo[q]);
             if (status[q] == 0) {
                 active[q] = 0;
-            } else if (status[q] == 1) {  // too few distinct below T: raise T
-                const uint64_t t2 = uint64_t(thresh[q]) * 2 + 1;
-                thresh[q] = t2 >= 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(t2);
-            } else {  // more candidates than one workgroup sorts: lower T
-                if (thresh[q] == 0xFFFFFFFFu || want > SORT_CAP / 2)
+            } else if (status[q] == 1) {
+                // everything in (lo, hi] is final; continue above it with a range sized by
+                // the density seen so far (at least doubling)
+                const uint64_t found = std::max<uint32_t>(lens[q], 1);
+                const uint64_t need = s - lens[q];
+                uint64_t next = std::max<uint64_t>(2 * width, uint64_t((long double)(uint64_t(hi[q]) + 1) / found * need * 1.5L));
+                lo[q] = hi[q];
+                const uint64_t nh = uint64_t(hi[q]) + std::max<uint64_t>(next, 1);
+                hi[q] = nh >= 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(nh);
+            } else {
+                // more than SORT_CAP (tile-distinct) candidates in the range: halve it
+                if (width <= 1)
                     return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED,
-                                         "sketch_size %u too large for the device path on sequence %u "
-                                         "(%u windows)", s, q, nwin[q]);
-                thresh[q] = uint32_t(uint64_t(thresh[q]) * 3 / 4);
+                                         "sequence %u: one hash value occurs in more than %u tiles", q, SORT_CAP);
+                hi[q] = uint32_t(lo[q] + (long long)(width / 2));
             }
         }
-        if (round == 39)
-            return dvs_set_error(ctx, DVS_ERR_RUNTIME, "mash sketch threshold search did not converge");
     }
     DVS_HIP(ctx, hipMemcpyAsync(sketches_out, d_sk.p, size_t(nseq) * s * 4, hipMemcpyDeviceToHost, ctx->stream));
     DVS_HIP(ctx, hipMemcpyAsync(lens_out, d_lens.p, nseq * 4, hipMemcpyDeviceToHost, ctx->stream));

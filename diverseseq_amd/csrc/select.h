@@ -24,6 +24,7 @@ struct SelCtl {
     uint32_t ev_n;      // members taking part in the pending leave-one-out pass
     uint32_t ev_risky;  // a sum-to-one check is too close to call on the device
     uint32_t n_windows, n_events, n_accepts;
+    uint32_t n_logged;  // entries of the event log (accepted set changes, for the arbiter)
     double total_jsd, sum_entropy;      // records.rs: total_jsd, summed_entropies
     double thr, band;                   // total_jsd + eps ; width of the undecidable zone
     double he_base;                     // summed_entropies - H(lowest)
@@ -57,11 +58,8 @@ struct SelDev {
     uint32_t *ord = nullptr;             // member order -> slot (Vec::remove / push order)
     uint8_t *inset = nullptr;            // label -> currently a member
     uint32_t *wg_rows = nullptr;         // rows actually read by each scan workgroup (last launch)
-};
-
-struct SelEvent {  // host log for the arbiter: what changed the set, in order
-    uint64_t pos;
-    uint32_t kind;  // 1 replace_lowest, 2 push (kept)
+    unsigned long long *evlog_pos = nullptr;  // accepted events in order: stream position ...
+    uint32_t *evlog_kind = nullptr;           // ... and kind (1 replace_lowest, 2 kept push)
 };
 
 struct dvs_select {

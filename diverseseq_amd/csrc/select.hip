@@ -296,6 +296,9 @@ __global__ __launch_bounds__(WIDE_THREADS) void resolve_kernel(SelDev d, const T
             d.mLabel[s] = lab;
             d.mPos[s] = p;
             ctl->n_accepts++;
+            d.evlog_pos[ctl->n_logged] = p;
+            d.evlog_kind[ctl->n_logged] = 1;
+            ctl->n_logged++;
         }
         __syncthreads();
         double sm2;
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void finalize_kernel(SelDev d) {
             if (tie) {
                 ctl->status = SEL_ARBITER;
                 ctl->arb_stage = ARB_FINALIZE;
-                ctl->arb_pos = ctl->cursor - 1;
+                ctl->arb_pos = (kind == 2) ? d.mPos[n - 1] : ctl->cursor - 1;
                 go = -1;
             }
         }
@@ -511,6 +514,9 @@ __global__ __launch_bounds__(WIDE_THREADS) void finalize_kernel(SelDev d) {
                 if (lab < d.nlabels) d.inset[lab] = 1;
                 ctl->size = n;
                 ctl->n_accepts++;
+                d.evlog_pos[ctl->n_logged] = d.mPos[n - 1];
+                d.evlog_kind[ctl->n_logged] = 2;
+                ctl->n_logged++;
             }
             ctl->lowest = lowest;
             ctl->mean_delta = mean;
@@ -592,7 +598,8 @@ static void sel_free(dvs_select *s) {
     if (!s) return;
     void *ptrs[] = {s->dev.ctl, s->dev.S, s->dev.Stmp, s->dev.base, s->dev.cand, s->dev.M,
                     s->dev.mH, s->dev.mDelta, s->dev.dtmp, s->dev.dsum, s->dev.mLabel, s->dev.mPos,
-                    s->dev.ord, s->dev.inset, s->dev.wg_rows, (void *)s->dev.order, (void *)s->dev.labels};
+                    s->dev.ord, s->dev.inset, s->dev.wg_rows, s->dev.evlog_pos, s->dev.evlog_kind,
+                    (void *)s->dev.order, (void *)s->dev.labels};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
@@ -601,10 +608,11 @@ static void sel_free(dvs_select *s) {
     delete s;
 }
 
+// stage 0: scan + resolve + loo + finalize; 1: resolve + loo + finalize; 2: loo + finalize
 template <typename T>
-static void launch_iteration(dvs_ctx *ctx, dvs_select *s, const T *mat, bool with_scan) {
+static void launch_iteration(dvs_ctx *ctx, dvs_select *s, const T *mat, int stage) {
     const SelDev &d = s->dev;
-    if (with_scan) {
+    if (stage == 0) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (s->time_scan) {
             if (s->ev_used + 2 > s->ev_pool.size()) {
@@ -623,9 +631,10 @@ static void launch_iteration(dvs_ctx *ctx, dvs_select *s, const T *mat, bool wit
                            ctx->stream, d.ctl, mat, d.totals, d.rowH, d.order, d.labels, d.inset,
                            d.nlabels, d.base, d.wg_rows, d.B, s->base_in_lds ? 1 : 0);
         if (s->time_scan) (void)hipEventRecord(e1, ctx->stream);
+    }
+    if (stage <= 1)
         hipLaunchKernelGGL((resolve_kernel<T>), dim3(1), dim3(WIDE_THREADS), 0, ctx->stream, d, mat,
                            s->scan_grid);
-    }
     hipLaunchKernelGGL(loo_kernel, dim3(s->loo_grid), dim3(LOO_THREADS), 0, ctx->stream, d);
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(WIDE_THREADS), 0, ctx->stream, d);
 }
@@ -662,13 +671,13 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat) {
                                      (unsigned long long)c.arb_pos, c.arb_stage);
             rc = dvs_select_arbitrate(ctx, s);
             if (rc) return rc;
-            if (s->mat_kind == 0)
-                launch_iteration<T>(ctx, s, mat, s->h_ctl->arb_stage == ARB_RESOLVE);
+            launch_iteration<T>(ctx, s, mat, c.arb_stage == ARB_RESOLVE ? 1 : 2);
+            DVS_HIP(ctx, hipGetLastError());
             continue;
         }
         if (c.status != SEL_RUN)
             return dvs_set_error(ctx, DVS_ERR_RUNTIME, "selection engine in state %u", c.status);
-        for (int i = 0; i < s->batch; i++) launch_iteration<T>(ctx, s, mat, true);
+        for (int i = 0; i < s->batch; i++) launch_iteration<T>(ctx, s, mat, 0);
         DVS_HIP(ctx, hipGetLastError());
     }
 }
@@ -682,7 +691,7 @@ static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat, const std::vecto
     hipLaunchKernelGGL((seed_kernel<T>), dim3(uint32_t(seeds.size())), dim3(LOO_THREADS), 0,
                        ctx->stream, s->dev, mat, d_seed);
     hipLaunchKernelGGL(rebuild_kernel, dim3(1), dim3(WIDE_THREADS), 0, ctx->stream, s->dev);
-    launch_iteration<T>(ctx, s, mat, false);  // loo + finalize of the initial set
+    launch_iteration<T>(ctx, s, mat, 2);  // loo + finalize of the initial set
     DVS_HIP(ctx, hipGetLastError());
     DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     (void)hipFree(d_seed);
@@ -793,6 +802,8 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     SEL_ALLOC(d.ord, size_t(cap) * 4);
     SEL_ALLOC(d.inset, std::max<size_t>(nlabels, 1));
     SEL_ALLOC(d.wg_rows, size_t(s->scan_grid) * 4);
+    SEL_ALLOC(d.evlog_pos, size_t(npos - n_seed + 2) * 8);
+    SEL_ALLOC(d.evlog_kind, size_t(npos - n_seed + 2) * 4);
     if (order) {
         SEL_ALLOC(d.order, size_t(npos) * 4);
         DVS_HIP(ctx, hipMemcpyAsync((void *)d.order, order, size_t(npos) * 4, hipMemcpyHostToDevice,
