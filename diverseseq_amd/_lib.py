@@ -24,12 +24,12 @@ SELECT_NO_ARBITER = 1
 # every symbol include/dvs_hip.h declares (tests/test_boundary.py checks the .so exports them)
 EXPORTS = (
     "dvs_abi_version", "dvs_ctx_create", "dvs_ctx_destroy", "dvs_last_error", "dvs_ctx_sync",
-    "dvs_ctx_device_info", "dvs_ctx_set_timing", "dvs_matrix_build", "dvs_matrix_from_freqs",
+    "dvs_ctx_trim", "dvs_ctx_device_info", "dvs_ctx_set_timing", "dvs_matrix_build", "dvs_matrix_from_freqs",
     "dvs_matrix_destroy", "dvs_matrix_nrows", "dvs_matrix_nbins", "dvs_matrix_dev_counts",
     "dvs_matrix_dev_totals", "dvs_matrix_dev_entropy", "dvs_matrix_get_counts",
     "dvs_matrix_get_totals", "dvs_matrix_get_entropy", "dvs_kmer_counts", "dvs_select_run",
     "dvs_select_destroy", "dvs_select_get_summary", "dvs_select_get_members",
-    "dvs_select_delta_jsd", "dvs_mash_sketch", "dvs_mash_distances", "dvs_euclidean_distances",
+    "dvs_select_delta_jsd", "dvs_selftest_fast_log2", "dvs_mash_sketch", "dvs_mash_distances", "dvs_euclidean_distances",
 )
 
 
@@ -106,6 +106,7 @@ def load() -> C.CDLL:
         L.dvs_last_error.argtypes = [vp]
         L.dvs_last_error.restype = C.c_char_p
         L.dvs_ctx_sync.argtypes = [vp]
+        L.dvs_ctx_trim.argtypes = [vp]
         L.dvs_ctx_set_timing.argtypes = [vp, C.c_int]
         L.dvs_ctx_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), u64p]
         L.dvs_matrix_build.argtypes = [vp, vp, C.c_int, u64p, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -132,6 +133,7 @@ def load() -> C.CDLL:
         L.dvs_select_get_summary.argtypes = [vp, vp, C.POINTER(SelectSummary)]
         L.dvs_select_get_members.argtypes = [vp, vp, u64p, u32p, f64p, f64p, f64p]
         L.dvs_select_delta_jsd.argtypes = [vp, vp, vp, u32p, f64p]
+        L.dvs_selftest_fast_log2.argtypes = [vp, f64p]
         L.dvs_mash_sketch.argtypes = [vp, vp, C.c_int, u64p, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.c_uint32, C.c_int, u32p, u32p]
         L.dvs_mash_distances.argtypes = [vp, u32p, C.c_uint32, u32p, C.c_uint32, C.c_uint32,

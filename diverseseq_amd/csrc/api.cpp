@@ -30,6 +30,49 @@ int dvs_hip_fail(dvs_ctx *ctx, hipError_t e, const char *what) {
     return dvs_set_error(ctx, code, "HIP error %d (%s) in %s", int(e), hipGetErrorString(e), what);
 }
 
+int dvs_dev_alloc(dvs_ctx *ctx, void **ptr, size_t bytes, const char *what) {
+    const size_t sz = ((bytes ? bytes : 1) + 4095) & ~size_t(4095);
+    auto it = ctx->pool.find(sz);
+    if (it != ctx->pool.end()) {
+        *ptr = it->second;
+        ctx->pool.erase(it);
+        ctx->pool_bytes -= sz;
+        ctx->live[*ptr] = sz;
+        return DVS_OK;
+    }
+    hipError_t e = hipMalloc(ptr, sz);
+    if (e != hipSuccess && !ctx->pool.empty()) {
+        (void)hipGetLastError();
+        dvs_dev_trim(ctx);
+        e = hipMalloc(ptr, sz);
+    }
+    if (e != hipSuccess) {
+        *ptr = nullptr;
+        return dvs_hip_fail(ctx, e, what);
+    }
+    ctx->live[*ptr] = sz;
+    return DVS_OK;
+}
+
+void dvs_dev_free(dvs_ctx *ctx, void *ptr) {
+    if (!ptr) return;
+    auto it = ctx ? ctx->live.find(ptr) : std::map<void *, size_t>::iterator();
+    if (!ctx || it == ctx->live.end()) {
+        (void)hipFree(ptr);
+        return;
+    }
+    ctx->pool.emplace(it->second, ptr);
+    ctx->pool_bytes += it->second;
+    ctx->live.erase(it);
+}
+
+void dvs_dev_trim(dvs_ctx *ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->pool) (void)hipFree(kv.second);
+    ctx->pool.clear();
+    ctx->pool_bytes = 0;
+}
+
 extern "C" {
 
 int dvs_abi_version(void) { return DVS_ABI_VERSION; }
@@ -76,11 +119,19 @@ int dvs_ctx_create(int device, void *stream, dvs_ctx **out) {
 
 void dvs_ctx_destroy(dvs_ctx *ctx) {
     if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    dvs_dev_trim(ctx);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 const char *dvs_last_error(const dvs_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int dvs_ctx_trim(dvs_ctx *ctx) {
+    if (!ctx) return DVS_ERR_VALUE;
+    dvs_dev_trim(ctx);
+    return DVS_OK;
+}
 
 int dvs_ctx_sync(dvs_ctx *ctx) {
     if (!ctx) return DVS_ERR_VALUE;
@@ -111,16 +162,18 @@ static int matrix_alloc(dvs_ctx *ctx, dvs_matrix *m) {
     const size_t bytes = cells * (m->kind == 0 ? 4 : 8);
     size_t free_b = 0, total_b = 0;
     DVS_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
-    if (bytes + size_t(m->nrows) * 12 + (64u << 20) > free_b)
+    if (bytes + size_t(m->nrows) * 12 + (64u << 20) > free_b + ctx->pool_bytes)
         return dvs_set_error(ctx, DVS_ERR_NOMEM,
                              "%u x %llu matrix needs %zu bytes of HBM, %zu free", m->nrows,
                              (unsigned long long)m->nbins, bytes, free_b);
     const size_t nr = m->nrows ? m->nrows : 1;
-    if (m->kind == 0) DVS_HIP(ctx, hipMalloc(&m->d_counts, bytes ? bytes : 4));
-    else DVS_HIP(ctx, hipMalloc(&m->d_freqs, bytes ? bytes : 8));
-    DVS_HIP(ctx, hipMalloc(&m->d_totals, nr * 4));
-    DVS_HIP(ctx, hipMalloc(&m->d_entropy, nr * 8));
-    return DVS_OK;
+    m->ctx = ctx;
+    int rc;
+    if (m->kind == 0) rc = dvs_dev_alloc(ctx, (void **)&m->d_counts, bytes ? bytes : 4, "matrix counts");
+    else rc = dvs_dev_alloc(ctx, (void **)&m->d_freqs, bytes ? bytes : 8, "matrix freqs");
+    if (!rc) rc = dvs_dev_alloc(ctx, (void **)&m->d_totals, nr * 4, "matrix totals");
+    if (!rc) rc = dvs_dev_alloc(ctx, (void **)&m->d_entropy, nr * 8, "matrix entropy");
+    return rc;
 }
 
 int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, const uint64_t *offsets,
@@ -157,11 +210,11 @@ int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, cons
     uint64_t readable = nbytes;
     if (!seqs_on_device) {
         const uint64_t padded = ((nbytes + 15) & ~15ull) + 16;
-        hipError_t e = hipMalloc(&d_tmp, padded);
-        if (e != hipSuccess) {
+        rc = dvs_dev_alloc(ctx, (void **)&d_tmp, padded, "sequence upload buffer");
+        if (rc) {
             dvs_matrix_free_fields(m);
             delete m;
-            return dvs_hip_fail(ctx, e, "hipMalloc(sequences)");
+            return rc;
         }
         (void)hipMemsetAsync(d_tmp + (nbytes & ~15ull), 0xFF, padded - (nbytes & ~15ull), ctx->stream);
         if (nbytes)
@@ -177,7 +230,7 @@ int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, cons
               : DVS_OK;
     if (d_tmp) {
         (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(d_tmp);
+        dvs_dev_free(ctx, d_tmp);
     }
     if (rc) {
         dvs_matrix_free_fields(m);

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -21,7 +22,18 @@ struct dvs_ctx {
     size_t lds_per_block = 0;  // max dynamic LDS a block may ask for
     bool timing = false;
     std::string err;
+    // device-memory cache: blocks released by dvs_dev_free are kept by size and
+    // handed back by dvs_dev_alloc, so a steady-state loop (build matrix, select,
+    // destroy) performs no hipMalloc / hipFree.  Released for real in
+    // dvs_ctx_destroy, dvs_ctx_trim or when an allocation fails.
+    std::multimap<size_t, void *> pool;
+    std::map<void *, size_t> live;
+    size_t pool_bytes = 0;
 };
+
+int dvs_dev_alloc(dvs_ctx *ctx, void **ptr, size_t bytes, const char *what);
+void dvs_dev_free(dvs_ctx *ctx, void *ptr);
+void dvs_dev_trim(dvs_ctx *ctx);
 
 int dvs_set_error(dvs_ctx *ctx, int code, const char *fmt, ...);
 int dvs_hip_fail(dvs_ctx *ctx, hipError_t e, const char *what);
@@ -43,6 +55,7 @@ struct dvs_matrix {
     uint32_t *d_totals = nullptr;  // valid k-mers per row (kind 1: 1 for every row)
     double *d_entropy = nullptr;   // H(row freq vector), bits
     int device = 0;
+    dvs_ctx *ctx = nullptr;  // owner of the allocations
 };
 
 // ---- device helpers -------------------------------------------------------

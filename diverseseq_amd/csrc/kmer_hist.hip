@@ -88,13 +88,27 @@ __device__ __forceinline__ double clog2c(uint32_t c, const double *tbl) {
 }
 
 // LDS: [hist B u32 (LDS_HIST)] [tbl 256 f64] [scratch 32 f64]
+// tiles == NULL: workgroup b owns sequence b outright (its tile comes from the
+// offsets; sequences needing more than one tile are left to the tile-list launch).
 template <bool NS4, bool LDS_HIST>
 __global__ __launch_bounds__(HIST_THREADS) void kmer_hist_kernel(
-    const uint8_t *__restrict__ seqs, uint64_t nbytes, const KTile *__restrict__ tiles,
-    uint32_t *__restrict__ counts, uint32_t *__restrict__ totals,
+    const uint8_t *__restrict__ seqs, uint64_t nbytes, const uint64_t *__restrict__ offsets,
+    const KTile *__restrict__ tiles, uint32_t *__restrict__ counts, uint32_t *__restrict__ totals,
     double *__restrict__ entropy, uint32_t k, uint32_t ns, uint64_t B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const KTile t = tiles[blockIdx.x];
+    KTile t;
+    if (tiles) {
+        t = tiles[blockIdx.x];
+    } else {
+        const uint64_t s0 = offsets[blockIdx.x], s1 = offsets[blockIdx.x + 1];
+        t.row = blockIdx.x;
+        t.single = 1;
+        t.seq_begin = s0;
+        t.begin = s0 + k - 1;
+        t.end = s1;
+        if (s1 - s0 >= k && s1 - t.begin > TILE_LEN) return;  // multi-tile: other launch
+        if (s1 - s0 < k) t.begin = t.end = s1;               // windows(k) empty: all-zero row
+    }
     uint32_t *row = counts + uint64_t(t.row) * B;
     uint32_t *hist = LDS_HIST ? reinterpret_cast<uint32_t *>(smem) : row;
     double *tbl = reinterpret_cast<double *>(smem + (LDS_HIST ? ((B * 4 + 15) & ~15ull) : 0));
@@ -113,7 +127,7 @@ __global__ __launch_bounds__(HIST_THREADS) void kmer_hist_kernel(
     __syncthreads();
 
     const uint64_t abase = t.begin & ~15ull;
-    const uint64_t nchunks = (t.end - abase + 15) >> 4;
+    const uint64_t nchunks = t.end > t.begin ? (t.end - abase + 15) >> 4 : 0;
     const uint32_t kmask = (k >= 32) ? 0xFFFFFFFFu : ((1u << k) - 1u);
     const uint32_t bmask = uint32_t(B - 1);  // NS4: B = 4^k, power of two (k = 16 -> 2^32 - 1)
 
@@ -152,6 +166,7 @@ __global__ __launch_bounds__(HIST_THREADS) void kmer_hist_kernel(
             }
         }
     }
+    if (!LDS_HIST) __threadfence();  // this thread's global atomics on `row` have been performed
     __syncthreads();
 
     if (t.single) {
@@ -175,7 +190,6 @@ __global__ __launch_bounds__(HIST_THREADS) void kmer_hist_kernel(
                 }
             }
         } else {
-            __threadfence();  // this block's global atomics on `row` are complete and visible to it
             for (uint64_t i = tid; i < B; i += HIST_THREADS) {
                 const uint32_t v = __hip_atomic_load(&row[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s += clog2c(v, tbl);
@@ -264,10 +278,10 @@ uint64_t dvs_pow_u64(uint32_t base, uint32_t exp, bool *overflow) {
 
 void dvs_matrix_free_fields(dvs_matrix *m) {
     if (!m) return;
-    if (m->d_counts) (void)hipFree(m->d_counts);
-    if (m->d_freqs) (void)hipFree(m->d_freqs);
-    if (m->d_totals) (void)hipFree(m->d_totals);
-    if (m->d_entropy) (void)hipFree(m->d_entropy);
+    dvs_dev_free(m->ctx, m->d_counts);
+    dvs_dev_free(m->ctx, m->d_freqs);
+    dvs_dev_free(m->ctx, m->d_totals);
+    dvs_dev_free(m->ctx, m->d_entropy);
     m->d_counts = nullptr;
     m->d_freqs = nullptr;
     m->d_totals = nullptr;
@@ -275,92 +289,98 @@ void dvs_matrix_free_fields(dvs_matrix *m) {
 }
 
 // Launches the histogram build for sequences already in HBM (d_seqs, nbytes
-// readable) into an allocated matrix.  Asynchronous on ctx->stream except for
-// the small tile-list upload.
+// readable) into an allocated matrix.  One launch gives every sequence that fits
+// a single tile its own workgroup (tile derived from the offsets on the device);
+// genome-length sequences get an explicit tile list and a second launch.
 int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
                            uint64_t nbytes, const uint64_t *offsets) {
     const uint32_t nseq = m->nrows, k = m->k, ns = m->num_states;
     const uint64_t B = m->nbins;
     std::vector<KTile> tiles;
-    std::vector<uint32_t> zero_rows, stat_rows;
-    tiles.reserve(nseq);
+    std::vector<uint32_t> long_rows;
     for (uint32_t r = 0; r < nseq; r++) {
         const uint64_t s0 = offsets[r], s1 = offsets[r + 1];
         if (s1 < s0 || s1 > nbytes)
             return dvs_set_error(ctx, DVS_ERR_VALUE, "offsets[%u..%u] = %llu..%llu out of range", r,
                                  r + 1, (unsigned long long)s0, (unsigned long long)s1);
-        if (s1 - s0 < k) {  // windows(k) empty -> all-zero row (record.rs:57)
-            zero_rows.push_back(r);
-            stat_rows.push_back(r);
-            continue;
-        }
+        if (s1 - s0 < k) continue;
         const uint64_t first = s0 + k - 1;
-        const uint64_t ntile = (s1 - first + TILE_LEN - 1) / TILE_LEN;
-        if (ntile > 1) {
-            zero_rows.push_back(r);
-            stat_rows.push_back(r);
-        }
-        for (uint64_t i = 0; i < ntile; i++) {
+        if (s1 - first <= TILE_LEN) continue;
+        long_rows.push_back(r);
+        for (uint64_t b = first; b < s1; b += TILE_LEN) {
             KTile t;
-            t.begin = first + i * TILE_LEN;
-            t.end = std::min<uint64_t>(t.begin + TILE_LEN, s1);
+            t.begin = b;
+            t.end = std::min<uint64_t>(b + TILE_LEN, s1);
             t.seq_begin = s0;
             t.row = r;
-            t.single = ntile == 1;
+            t.single = 0;
             tiles.push_back(t);
         }
     }
     const bool lds_hist = B * 4 <= 64 * 1024;
     const bool ns4 = ns == 4;
-    if (!lds_hist) {  // the rows take the atomics directly: all must start at zero
-        zero_rows.clear();
-        DVS_HIP(ctx, hipMemsetAsync(m->d_counts, 0, size_t(nseq) * B * 4, ctx->stream));
-    }
+    uint64_t *d_off = nullptr;
     uint32_t *d_rows = nullptr;
     KTile *d_tiles = nullptr;
-    const size_t nlist = zero_rows.size() + stat_rows.size();
-    if (nlist) {
-        DVS_HIP(ctx, hipMalloc(&d_rows, nlist * sizeof(uint32_t)));
-        if (!zero_rows.empty())
-            DVS_HIP(ctx, hipMemcpyAsync(d_rows, zero_rows.data(), zero_rows.size() * 4,
-                                        hipMemcpyHostToDevice, ctx->stream));
-        if (!stat_rows.empty())
-            DVS_HIP(ctx, hipMemcpyAsync(d_rows + zero_rows.size(), stat_rows.data(),
-                                        stat_rows.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    int rc = dvs_dev_alloc(ctx, (void **)&d_off, size_t(nseq + 1) * 8, "offsets");
+    if (!rc && !long_rows.empty()) rc = dvs_dev_alloc(ctx, (void **)&d_rows, long_rows.size() * 4, "row list");
+    if (!rc && !tiles.empty()) rc = dvs_dev_alloc(ctx, (void **)&d_tiles, tiles.size() * sizeof(KTile), "tile list");
+    auto cleanup = [&]() {
+        dvs_dev_free(ctx, d_off);
+        dvs_dev_free(ctx, d_rows);
+        dvs_dev_free(ctx, d_tiles);
+    };
+    if (rc) {
+        cleanup();
+        return rc;
     }
-    if (!zero_rows.empty())
-        hipLaunchKernelGGL(zero_rows_kernel, dim3(uint32_t(zero_rows.size())), dim3(HIST_THREADS), 0,
-                           ctx->stream, m->d_counts, d_rows, B);
-    if (!tiles.empty()) {
-        DVS_HIP(ctx, hipMalloc(&d_tiles, tiles.size() * sizeof(KTile)));
-        DVS_HIP(ctx, hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(KTile),
-                                    hipMemcpyHostToDevice, ctx->stream));
-        const size_t lds = (lds_hist ? ((B * 4 + 15) & ~15ull) : 0) + (CLOG_TBL + 32) * sizeof(double);
-        const dim3 grid{uint32_t(tiles.size())}, block{HIST_THREADS};
-#define DVS_LAUNCH_HIST(NS4, LH)                                                                \
-    do {                                                                                        \
-        int rc__ = set_dyn_lds(ctx, kmer_hist_kernel<NS4, LH>, lds);                            \
-        if (rc__) return rc__;                                                                  \
-        hipLaunchKernelGGL((kmer_hist_kernel<NS4, LH>), grid, block, lds, ctx->stream, d_seqs,  \
-                           nbytes, d_tiles, m->d_counts, m->d_totals, m->d_entropy, k, ns, B);  \
+    hipError_t e = hipMemcpyAsync(d_off, offsets, size_t(nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && !lds_hist)  // the rows take the atomics directly: all start at zero
+        e = hipMemsetAsync(m->d_counts, 0, size_t(nseq) * B * 4, ctx->stream);
+    if (e == hipSuccess && !long_rows.empty()) {
+        e = hipMemcpyAsync(d_rows, long_rows.data(), long_rows.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(KTile), hipMemcpyHostToDevice,
+                               ctx->stream);
+        if (e == hipSuccess && lds_hist)
+            hipLaunchKernelGGL(zero_rows_kernel, dim3(uint32_t(long_rows.size())), dim3(HIST_THREADS), 0,
+                               ctx->stream, m->d_counts, d_rows, B);
+    }
+    if (e != hipSuccess) {
+        cleanup();
+        return dvs_hip_fail(ctx, e, "histogram setup");
+    }
+    const size_t lds = (lds_hist ? ((B * 4 + 15) & ~15ull) : 0) + (CLOG_TBL + 32) * sizeof(double);
+#define DVS_LAUNCH_HIST(NS4, LH, GRID, TILES)                                                    \
+    do {                                                                                         \
+        rc = set_dyn_lds(ctx, kmer_hist_kernel<NS4, LH>, lds);                                   \
+        if (!rc)                                                                                 \
+            hipLaunchKernelGGL((kmer_hist_kernel<NS4, LH>), dim3(GRID), dim3(HIST_THREADS), lds, \
+                               ctx->stream, d_seqs, nbytes, d_off, TILES, m->d_counts,           \
+                               m->d_totals, m->d_entropy, k, ns, B);                             \
     } while (0)
-        if (ns4 && lds_hist) DVS_LAUNCH_HIST(true, true);
-        else if (ns4) DVS_LAUNCH_HIST(true, false);
-        else if (lds_hist) DVS_LAUNCH_HIST(false, true);
-        else DVS_LAUNCH_HIST(false, false);
+#define DVS_LAUNCH_HIST_ANY(GRID, TILES)                            \
+    do {                                                            \
+        if (ns4 && lds_hist) DVS_LAUNCH_HIST(true, true, GRID, TILES);   \
+        else if (ns4) DVS_LAUNCH_HIST(true, false, GRID, TILES);         \
+        else if (lds_hist) DVS_LAUNCH_HIST(false, true, GRID, TILES);    \
+        else DVS_LAUNCH_HIST(false, false, GRID, TILES);                 \
+    } while (0)
+    DVS_LAUNCH_HIST_ANY(nseq, static_cast<const KTile *>(nullptr));
+    if (!rc && !tiles.empty()) {
+        DVS_LAUNCH_HIST_ANY(uint32_t(tiles.size()), d_tiles);
+        if (!rc)
+            hipLaunchKernelGGL(row_stats_kernel, dim3(uint32_t(long_rows.size())), dim3(HIST_THREADS), 0,
+                               ctx->stream, m->d_counts, d_rows, m->d_totals, m->d_entropy, B);
+    }
+#undef DVS_LAUNCH_HIST_ANY
 #undef DVS_LAUNCH_HIST
-        DVS_HIP(ctx, hipGetLastError());
-    }
-    if (!stat_rows.empty()) {
-        hipLaunchKernelGGL(row_stats_kernel, dim3(uint32_t(stat_rows.size())), dim3(HIST_THREADS), 0,
-                           ctx->stream, m->d_counts, d_rows + zero_rows.size(), m->d_totals,
-                           m->d_entropy, B);
-        DVS_HIP(ctx, hipGetLastError());
-    }
-    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // tile lists are freed below
-    if (d_rows) (void)hipFree(d_rows);
-    if (d_tiles) (void)hipFree(d_tiles);
-    return DVS_OK;
+    if (!rc && (e = hipGetLastError()) != hipSuccess) rc = dvs_hip_fail(ctx, e, "histogram launch");
+    // the lists go back to the cache; stream order protects them until the kernels ran
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc)
+        rc = dvs_set_error(ctx, DVS_ERR_RUNTIME, "histogram kernels failed");
+    cleanup();
+    return rc;
 }
 
 int dvs_matrix_fill_freq_entropy(dvs_ctx *ctx, dvs_matrix *m) {

@@ -63,6 +63,7 @@ struct SelDev {
 };
 
 struct dvs_select {
+    dvs_ctx *ctx = nullptr;
     dvs_select_params params{};
     const dvs_matrix *mat = nullptr;
     int mat_kind = 0;
@@ -76,6 +77,7 @@ struct dvs_select {
     uint32_t scan_grid = 0, loo_grid = 0;
     size_t scan_lds = 0;
     bool base_in_lds = true;
+    bool scan_hot = false;
     int batch = 16;
     // timing
     bool time_scan = false;

@@ -28,10 +28,11 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 namespace {
 
-constexpr int SCAN_THREADS = 256;   // 4 waves, one row per wave at a time
+constexpr int SCAN_THREADS = 512;   // 8 waves share one LDS copy of the state vector
 constexpr int WIDE_THREADS = 1024;  // single-block state kernels
 constexpr int LOO_THREADS = 256;
 
@@ -62,29 +63,243 @@ __device__ __forceinline__ double row_value(const double *row, uint64_t i) { ret
 // ---------------------------------------------------------------- scan kernel
 // One wavefront per candidate row; lane l owns bins 4*(j*64 + l) .. +3 so that a
 // wave instruction reads 1 KiB (16 B per lane) of the row.  The per-state vector
-// b_i = (S_i - low_i) / size is staged once per workgroup in LDS.
+// b_i = (S_i - low_i) / size is staged once per workgroup in LDS (8 waves share it).
 //   x_i = b_i + c_i / (total * size)      (reference: (S_i - low_i + f_i) / size)
 //   jsd = sum_i -x_i log2 x_i - (sumH - H_low + H_c) / size
-// Event <=> jsd > thr - band (NaN compares false: the reference rejects too).
+//
+// Two tiers.  FAST: x in f64, log2 x = exponent + v_log_f32(mantissa) -- the
+// mantissa is rounded to f32 (<= 2^-24 relative -> <= 8.6e-8 in log2) and
+// v_log_f32 is good to ~1 ulp of a result in [-1, 0] (<= 6e-8), so each log is
+// off by < 1.5e-7 and, as sum x_i = 1, so is the row's entropy (FAST_BAND below;
+// the bound on v_log_f32 is measured exhaustively by dvs_selftest_fast_log2).
+// A row whose fast score clears thr + band + FAST_BAND is an event outright; a
+// row within FAST_BAND (+ band) of the threshold is re-evaluated by the same wave
+// in full f64 (PRECISE) and is an event <=> precise jsd > thr - band.  Either way
+// the resolve kernel re-evaluates the first event in f64 before acting (NaN
+// compares false everywhere: the reference rejects too).
+constexpr double FAST_BAND = 4e-7;
+constexpr int SCAN_CH = 16;  // chunks (1 KiB per wave instruction) requested per batch
+
+__device__ __forceinline__ double fast_neg_xlog2x(double x) {
+    const double xm = fmax(x, 1e-300);  // x <= 0 contributes ~0 here; sign handled via min(x)
+    const double m = __builtin_amdgcn_frexp_mant(xm);       // [0.5, 1)
+    const int e = __builtin_amdgcn_frexp_exp(xm);
+    const float l = __builtin_amdgcn_logf(float(m));        // v_log_f32 = log2
+    return -xm * (double(e) + double(l));
+}
+
+// 4 consecutive bins as they sit in memory (converted to f64 only when consumed, so a
+// batch of in-flight chunks costs 4 VGPRs each for a count matrix)
+template <typename T> struct Raw4;
+template <> struct Raw4<uint32_t> {
+    uint4 c;
+    __device__ __forceinline__ void load(const uint32_t *p) { c = *reinterpret_cast<const uint4 *>(p); }
+    __device__ __forceinline__ void get(double &v0, double &v1, double &v2, double &v3) const {
+        v0 = double(c.x); v1 = double(c.y); v2 = double(c.z); v3 = double(c.w);
+    }
+};
+template <> struct Raw4<double> {
+    double2 a, b;
+    __device__ __forceinline__ void load(const double *p) {
+        a = *reinterpret_cast<const double2 *>(p);
+        b = *reinterpret_cast<const double2 *>(p + 2);
+    }
+    __device__ __forceinline__ void get(double &v0, double &v1, double &v2, double &v3) const {
+        v0 = a.x; v1 = a.y; v2 = b.x; v3 = b.y;
+    }
+};
+
 template <typename T>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(
+__device__ __forceinline__ void load4(const T *rp, uint64_t i, double &v0, double &v1, double &v2,
+                                      double &v3) {
+    if constexpr (sizeof(T) == 4) {
+        const uint4 c = *reinterpret_cast<const uint4 *>(rp + i);
+        v0 = double(c.x); v1 = double(c.y); v2 = double(c.z); v3 = double(c.w);
+    } else {
+        const double2 a = *reinterpret_cast<const double2 *>(rp + i);
+        const double2 b = *reinterpret_cast<const double2 *>(rp + i + 2);
+        v0 = a.x; v1 = a.y; v2 = b.x; v3 = b.y;
+    }
+}
+
+// per-launch constants of the scan, read once from the control block
+struct ScanState {
+    uint64_t cursor, nrows;
+    double thr_lo, thr_fast, thr_sure, he_base, dsize;
+};
+
+__device__ __forceinline__ void fast4(const double2 b01, const double2 b23, double v0, double v1,
+                                      double v2, double v3, double rinv, double &a0, double &a1,
+                                      double &a2, double &a3, double &xmin) {
+    const double x0 = fma(v0, rinv, b01.x), x1 = fma(v1, rinv, b01.y);
+    const double x2 = fma(v2, rinv, b23.x), x3 = fma(v3, rinv, b23.y);
+    a0 += fast_neg_xlog2x(x0);
+    a1 += fast_neg_xlog2x(x1);
+    a2 += fast_neg_xlog2x(x2);
+    a3 += fast_neg_xlog2x(x3);
+    xmin = fmin(fmin(xmin, fmin(x0, x1)), fmin(x2, x3));
+}
+
+// PRECISE tier for one row (rare): same bins, f64 log2; true if it clears thr - band
+template <typename T>
+__device__ __forceinline__ bool precise_row(const T *rp, const double *bvec, uint64_t B, double rinv,
+                                            double mean_entropy, double thr_lo, uint32_t lane) {
+    Ent e;
+    if ((B & 255) == 0) {
+        for (uint64_t i0 = 0; i0 < B; i0 += 256) {
+            const uint64_t i = i0 + lane * 4;
+            double v0, v1, v2, v3;
+            load4(rp, i, v0, v1, v2, v3);
+            e.add(fma(v0, rinv, bvec[i]));
+            e.add(fma(v1, rinv, bvec[i + 1]));
+            e.add(fma(v2, rinv, bvec[i + 2]));
+            e.add(fma(v3, rinv, bvec[i + 3]));
+        }
+    } else {
+        for (uint64_t i = lane; i < B; i += 64) e.add(fma(row_value(rp, i), rinv, bvec[i]));
+    }
+    const double h = dvs_wave_sum(e.h);
+    return h - mean_entropy > thr_lo;
+}
+
+// Hot row loop of one wave: identity order, unique ids, B a multiple of 256 * SCAN_CH
+// bins.  A row is consumed in batches of SCAN_CH chunks of 1 KiB per wave instruction,
+// each batch requested in one burst before any of it is consumed.
+template <typename T>
+__device__ __forceinline__ void scan_rows_hot(SelCtl *ctl, const T *__restrict__ mat,
+                                              const uint32_t *__restrict__ totals,
+                                              const double *__restrict__ rowH, const double *bvec,
+                                              uint64_t B, const ScanState &st, uint64_t first,
+                                              uint64_t stride, uint32_t lane, uint32_t &nread,
+                                              uint32_t &nprecise) {
+    for (uint64_t r = first; r < st.nrows; r += stride) {
+        const uint64_t p = st.cursor + r;
+        const T *rp = mat + p * B;
+        // the event word and the row's total / entropy in one round trip
+        const unsigned long long ev =
+            __hip_atomic_load(&ctl->event_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t tot = totals[p];
+        const double hrow = rowH[p];
+        if (ev < p) break;       // an earlier event already ends this window: later rows are void
+        if (tot == 0) continue;  // "No valid k-mers": skipped (src/records.rs:332-335)
+        const double rinv = 1.0 / (double(tot) * st.dsize);
+        const double mean_entropy = (st.he_base + hrow) / st.dsize;
+        nread++;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, xmin = 0.0;
+        for (uint64_t i0 = 0; i0 < B; i0 += 256 * SCAN_CH) {
+            // SCAN_CH chunks (1 KiB per wave instruction each) requested before any is consumed
+            Raw4<T> raw[SCAN_CH];
+#pragma unroll
+            for (int j = 0; j < SCAN_CH; j++) raw[j].load(rp + i0 + uint64_t(j) * 256 + lane * 4);
+#pragma unroll
+            for (int j = 0; j < SCAN_CH; j++) {
+                const uint64_t i = i0 + uint64_t(j) * 256 + lane * 4;
+                const double2 b01 = *reinterpret_cast<const double2 *>(bvec + i);
+                const double2 b23 = *reinterpret_cast<const double2 *>(bvec + i + 2);
+                double v0, v1, v2, v3;
+                raw[j].get(v0, v1, v2, v3);
+                fast4(b01, b23, v0, v1, v2, v3, rinv, a0, a1, a2, a3, xmin);
+            }
+        }
+        const double hf = dvs_wave_sum((a0 + a1) + (a2 + a3));
+        const double mn = dvs_wave_min(xmin);
+        // a negative bin is NaN in the reference (rejected); else compare with margin
+        const double jf = hf - mean_entropy;
+        if (!(mn < 0.0) && jf > st.thr_fast) {
+            bool hit = jf > st.thr_sure;  // above the threshold by more than the fast tier's error
+            if (!hit) {                   // only the +-FAST_BAND zone pays for the f64 tier
+                nprecise++;
+                hit = precise_row(rp, bvec, B, rinv, mean_entropy, st.thr_lo, lane);
+            }
+            if (hit && lane == 0) atomicMin(&ctl->event_pos, (unsigned long long)p);
+        }
+    }
+}
+
+// General row loop (explicit order / labels, any B): correctness first.
+template <typename T>
+__device__ __forceinline__ void scan_rows_general(SelCtl *ctl, const T *__restrict__ mat,
+                                               const uint32_t *__restrict__ totals,
+                                               const double *__restrict__ rowH,
+                                               const uint32_t *__restrict__ order,
+                                               const uint32_t *__restrict__ labels,
+                                               const uint8_t *__restrict__ inset, uint32_t nlabels,
+                                               const double *bvec, uint64_t B, const ScanState &st,
+                                               uint64_t first, uint64_t stride, uint32_t lane,
+                                               uint32_t &nread, uint32_t &nprecise) {
+    for (uint64_t r = first; r < st.nrows; r += stride) {
+        const uint64_t p = st.cursor + r;
+        if (__hip_atomic_load(&ctl->event_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p) break;
+        const uint32_t row = order ? order[p] : uint32_t(p);
+        const uint32_t tot = totals[row];
+        if (tot == 0) continue;
+        if (labels) {  // ids can only repeat when the caller passed labels (records.rs:87-89)
+            const uint32_t lab = labels[p];
+            if (lab < nlabels && inset[lab]) continue;
+        }
+        const T *rp = mat + uint64_t(row) * B;
+        const double rinv = 1.0 / (double(tot) * st.dsize);
+        const double mean_entropy = (st.he_base + rowH[row]) / st.dsize;
+        nread++;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, xmin = 0.0;
+        if ((B & 255) == 0) {
+            for (uint64_t i0 = 0; i0 < B; i0 += 256) {
+                const uint64_t i = i0 + lane * 4;
+                double v0, v1, v2, v3;
+                load4(rp, i, v0, v1, v2, v3);
+                const double2 b01 = *reinterpret_cast<const double2 *>(bvec + i);
+                const double2 b23 = *reinterpret_cast<const double2 *>(bvec + i + 2);
+                fast4(b01, b23, v0, v1, v2, v3, rinv, a0, a1, a2, a3, xmin);
+            }
+        } else {
+            for (uint64_t i = lane; i < B; i += 64) {
+                const double x = fma(row_value(rp, i), rinv, bvec[i]);
+                a0 += fast_neg_xlog2x(x);
+                xmin = fmin(xmin, x);
+            }
+        }
+        const double hf = dvs_wave_sum((a0 + a1) + (a2 + a3));
+        const double mn = dvs_wave_min(xmin);
+        if (mn < 0.0) continue;
+        const double jf = hf - mean_entropy;
+        if (!(jf > st.thr_fast)) continue;
+        bool hit = jf > st.thr_sure;
+        if (!hit) {
+            nprecise++;
+            hit = precise_row(rp, bvec, B, rinv, mean_entropy, st.thr_lo, lane);
+        }
+        if (hit && lane == 0) atomicMin(&ctl->event_pos, (unsigned long long)p);
+    }
+}
+
+// HOT: identity order, unique ids, B a multiple of 256 * SCAN_CH (host-checked)
+template <typename T, bool HOT>
+__global__ __launch_bounds__(SCAN_THREADS, 4) void scan_kernel(
     SelCtl *__restrict__ ctl, const T *__restrict__ mat, const uint32_t *__restrict__ totals,
     const double *__restrict__ rowH, const uint32_t *__restrict__ order,
     const uint32_t *__restrict__ labels, const uint8_t *__restrict__ inset, uint32_t nlabels,
     const double *__restrict__ base, uint32_t *__restrict__ wg_rows, uint64_t B, int base_in_lds) {
+    // all LDS in the dynamic region (a static __shared__ in front of it would shift its
+    // base off 16 B and every ds_read_b128 of the state vector would be replayed)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t s_rows;
-    double *sb = reinterpret_cast<double *>(smem);
+    uint32_t *s_rows = reinterpret_cast<uint32_t *>(smem);  // 16 B header
+    double *sb = reinterpret_cast<double *>(smem + 16);
     if (ctl->status != SEL_RUN) return;
-    const uint64_t cursor = ctl->cursor;
-    const uint64_t end = umin64(cursor + uint64_t(ctl->window), ctl->npos);
-    if (cursor >= end) return;
-    const uint64_t nrows = end - cursor;
+    ScanState st;
+    st.cursor = ctl->cursor;
+    const uint64_t end = umin64(st.cursor + uint64_t(ctl->window), ctl->npos);
+    if (st.cursor >= end) return;
+    st.nrows = end - st.cursor;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint64_t wpb = SCAN_THREADS / 64;
-    if (uint64_t(blockIdx.x) * wpb >= nrows) return;  // whole workgroup idle
+    if (uint64_t(blockIdx.x) * wpb >= st.nrows) return;  // whole workgroup idle
+    st.thr_lo = ctl->thr - ctl->band;
+    st.thr_fast = st.thr_lo - FAST_BAND;
+    st.thr_sure = ctl->thr + ctl->band + FAST_BAND;
+    st.he_base = ctl->he_base;
+    st.dsize = double(ctl->size);
     const double *bvec = base;
-    if (threadIdx.x == 0) s_rows = 0;
+    if (threadIdx.x < 2) s_rows[threadIdx.x] = 0;
     if (base_in_lds) {
         if ((B & 1) == 0) {
             const double2 *s2 = reinterpret_cast<const double2 *>(base);
@@ -96,57 +311,41 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(
         bvec = sb;
     }
     __syncthreads();
-    const double thr_lo = ctl->thr - ctl->band;
-    const double he_base = ctl->he_base;
-    const double dsize = double(ctl->size);
-    const uint64_t nwaves = uint64_t(gridDim.x) * wpb;
-    uint32_t nread = 0;
-    for (uint64_t r = uint64_t(blockIdx.x) * wpb + wave; r < nrows; r += nwaves) {
-        const uint64_t p = cursor + r;
-        // an earlier event already ends this window: later rows are void
-        if (__hip_atomic_load(&ctl->event_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p) break;
-        const uint32_t row = order ? order[p] : uint32_t(p);
-        const uint32_t tot = totals[row];
-        if (tot == 0) continue;  // "No valid k-mers": skipped (src/records.rs:332-335)
-        const uint32_t lab = labels ? labels[p] : row;
-        if (lab < nlabels && inset[lab]) continue;  // id already in the set (:87-89)
-        const T *rp = mat + uint64_t(row) * B;
-        const double rinv = 1.0 / (double(tot) * dsize);
-        nread++;
-        Ent e;
-        if ((B & 255) == 0) {
-            for (uint64_t i0 = 0; i0 < B; i0 += 256) {
-                const uint64_t i = i0 + lane * 4;
-                double v0, v1, v2, v3;
-                if constexpr (sizeof(T) == 4) {
-                    const uint4 c = *reinterpret_cast<const uint4 *>(rp + i);
-                    v0 = double(c.x); v1 = double(c.y); v2 = double(c.z); v3 = double(c.w);
-                } else {
-                    const double2 a = *reinterpret_cast<const double2 *>(rp + i);
-                    const double2 b = *reinterpret_cast<const double2 *>(rp + i + 2);
-                    v0 = a.x; v1 = a.y; v2 = b.x; v3 = b.y;
-                }
-                const double2 b01 = *reinterpret_cast<const double2 *>(bvec + i);
-                const double2 b23 = *reinterpret_cast<const double2 *>(bvec + i + 2);
-                e.add(fma(v0, rinv, b01.x));
-                e.add(fma(v1, rinv, b01.y));
-                e.add(fma(v2, rinv, b23.x));
-                e.add(fma(v3, rinv, b23.y));
-            }
-        } else {
-            for (uint64_t i = lane; i < B; i += 64) e.add(fma(row_value(rp, i), rinv, bvec[i]));
-        }
-        const double h = dvs_wave_sum(e.h);
-        const double mn = dvs_wave_min(e.mn);
-        if (lane == 0) {
-            const double mean_entropy = (he_base + rowH[row]) / dsize;
-            const double jsd = (mn < 0.0) ? NAN : h - mean_entropy;
-            if (jsd > thr_lo) atomicMin(&ctl->event_pos, (unsigned long long)p);
-        }
+    const uint64_t first = uint64_t(blockIdx.x) * wpb + wave;
+    const uint64_t stride = uint64_t(gridDim.x) * wpb;
+    uint32_t nread = 0, nprecise = 0;
+    if (HOT)
+        scan_rows_hot<T>(ctl, mat, totals, rowH, bvec, B, st, first, stride, lane, nread, nprecise);
+    else
+        scan_rows_general<T>(ctl, mat, totals, rowH, order, labels, inset, nlabels, bvec, B, st, first,
+                             stride, lane, nread, nprecise);
+    if (lane == 0 && nread) {
+        atomicAdd(&s_rows[0], nread);
+        if (nprecise) atomicAdd(&s_rows[1], nprecise);
     }
-    if (lane == 0 && nread) atomicAdd(&s_rows, nread);
     __syncthreads();
-    if (threadIdx.x == 0 && s_rows) wg_rows[blockIdx.x] = s_rows;  // summed + cleared by resolve
+    if (threadIdx.x == 0 && s_rows[0]) {  // summed + cleared by resolve
+        wg_rows[2 * blockIdx.x] = s_rows[0];
+        wg_rows[2 * blockIdx.x + 1] = s_rows[1];
+    }
+}
+
+// max |double(v_log_f32(m)) - log2(m)| over every f32 m in [0.5, 1): the hardware
+// term of FAST_BAND.  One thread per 2^11 consecutive mantissas.
+__global__ void fast_log2_selftest_kernel(double *out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;  // 4096 threads x 2048 = 2^23
+    double worst = 0.0;
+    for (uint32_t j = 0; j < 2048; j++) {
+        const uint32_t bits = 0x3F000000u + t * 2048u + j;  // [0.5, 1)
+        const float m = __uint_as_float(bits);
+        const double err = fabs(double(__builtin_amdgcn_logf(m)) - log2(double(m)));
+        worst = fmax(worst, err);
+    }
+    for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o, 64));
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long *p = reinterpret_cast<unsigned long long *>(out);
+        atomicMax(p, (unsigned long long)__double_as_longlong(worst));  // positive doubles order as ints
+    }
 }
 
 // ------------------------------------------------------------- state kernels
@@ -214,13 +413,19 @@ __global__ __launch_bounds__(WIDE_THREADS) void resolve_kernel(SelDev d, const T
     const uint64_t p = ctl->event_pos;
     if (ctl->ev_kind != 0) return;  // a finalize is pending (arbiter re-entry)
     {   // rows the scan launch actually read (an arbiter re-entry finds zeros)
-        double cnt = 0.0;
+        double cnt = 0.0, cnt2 = 0.0;
         for (uint32_t i = tid; i < scan_grid; i += WIDE_THREADS) {
-            cnt += double(d.wg_rows[i]);
-            d.wg_rows[i] = 0;
+            cnt += double(d.wg_rows[2 * i]);
+            cnt2 += double(d.wg_rows[2 * i + 1]);
+            d.wg_rows[2 * i] = 0;
+            d.wg_rows[2 * i + 1] = 0;
         }
         cnt = dvs_block_sum(cnt, scratch);
-        if (tid == 0) ctl->rows_scored += (unsigned long long)cnt;
+        cnt2 = dvs_block_sum(cnt2, scratch);
+        if (tid == 0) {
+            ctl->rows_scored += (unsigned long long)cnt;
+            ctl->rows_rechecked += (unsigned long long)cnt2;
+        }
     }
     if (p == SEL_NONE) {
         if (tid == 0) {
@@ -601,7 +806,7 @@ static void sel_free(dvs_select *s) {
                     s->dev.ord, s->dev.inset, s->dev.wg_rows, s->dev.evlog_pos, s->dev.evlog_kind,
                     (void *)s->dev.order, (void *)s->dev.labels};
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        dvs_dev_free(s->ctx, p);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
     dvs_select_arbiter_free(s);
@@ -627,9 +832,14 @@ static void launch_iteration(dvs_ctx *ctx, dvs_select *s, const T *mat, int stag
             s->ev_used += 2;
             (void)hipEventRecord(e0, ctx->stream);
         }
-        hipLaunchKernelGGL((scan_kernel<T>), dim3(s->scan_grid), dim3(SCAN_THREADS), s->scan_lds,
-                           ctx->stream, d.ctl, mat, d.totals, d.rowH, d.order, d.labels, d.inset,
-                           d.nlabels, d.base, d.wg_rows, d.B, s->base_in_lds ? 1 : 0);
+        if (s->scan_hot)
+            hipLaunchKernelGGL((scan_kernel<T, true>), dim3(s->scan_grid), dim3(SCAN_THREADS),
+                               s->scan_lds, ctx->stream, d.ctl, mat, d.totals, d.rowH, d.order, d.labels,
+                               d.inset, d.nlabels, d.base, d.wg_rows, d.B, s->base_in_lds ? 1 : 0);
+        else
+            hipLaunchKernelGGL((scan_kernel<T, false>), dim3(s->scan_grid), dim3(SCAN_THREADS),
+                               s->scan_lds, ctx->stream, d.ctl, mat, d.totals, d.rowH, d.order, d.labels,
+                               d.inset, d.nlabels, d.base, d.wg_rows, d.B, s->base_in_lds ? 1 : 0);
         if (s->time_scan) (void)hipEventRecord(e1, ctx->stream);
     }
     if (stage <= 1)
@@ -685,7 +895,8 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat) {
 template <typename T>
 static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat, const std::vector<uint64_t> &seeds) {
     uint64_t *d_seed = nullptr;
-    DVS_HIP(ctx, hipMalloc(&d_seed, seeds.size() * sizeof(uint64_t)));
+    int rc0 = dvs_dev_alloc(ctx, (void **)&d_seed, seeds.size() * sizeof(uint64_t), "seed list");
+    if (rc0) return rc0;
     DVS_HIP(ctx, hipMemcpyAsync(d_seed, seeds.data(), seeds.size() * sizeof(uint64_t),
                                 hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL((seed_kernel<T>), dim3(uint32_t(seeds.size())), dim3(LOO_THREADS), 0,
@@ -694,7 +905,7 @@ static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat, const std::vecto
     launch_iteration<T>(ctx, s, mat, 2);  // loo + finalize of the initial set
     DVS_HIP(ctx, hipGetLastError());
     DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(d_seed);
+    dvs_dev_free(ctx, d_seed);
     return sel_run_loop<T>(ctx, s, mat);
 }
 
@@ -741,6 +952,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     if (seeds.size() < 2) return dvs_set_error(ctx, DVS_ERR_VALUE, "must have > 1 KmerSeq");  // :227-230
 
     dvs_select *s = new dvs_select();
+    s->ctx = ctx;
     s->params = *params;
     s->params.n_seed = n_seed;
     s->params.max_size = max_size;
@@ -759,32 +971,39 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     const size_t need = size_t(cap) * B * 8 + 5 * B * 8 + size_t(npos) * 8 + nlabels + (1 << 20);
     size_t free_b = 0, total_b = 0;
     DVS_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
-    if (need > free_b) {
+    if (need > free_b + ctx->pool_bytes) {
         delete s;
         return dvs_set_error(ctx, DVS_ERR_NOMEM, "selection state needs %zu bytes, %zu free", need,
                              free_b);
     }
     // launch geometry
     s->base_in_lds = B * 8 <= 128 * 1024 && B * 8 + 1024 <= ctx->lds_per_block;
-    s->scan_lds = s->base_in_lds ? B * 8 : 0;
-    const uint32_t wg_per_cu = s->base_in_lds ? std::max<uint32_t>(1, uint32_t((160 * 1024) / (B * 8 + 512))) : 8;
-    s->scan_grid = std::max<uint32_t>(1, uint32_t(ctx->n_cu) * std::min<uint32_t>(wg_per_cu, 5));
+    s->scan_lds = 16 + (s->base_in_lds ? B * 8 : 0);
+    const uint32_t wg_fit = s->base_in_lds ? std::max<uint32_t>(1, uint32_t((160 * 1024) / (B * 8 + 512))) : 4;
+    uint32_t wg_per_cu = std::min<uint32_t>(wg_fit, 2);  // 16 waves per CU, 16 KB of loads in flight each
+    if (const char *e = getenv("DVS_SCAN_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
+    s->scan_grid = std::max<uint32_t>(1, uint32_t(ctx->n_cu) * wg_per_cu);
     s->loo_grid = cap;
     s->batch = 16;
     s->time_scan = ctx->timing;
+    s->scan_hot = B % (256 * SCAN_CH) == 0 && !order && !labels && s->base_in_lds;
     if (s->scan_lds > 48 * 1024) {
-        const void *fn = m->kind == 0 ? reinterpret_cast<const void *>(scan_kernel<uint32_t>)
-                                      : reinterpret_cast<const void *>(scan_kernel<double>);
+        const void *fn =
+            m->kind == 0
+                ? (s->scan_hot ? reinterpret_cast<const void *>(scan_kernel<uint32_t, true>)
+                               : reinterpret_cast<const void *>(scan_kernel<uint32_t, false>))
+                : (s->scan_hot ? reinterpret_cast<const void *>(scan_kernel<double, true>)
+                               : reinterpret_cast<const void *>(scan_kernel<double, false>));
         DVS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          int(s->scan_lds)));
     }
 
 #define SEL_ALLOC(ptr, bytes)                                        \
     do {                                                             \
-        hipError_t e__ = hipMalloc((void **)&(ptr), (bytes));        \
-        if (e__ != hipSuccess) {                                     \
+        int rc__ = dvs_dev_alloc(ctx, (void **)&(ptr), (bytes), #ptr); \
+        if (rc__) {                                                  \
             sel_free(s);                                             \
-            return dvs_hip_fail(ctx, e__, "hipMalloc(" #ptr ")");    \
+            return rc__;                                             \
         }                                                            \
     } while (0)
     SEL_ALLOC(d.ctl, sizeof(SelCtl));
@@ -801,7 +1020,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     SEL_ALLOC(d.mPos, size_t(cap) * 8);
     SEL_ALLOC(d.ord, size_t(cap) * 4);
     SEL_ALLOC(d.inset, std::max<size_t>(nlabels, 1));
-    SEL_ALLOC(d.wg_rows, size_t(s->scan_grid) * 4);
+    SEL_ALLOC(d.wg_rows, size_t(s->scan_grid) * 8);
     SEL_ALLOC(d.evlog_pos, size_t(npos - n_seed + 2) * 8);
     SEL_ALLOC(d.evlog_kind, size_t(npos - n_seed + 2) * 4);
     if (order) {
@@ -816,7 +1035,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     }
 #undef SEL_ALLOC
     DVS_HIP(ctx, hipMemsetAsync(d.inset, 0, std::max<size_t>(nlabels, 1), ctx->stream));
-    DVS_HIP(ctx, hipMemsetAsync(d.wg_rows, 0, size_t(s->scan_grid) * 4, ctx->stream));
+    DVS_HIP(ctx, hipMemsetAsync(d.wg_rows, 0, size_t(s->scan_grid) * 8, ctx->stream));
     hipError_t he = hipHostMalloc((void **)&s->h_ctl, sizeof(SelCtl), hipHostMallocDefault);
     if (he != hipSuccess) {
         sel_free(s);
@@ -931,5 +1150,19 @@ extern "C" int dvs_select_delta_jsd(dvs_ctx *ctx, const dvs_select *s, const dvs
     DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     (void)hipFree(d_out);
     if (d_lab) (void)hipFree(d_lab);
+    return DVS_OK;
+}
+
+extern "C" int dvs_selftest_fast_log2(dvs_ctx *ctx, double *max_abs_err) {
+    if (!ctx || !max_abs_err) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    double *d = nullptr;
+    DVS_HIP(ctx, hipMalloc(&d, 8));
+    DVS_HIP(ctx, hipMemsetAsync(d, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(fast_log2_selftest_kernel, dim3(16), dim3(256), 0, ctx->stream, d);
+    DVS_HIP(ctx, hipGetLastError());
+    DVS_HIP(ctx, hipMemcpyAsync(max_abs_err, d, 8, hipMemcpyDeviceToHost, ctx->stream));
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d);
     return DVS_OK;
 }

@@ -50,6 +50,8 @@ void dvs_ctx_destroy(dvs_ctx *ctx);
 /* message of the last failing call on ctx (ctx == NULL: last ctx_create failure) */
 const char *dvs_last_error(const dvs_ctx *ctx);
 int dvs_ctx_sync(dvs_ctx *ctx);
+/* the ctx caches device allocations released by *_destroy for reuse; this frees them */
+int dvs_ctx_trim(dvs_ctx *ctx);
 /* name, CU count and HBM bytes of the ctx's device */
 int dvs_ctx_device_info(dvs_ctx *ctx, char *name, size_t name_len, int *n_cu,
                         uint64_t *hbm_bytes);
@@ -152,6 +154,9 @@ int dvs_select_delta_jsd(dvs_ctx *ctx, const dvs_select *s, const dvs_matrix *qu
  * ctx stream (no extra host sync); they are read once the selection has finished
  * and summed into dvs_select_summary.scan_ms / scan_launches */
 int dvs_ctx_set_timing(dvs_ctx *ctx, int on);
+/* diagnostic: max |v_log_f32(m) - log2(m)| over every f32 m in [0.5, 1), the
+ * hardware term of the scan kernel's fast-tier error bound (select.hip FAST_BAND) */
+int dvs_selftest_fast_log2(dvs_ctx *ctx, double *max_abs_err);
 
 /* ---- mash ----------------------------------------------------------------- *
  * dvs_mash_sketch replaces _dvs.mash_sketch (src/distance.rs:136-182) for a

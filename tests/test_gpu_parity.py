@@ -507,3 +507,15 @@ def test_degenerate_inputs_take_the_arbiter(ctx):
     with pytest.raises(NotImplementedError, match="ambiguous decision"):
         from diverseseq_amd import _lib
         ctx.build_matrix(same, 2, 4).nmost(5, flags=_lib.SELECT_NO_ARBITER)
+
+
+def test_fast_log2_error_bound(ctx):
+    """the hardware term of the scan's fast tier: |v_log_f32(m) - log2 m| over EVERY f32
+    mantissa in [0.5, 1) must stay below what FAST_BAND (select.hip, 4e-7) budgets:
+    mantissa rounding to f32 (8.6e-8) + this + margin"""
+    import ctypes as C
+
+    err = C.c_double()
+    ctx.check(ctx._L.dvs_selftest_fast_log2(ctx._h, C.byref(err)))
+    assert 0.0 < err.value < 1.5e-7, err.value
+    print("max |v_log_f32 - log2| on [0.5,1):", err.value)
