@@ -78,6 +78,7 @@ struct dvs_select {
     size_t scan_lds = 0;
     bool base_in_lds = true;
     bool scan_hot = false;
+    bool fused = false;  // resolve + leave-one-out + finalize in one launch (small sets)
     int batch = 16;
     // timing
     bool time_scan = false;

@@ -354,6 +354,32 @@ __device__ __forceinline__ double cand_freq(const uint32_t *row, uint64_t i, dou
 }
 __device__ __forceinline__ double cand_freq(const double *row, uint64_t i, double) { return row[i]; }
 
+// (sum, min, sum) over the block in ONE barrier pair; every thread gets the result.
+// scratch: >= 3 * 16 doubles.  Fixed tree -> same inputs, same bits.
+__device__ __forceinline__ void block_red3(double &h, double &mn, double &sm, double *scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwave = (blockDim.x + 63) >> 6;
+    h = dvs_wave_sum(h);
+    mn = dvs_wave_min(mn);
+    sm = dvs_wave_sum(sm);
+    __syncthreads();  // scratch may still be read from a previous call
+    if (lane == 0) {
+        scratch[wave] = h;
+        scratch[16 + wave] = mn;
+        scratch[32 + wave] = sm;
+    }
+    __syncthreads();
+    double a = 0.0, b = scratch[16], c = 0.0;
+    for (int i = 0; i < nwave; i++) {
+        a += scratch[i];
+        b = fmin(b, scratch[16 + i]);
+        c += scratch[32 + i];
+    }
+    h = a;
+    mn = b;
+    sm = c;
+}
+
 // JSD of the set with `lowest` swapped for the candidate in d.cand
 // (src/records.rs:70-84), all threads of the block get the result.
 __device__ double block_delta_jsd(const SelDev &d, const SelCtl *ctl, double cand_H,
@@ -364,9 +390,8 @@ __device__ double block_delta_jsd(const SelDev &d, const SelCtl *ctl, double can
     Ent e;
     for (uint64_t i = threadIdx.x; i < d.B; i += blockDim.x)
         e.add((d.S[i] - low[i] + d.cand[i]) / dsize);
-    const double h = dvs_block_sum(e.h, scratch);
-    const double mn = dvs_block_min(e.mn, scratch);
-    const double sm = dvs_block_sum(e.sum, scratch);
+    double h = e.h, mn = e.mn, sm = e.sum;
+    block_red3(h, mn, sm, scratch);
     if (sum_out) *sum_out = sm;
     const double mean_entropy = (ctl->sum_entropy - d.mH[low_slot] + cand_H) / dsize;
     return (mn < 0.0) ? NAN : h - mean_entropy;
@@ -377,9 +402,8 @@ __device__ double block_entropy_div(const double *vec, double div, uint64_t B, d
                                     double *sum_out) {
     Ent e;
     for (uint64_t i = threadIdx.x; i < B; i += blockDim.x) e.add(vec[i] / div);
-    const double h = dvs_block_sum(e.h, scratch);
-    const double mn = dvs_block_min(e.mn, scratch);
-    const double sm = dvs_block_sum(e.sum, scratch);
+    double h = e.h, mn = e.mn, sm = e.sum;
+    block_red3(h, mn, sm, scratch);
     if (sum_out) *sum_out = sm;
     return (mn < 0.0) ? NAN : h;
 }
@@ -403,25 +427,23 @@ __device__ __forceinline__ bool sum_risky(double sum, uint64_t B) {
 // score with the reference's per-bin operation order, decide, and apply
 // replace_lowest (or stage a tentative push for MODE_MAX).  One 1024-thread block.
 template <typename T>
-__global__ __launch_bounds__(WIDE_THREADS) void resolve_kernel(SelDev d, const T *__restrict__ mat,
-                                                            uint32_t scan_grid) {
-    __shared__ double scratch[32];
-    __shared__ int s_action;  // 0 reject, 1 replace, 2 tentative push, 3 stop
+__device__ void resolve_body(SelDev &d, const T *__restrict__ mat, uint32_t scan_grid,
+                             double *scratch, int &s_action) {
     SelCtl *ctl = d.ctl;
     if (ctl->status != SEL_RUN) return;
     const int tid = threadIdx.x;
+    const uint32_t WIDE = blockDim.x;
     const uint64_t p = ctl->event_pos;
     if (ctl->ev_kind != 0) return;  // a finalize is pending (arbiter re-entry)
     {   // rows the scan launch actually read (an arbiter re-entry finds zeros)
-        double cnt = 0.0, cnt2 = 0.0;
-        for (uint32_t i = tid; i < scan_grid; i += WIDE_THREADS) {
+        double cnt = 0.0, cnt2 = 0.0, mnz = 0.0;
+        for (uint32_t i = tid; i < scan_grid; i += WIDE) {
             cnt += double(d.wg_rows[2 * i]);
             cnt2 += double(d.wg_rows[2 * i + 1]);
             d.wg_rows[2 * i] = 0;
             d.wg_rows[2 * i + 1] = 0;
         }
-        cnt = dvs_block_sum(cnt, scratch);
-        cnt2 = dvs_block_sum(cnt2, scratch);
+        block_red3(cnt, mnz, cnt2, scratch);
         if (tid == 0) {
             ctl->rows_scored += (unsigned long long)cnt;
             ctl->rows_rechecked += (unsigned long long)cnt2;
@@ -442,7 +464,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void resolve_kernel(SelDev d, const T
     const double tot = double(d.totals[row]);
     const double cand_H = d.rowH[row];
     const T *rp = mat + uint64_t(row) * d.B;
-    for (uint64_t i = tid; i < d.B; i += WIDE_THREADS) d.cand[i] = cand_freq(rp, i, tot);
+    for (uint64_t i = tid; i < d.B; i += WIDE) d.cand[i] = cand_freq(rp, i, tot);
     __syncthreads();
     double sm;
     const double jsd = block_delta_jsd(d, ctl, cand_H, scratch, &sm);
@@ -480,7 +502,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void resolve_kernel(SelDev d, const T
         const uint32_t li = ctl->lowest, n = ctl->size;
         const uint32_t s = d.ord[li];
         double *mrow = d.M + uint64_t(s) * d.B;
-        for (uint64_t i = tid; i < d.B; i += WIDE_THREADS) {
+        for (uint64_t i = tid; i < d.B; i += WIDE) {
             double v = d.S[i] - mrow[i];
             if (v <= DVS_EPS) v = 0.0;
             const double f = d.cand[i];
@@ -519,7 +541,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void resolve_kernel(SelDev d, const T
         // then push the candidate; kept only if the stat rises (finalize decides)
         const uint32_t n = ctl->size;
         double *mrow = d.M + uint64_t(n) * d.B;  // slot n is free
-        for (uint64_t i = tid; i < d.B; i += WIDE_THREADS) {
+        for (uint64_t i = tid; i < d.B; i += WIDE) {
             double acc = 0.0;
             for (uint32_t r = 0; r < n; r++) acc += d.M[uint64_t(d.ord[r]) * d.B + i];
             const double f = d.cand[i];
@@ -551,7 +573,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void resolve_kernel(SelDev d, const T
 // total_jsd (SummedRecords::new, records.rs:36-47).  Members were written by
 // seed_kernel.  One block.
 __global__ __launch_bounds__(WIDE_THREADS) void rebuild_kernel(SelDev d) {
-    __shared__ double scratch[32];
+    __shared__ double scratch[48];
     SelCtl *ctl = d.ctl;
     const uint32_t n = ctl->size;
     for (uint64_t i = threadIdx.x; i < d.B; i += WIDE_THREADS) {
@@ -599,13 +621,11 @@ __global__ __launch_bounds__(LOO_THREADS) void seed_kernel(SelDev d, const T *__
 
 // Leave-one-out pass (get_lowest_record_index, records.rs:220-252): block r
 // computes delta_jsd of the r-th member of the (possibly tentative) set.
-__global__ __launch_bounds__(LOO_THREADS) void loo_kernel(SelDev d) {
-    __shared__ double scratch[32];
+__device__ void loo_body(const SelDev &d, uint32_t r, double *scratch) {
     const SelCtl *ctl = d.ctl;
     const uint32_t kind = ctl->ev_kind;
     if (kind == 0 || ctl->status != SEL_RUN) return;
     const uint32_t n = ctl->ev_n;
-    const uint32_t r = blockIdx.x;
     if (r >= n) return;
     const bool tent = kind == 2;
     const uint32_t slot = (tent && r == n - 1) ? n - 1 : d.ord[r];
@@ -615,13 +635,13 @@ __global__ __launch_bounds__(LOO_THREADS) void loo_kernel(SelDev d) {
     const double div = double(n) - 1.0;
     const double *mrow = d.M + uint64_t(slot) * d.B;
     Ent e;
-    for (uint64_t i = threadIdx.x; i < d.B; i += LOO_THREADS) {
+    for (uint64_t i = threadIdx.x; i < d.B; i += blockDim.x) {
         double v = (Sv[i] - mrow[i]) / div;  // updated_mean_freqs, records.rs:276-286
         if (v <= DVS_EPS) v = 0.0;
         e.add(v);
     }
-    const double h = dvs_block_sum(e.h, scratch);
-    const double sm = dvs_block_sum(e.sum, scratch);
+    double h = e.h, mnz = 0.0, sm = e.sum;
+    block_red3(h, mnz, sm, scratch);
     if (threadIdx.x == 0) {
         const double mean_entropy = (sumH - d.mH[slot]) / div;
         const double jsd = h - mean_entropy;
@@ -631,13 +651,12 @@ __global__ __launch_bounds__(LOO_THREADS) void loo_kernel(SelDev d) {
 }
 
 // argmin / stats / commit-or-rollback / next scan state.  One block.
-__global__ __launch_bounds__(WIDE_THREADS) void finalize_kernel(SelDev d) {
-    __shared__ double scratch[32];
-    __shared__ int s_go;
+__device__ void finalize_body(SelDev &d, double *scratch, int &s_go) {
     SelCtl *ctl = d.ctl;
     const uint32_t kind = ctl->ev_kind;
     if (kind == 0 || ctl->status != SEL_RUN) return;
     const int tid = threadIdx.x;
+    const uint32_t WIDE = blockDim.x;
     const uint32_t n = ctl->ev_n;
 
     // argmin with strict '<' from 1e6, earliest index on ties (records.rs:231,246-249);
@@ -645,19 +664,19 @@ __global__ __launch_bounds__(WIDE_THREADS) void finalize_kernel(SelDev d) {
     // index, and the runner-up (for the ambiguity check).
     bool risky = false;
     double best = 1e6;
-    for (uint32_t r = tid; r < n; r += WIDE_THREADS) {
+    for (uint32_t r = tid; r < n; r += WIDE) {
         const double v = d.dtmp[r];
         if (sum_risky(d.dsum[r], d.B)) risky = true;
         if (v < best) best = v;
     }
     const double dmin = dvs_block_min(best, scratch);
     double fi = 4294967295.0;
-    for (uint32_t r = tid; r < n; r += WIDE_THREADS)
+    for (uint32_t r = tid; r < n; r += WIDE)
         if (dmin < 1e6 && d.dtmp[r] == dmin) fi = fmin(fi, double(r));
     const double dfirst = dvs_block_min(fi, scratch);
     uint32_t lowest = (dfirst < 4294967295.0) ? uint32_t(dfirst) : 0u;  // nothing below 1e6 -> 0
     double second = 1e6;
-    for (uint32_t r = tid; r < n; r += WIDE_THREADS) {
+    for (uint32_t r = tid; r < n; r += WIDE) {
         const double v = d.dtmp[r];
         if (r != lowest && v < second) second = v;
     }
@@ -666,10 +685,10 @@ __global__ __launch_bounds__(WIDE_THREADS) void finalize_kernel(SelDev d) {
 
     // mean / std / cov of delta_jsd (records.rs:156-172)
     double acc = 0.0;
-    for (uint32_t r = tid; r < n; r += WIDE_THREADS) acc += d.dtmp[r];
+    for (uint32_t r = tid; r < n; r += WIDE) acc += d.dtmp[r];
     const double mean = dvs_block_sum(acc, scratch) / double(n);
     acc = 0.0;
-    for (uint32_t r = tid; r < n; r += WIDE_THREADS) {
+    for (uint32_t r = tid; r < n; r += WIDE) {
         const double t = d.dtmp[r] - mean;
         acc += t * t;
     }
@@ -735,9 +754,9 @@ __global__ __launch_bounds__(WIDE_THREADS) void finalize_kernel(SelDev d) {
     const int go = s_go;
     if (go < 0) return;
     if (go == 1) {
-        for (uint32_t r = tid; r < n; r += WIDE_THREADS) d.mDelta[r] = d.dtmp[r];
+        for (uint32_t r = tid; r < n; r += WIDE) d.mDelta[r] = d.dtmp[r];
         if (kind == 2)
-            for (uint64_t i = tid; i < d.B; i += WIDE_THREADS) d.S[i] = d.Stmp[i];
+            for (uint64_t i = tid; i < d.B; i += WIDE) d.S[i] = d.Stmp[i];
     }
     __syncthreads();
     // state for the next scan: b_i = (S_i - low_i) / size, thresholds
@@ -745,7 +764,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void finalize_kernel(SelDev d) {
     const uint32_t low_slot = d.ord[ctl->lowest];
     const double *low = d.M + uint64_t(low_slot) * d.B;
     const double dsize = double(sz);
-    for (uint64_t i = tid; i < d.B; i += WIDE_THREADS) d.base[i] = (d.S[i] - low[i]) / dsize;
+    for (uint64_t i = tid; i < d.B; i += WIDE) d.base[i] = (d.S[i] - low[i]) / dsize;
     if (tid == 0) {
         ctl->he_base = ctl->sum_entropy - d.mH[low_slot];
         ctl->thr = ctl->total_jsd + DVS_EPS;
@@ -755,6 +774,97 @@ __global__ __launch_bounds__(WIDE_THREADS) void finalize_kernel(SelDev d) {
         if (ctl->cursor >= ctl->npos) ctl->status = SEL_DONE;
         ctl_next_window(ctl);
     }
+}
+
+
+// All members' leave-one-out scores in ONE pass of one block (small sets): every thread
+// keeps a (h, sum) pair per member for its bins and the 2 * n values are reduced
+// together -- one barrier pair instead of n.  Same per-bin arithmetic as loo_body.
+constexpr uint32_t FUSE_MAX = 16;
+__device__ void loo_small(const SelDev &d, double *scratch, uint32_t *s_slot) {
+    const SelCtl *ctl = d.ctl;
+    const uint32_t kind = ctl->ev_kind;
+    const uint32_t n = ctl->ev_n;
+    const bool tent = kind == 2;
+    const double *Sv = tent ? d.Stmp : d.S;
+    const double sumH = tent ? ctl->t_sum_entropy : ctl->sum_entropy;
+    const double tj = tent ? ctl->t_total_jsd : ctl->total_jsd;
+    const double div = double(n) - 1.0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = (blockDim.x + 63) >> 6;
+    if (threadIdx.x < n) s_slot[threadIdx.x] = (tent && threadIdx.x == n - 1) ? n - 1 : d.ord[threadIdx.x];
+    __syncthreads();
+    double h[FUSE_MAX], sm[FUSE_MAX];
+#pragma unroll
+    for (uint32_t r = 0; r < FUSE_MAX; r++) h[r] = sm[r] = 0.0;
+    for (uint64_t i = threadIdx.x; i < d.B; i += blockDim.x) {
+        const double sv = Sv[i];
+#pragma unroll
+        for (uint32_t r = 0; r < FUSE_MAX; r++) {
+            if (r < n) {
+                double v = (sv - d.M[uint64_t(s_slot[r]) * d.B + i]) / div;
+                if (v <= DVS_EPS) v = 0.0;
+                if (v > 0.0) h[r] -= v * log2(v);
+                sm[r] += v;
+            }
+        }
+    }
+    // scratch layout: [wave][2 * FUSE_MAX]
+#pragma unroll
+    for (uint32_t r = 0; r < FUSE_MAX; r++) {
+        if (r < n) {
+            const double a = dvs_wave_sum(h[r]), b = dvs_wave_sum(sm[r]);
+            if (lane == 0) {
+                scratch[wave * 2 * FUSE_MAX + r] = a;
+                scratch[wave * 2 * FUSE_MAX + FUSE_MAX + r] = b;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < n) {
+        const uint32_t r = threadIdx.x;
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < nwave; w++) {
+            a += scratch[w * 2 * FUSE_MAX + r];
+            b += scratch[w * 2 * FUSE_MAX + FUSE_MAX + r];
+        }
+        const double mean_entropy = (sumH - d.mH[s_slot[r]]) / div;
+        d.dtmp[r] = tj - (a - mean_entropy);
+        d.dsum[r] = b;
+    }
+    __syncthreads();
+}
+
+// Resolve kernel.  FUSED (sets of at most FUSE_MAX members): the leave-one-out pass and
+// the finalize step run in the same launch, so an event costs one kernel after the scan.
+template <typename T, bool FUSED>
+__global__ __launch_bounds__(WIDE_THREADS) void resolve_kernel(SelDev d, const T *__restrict__ mat,
+                                                            uint32_t scan_grid) {
+    __shared__ double scratch[16 * 2 * FUSE_MAX];
+    __shared__ uint32_t s_slot[FUSE_MAX];
+    __shared__ int s_flag;
+    resolve_body<T>(d, mat, scan_grid, scratch, s_flag);
+    if (!FUSED) return;
+    __syncthreads();
+    const SelCtl *ctl = d.ctl;
+    if (ctl->status != SEL_RUN || ctl->ev_kind == 0) return;
+    if (ctl->ev_n <= FUSE_MAX) {
+        loo_small(d, scratch, s_slot);
+    } else {
+        for (uint32_t r = 0; r < ctl->ev_n; r++) loo_body(d, r, scratch);
+        __syncthreads();
+    }
+    finalize_body(d, scratch, s_flag);
+}
+
+__global__ __launch_bounds__(LOO_THREADS) void loo_kernel(SelDev d) {
+    __shared__ double scratch[48];
+    loo_body(d, blockIdx.x, scratch);
+}
+
+__global__ __launch_bounds__(WIDE_THREADS) void finalize_kernel(SelDev d) {
+    __shared__ double scratch[48];
+    __shared__ int s_go;
+    finalize_body(d, scratch, s_go);
 }
 
 // delta_jsd of every query row against the set (SummedRecordsWrapper.delta_jsd,
@@ -842,9 +952,15 @@ static void launch_iteration(dvs_ctx *ctx, dvs_select *s, const T *mat, int stag
                                d.inset, d.nlabels, d.base, d.wg_rows, d.B, s->base_in_lds ? 1 : 0);
         if (s->time_scan) (void)hipEventRecord(e1, ctx->stream);
     }
-    if (stage <= 1)
-        hipLaunchKernelGGL((resolve_kernel<T>), dim3(1), dim3(WIDE_THREADS), 0, ctx->stream, d, mat,
-                           s->scan_grid);
+    if (stage <= 1) {
+        if (s->fused)
+            hipLaunchKernelGGL((resolve_kernel<T, true>), dim3(1), dim3(WIDE_THREADS), 0, ctx->stream, d,
+                               mat, s->scan_grid);
+        else
+            hipLaunchKernelGGL((resolve_kernel<T, false>), dim3(1), dim3(WIDE_THREADS), 0, ctx->stream, d,
+                               mat, s->scan_grid);
+        if (s->fused) return;
+    }
     hipLaunchKernelGGL(loo_kernel, dim3(s->loo_grid), dim3(LOO_THREADS), 0, ctx->stream, d);
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(WIDE_THREADS), 0, ctx->stream, d);
 }
@@ -984,6 +1100,8 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     if (const char *e = getenv("DVS_SCAN_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
     s->scan_grid = std::max<uint32_t>(1, uint32_t(ctx->n_cu) * wg_per_cu);
     s->loo_grid = cap;
+    // measured slower than three launches (one CU does the whole leave-one-out pass): opt-in only
+    s->fused = cap <= FUSE_MAX + 1 && getenv("DVS_FUSE_EVENT");
     s->batch = 16;
     s->time_scan = ctx->timing;
     s->scan_hot = B % (256 * SCAN_CH) == 0 && !order && !labels && s->base_in_lds;
