@@ -29,7 +29,7 @@ EXPORTS = (
     "dvs_matrix_dev_totals", "dvs_matrix_dev_entropy", "dvs_matrix_get_counts",
     "dvs_matrix_get_totals", "dvs_matrix_get_entropy", "dvs_kmer_counts", "dvs_select_run",
     "dvs_select_destroy", "dvs_select_get_summary", "dvs_select_get_members",
-    "dvs_select_delta_jsd", "dvs_selftest_fast_log2", "dvs_mash_sketch", "dvs_mash_distances", "dvs_euclidean_distances",
+    "dvs_select_delta_jsd", "dvs_selftest_fast_log2", "dvs_selftest_log2_acc", "dvs_mash_sketch", "dvs_mash_distances", "dvs_euclidean_distances",
 )
 
 
@@ -134,6 +134,7 @@ def load() -> C.CDLL:
         L.dvs_select_get_members.argtypes = [vp, vp, u64p, u32p, f64p, f64p, f64p]
         L.dvs_select_delta_jsd.argtypes = [vp, vp, vp, u32p, f64p]
         L.dvs_selftest_fast_log2.argtypes = [vp, f64p]
+        L.dvs_selftest_log2_acc.argtypes = [vp, f64p]
         L.dvs_mash_sketch.argtypes = [vp, vp, C.c_int, u64p, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.c_uint32, C.c_int, u32p, u32p]
         L.dvs_mash_distances.argtypes = [vp, u32p, C.c_uint32, u32p, C.c_uint32, C.c_uint32,

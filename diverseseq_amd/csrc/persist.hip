@@ -1,0 +1,607 @@
+// Persistent form of the greedy selection (MODE_NMOST, identity order, unique ids).
+//
+// The multi-launch engine in select.hip pays, for every greedy event, a scan launch
+// plus resolve / leave-one-out / finalize launches and their serial latencies.  Here
+// ONE launch of one workgroup per CU walks the whole candidate stream:
+//
+//   * every workgroup keeps a private replica of the scalar set state (size, lowest,
+//     sumH, total_jsd, threshold, cursor, window, member order) in registers / LDS,
+//     and the vector sl_i = S_i - lowest_i in LDS (32 KB at k=6) -- what a
+//     candidate's frequencies are added to (src/records.rs:78-81);
+//   * SCAN: waves score the rows of the current window exactly as scan_kernel does
+//     (x = (sl + c/T)/n, fast tier + f64 recheck), atomicMin'ing the first event into
+//     an epoch-tagged word;
+//   * grid barrier; then EVERY workgroup resolves the first event redundantly and
+//     deterministically (same code, same reduction tree -> same bits, so no
+//     broadcast is needed): exact delta_jsd of the candidate, decision,
+//     replace_lowest, new total_jsd;
+//   * leave-one-out: workgroup r scores member r (get_lowest_record_index,
+//     src/records.rs:220-252); grid barrier; every workgroup reads the n scores,
+//     takes the argmin, rebuilds sl in its LDS and scans on from the event + 1.
+//   * workgroup 0 additionally mirrors the state into the global SelDev / SelCtl
+//     arrays (what the host reads back, and what the multi-launch kernels resume
+//     from).
+//
+// Two grid barriers per accepted event and none of the launch latencies.  Any decision
+// inside the rounding band stops the kernel with SEL_ARBITER; the host arbitrates and
+// runs that one event through the multi-launch kernels, then relaunches this one.
+//
+// Inter-workgroup protocol (MI355X: 8 XCDs, private L2s): a monotonic arrival counter;
+// barrier k is complete when it reaches G*k and the last arriver publishes gen = k.
+// Every workgroup: all waves drain (s_waitcnt vmcnt(0)), __syncthreads, lane 0 does an
+// agent-scope release, the counter add, polls gen relaxed with s_sleep, then an
+// agent-scope acquire, __syncthreads.  All polled words are agent-scope atomics and
+// are zeroed by the host before every launch; every spin is bounded (a grid that is
+// not fully resident ends with SEL_ERROR instead of hanging).
+#include "select_dev.h"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+
+constexpr int P_THREADS = 512;
+constexpr int P_J = 8;                      // bins per thread kept in registers (B <= 4096)
+constexpr int P_CH = 16;                    // row chunks requested per burst (4096 bins)
+constexpr uint32_t P_MAXN = 512;            // members the LDS replica holds
+constexpr uint32_t P_SPIN_LIMIT = 1u << 22;  // ~0.5 s of polling
+
+struct PSync {
+    uint32_t count;  // arrivals, monotonic over the launch
+    uint32_t gen;    // completed barriers
+    uint32_t timeout;
+    uint32_t pad;
+    unsigned long long ev[4];  // event words, slot = epoch % 3
+    unsigned long long dbg2[8];  // block 0 (owns member 0): the same phases
+    unsigned long long dbg[8];  // lead block: 100 MHz ticks per phase (scan, bar1, resolve, loo, bar2, finalize)
+};
+
+struct PState {  // replicated scalars (identical in every workgroup)
+    uint64_t cursor, npos;
+    uint32_t window, wmin, wmax;
+    uint32_t n, li;
+    double sumH, total_jsd, thr, band;
+    uint32_t n_windows, n_events, n_accepts;
+};
+
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// returns false on timeout (every thread of the block gets the same answer)
+__device__ bool grid_barrier(PSync *sync, uint32_t G, uint32_t &gen, int *s_ok) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t target = gen + 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t old = __hip_atomic_fetch_add(&sync->count, 1u, RLX_AGENT);
+        int ok = 1;
+        if (old == G * target - 1) {
+            __hip_atomic_store(&sync->gen, target, RLX_AGENT);
+        } else {
+            uint32_t spins = 0;
+            while (__hip_atomic_load(&sync->gen, RLX_AGENT) < target) {
+                if (++spins > P_SPIN_LIMIT || __hip_atomic_load(&sync->timeout, RLX_AGENT)) {
+                    __hip_atomic_store(&sync->timeout, 1u, RLX_AGENT);
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *s_ok = ok;
+    }
+    __syncthreads();
+    gen++;
+    return *s_ok != 0;
+}
+
+// One wave's share of the window, as scan_rows_hot but against the unscaled vector sl:
+// x = (sl_i + c_i / T) / n  computed as  fma(c, 1/T, sl) * (1/n).
+template <typename T>
+__device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
+                                            const uint32_t *__restrict__ totals,
+                                            const double *__restrict__ rowH, const double *sl,
+                                            uint64_t B, const PState &st, double he_base,
+                                            unsigned long long *evp, uint64_t first, uint64_t stride,
+                                            uint64_t nrows, uint32_t lane, uint32_t &nread,
+                                            uint32_t &nprecise) {
+    const double dn = double(st.n), rn = 1.0 / dn;
+    const double thr_lo = st.thr - st.band;
+    const double thr_fast = thr_lo - FAST_BAND, thr_sure = st.thr + st.band + FAST_BAND;
+    const bool vec = (B & 255) == 0;
+    for (uint64_t r = first; r < nrows; r += stride) {
+        const uint64_t p = st.cursor + r;
+        const T *rp = mat + p * B;
+        const unsigned long long ev = __hip_atomic_load(evp, RLX_AGENT);
+        const uint32_t tot = totals[p];
+        const double hrow = rowH[p];
+        if (ev < p) break;
+        if (tot == 0) continue;
+        const double rt = 1.0 / double(tot);
+        const double mean_entropy = (he_base + hrow) / dn;
+        nread++;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, xmin = 0.0;
+        if (vec) {
+            const uint64_t full = B - B % (256 * P_CH);
+            uint64_t i0 = 0;
+            for (; i0 < full; i0 += 256 * P_CH) {  // P_CH chunks of 1 KiB per wave instruction per burst
+                Raw4<T> raw[P_CH];
+#pragma unroll
+                for (int j = 0; j < P_CH; j++) raw[j].load(rp + i0 + uint64_t(j) * 256 + lane * 4);
+#pragma unroll
+                for (int j = 0; j < P_CH; j++) {
+                    const uint64_t i = i0 + uint64_t(j) * 256 + lane * 4;
+                    const double2 b01 = *reinterpret_cast<const double2 *>(sl + i);
+                    const double2 b23 = *reinterpret_cast<const double2 *>(sl + i + 2);
+                    double v0, v1, v2, v3;
+                    raw[j].get(v0, v1, v2, v3);
+                    const double x0 = fma(v0, rt, b01.x) * rn, x1 = fma(v1, rt, b01.y) * rn;
+                    const double x2 = fma(v2, rt, b23.x) * rn, x3 = fma(v3, rt, b23.y) * rn;
+                    a0 += fast_neg_xlog2x(x0);
+                    a1 += fast_neg_xlog2x(x1);
+                    a2 += fast_neg_xlog2x(x2);
+                    a3 += fast_neg_xlog2x(x3);
+                    xmin = fmin(fmin(xmin, fmin(x0, x1)), fmin(x2, x3));
+                }
+            }
+            for (; i0 < B; i0 += 256) {
+                const uint64_t i = i0 + lane * 4;
+                double v0, v1, v2, v3;
+                load4(rp, i, v0, v1, v2, v3);
+                const double2 b01 = *reinterpret_cast<const double2 *>(sl + i);
+                const double2 b23 = *reinterpret_cast<const double2 *>(sl + i + 2);
+                const double x0 = fma(v0, rt, b01.x) * rn, x1 = fma(v1, rt, b01.y) * rn;
+                const double x2 = fma(v2, rt, b23.x) * rn, x3 = fma(v3, rt, b23.y) * rn;
+                a0 += fast_neg_xlog2x(x0);
+                a1 += fast_neg_xlog2x(x1);
+                a2 += fast_neg_xlog2x(x2);
+                a3 += fast_neg_xlog2x(x3);
+                xmin = fmin(fmin(xmin, fmin(x0, x1)), fmin(x2, x3));
+            }
+        } else {
+            for (uint64_t i = lane; i < B; i += 64) {
+                const double x = fma(row_value(rp, i), rt, sl[i]) * rn;
+                a0 += fast_neg_xlog2x(x);
+                xmin = fmin(xmin, x);
+            }
+        }
+        const double hf = dvs_wave_sum((a0 + a1) + (a2 + a3));
+        const double mn = dvs_wave_min(xmin);
+        const double jf = hf - mean_entropy;
+        if (!(mn < 0.0) && jf > thr_fast) {
+            bool hit = jf > thr_sure;
+            if (!hit) {  // f64 tier for the +-FAST_BAND zone
+                nprecise++;
+                Ent e;
+                for (uint64_t i = lane; i < B; i += 64) e.add(fma(row_value(rp, i), rt, sl[i]) * rn);
+                hit = dvs_wave_sum(e.h) - mean_entropy > thr_lo;
+            }
+            if (hit && lane == 0) atomicMin(evp, (unsigned long long)p);
+        }
+    }
+}
+
+// LDS: [sl B f64][scratch 128 f64][s_mH P_MAXN f64][s_slot P_MAXN u32][flags]
+// CACHED: B <= P_J * 512, so a thread's share of the candidate row stays in registers
+template <typename T, bool CACHED>
+__global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, const T *__restrict__ mat,
+                                                                    PSync *sync, uint32_t G) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint64_t B = d.B;
+    double *sl = reinterpret_cast<double *>(smem);
+    double *scratch = sl + ((B + 1) & ~1ull);
+    double *s_mH = scratch + 128;
+    uint32_t *s_slot = reinterpret_cast<uint32_t *>(s_mH + P_MAXN);
+    int *s_flag = reinterpret_cast<int *>(s_slot + P_MAXN);
+    SelCtl *ctl = d.ctl;
+    const int tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    // the LAST block mirrors the state into global memory: with n < G it owns no member in
+    // the leave-one-out pass, so its extra stores overlap the other blocks' arithmetic
+    const bool lead = blockIdx.x == G - 1;
+
+    // ---- replica of the state (global memory is quiescent: written by earlier launches)
+    PState st;
+    st.cursor = ctl->cursor;
+    st.npos = ctl->npos;
+    st.window = ctl->window;
+    st.wmin = ctl->window_min;
+    st.wmax = ctl->window_max;
+    st.n = ctl->size;
+    st.li = ctl->lowest;
+    st.sumH = ctl->sum_entropy;
+    st.total_jsd = ctl->total_jsd;
+    st.thr = ctl->thr;
+    st.band = ctl->band;
+    st.n_windows = st.n_events = st.n_accepts = 0;
+    if (ctl->status != SEL_RUN || ctl->ev_kind != 0 || st.n > P_MAXN || st.n < 2) return;
+    for (uint32_t r = tid; r < st.n; r += P_THREADS) {
+        s_slot[r] = d.ord[r];
+        s_mH[r] = d.mH[d.ord[r]];
+    }
+    __syncthreads();
+    {
+        const double *low = d.M + uint64_t(s_slot[st.li]) * B;
+        for (uint64_t i = tid; i < B; i += P_THREADS) sl[i] = d.S[i] - low[i];
+    }
+    __syncthreads();
+
+    uint32_t gen = 0, epoch = 0;
+    uint32_t nread = 0, nprecise = 0;
+    uint32_t exit_status = SEL_RUN;  // what the lead block writes to ctl->status on exit
+    uint32_t arb_stage = 0;
+    uint64_t arb_pos = 0;
+    uint32_t pend_kind = 0;  // ev_kind left pending for the multi-launch kernels (finalize tie)
+    const uint64_t wpb = P_THREADS / 64;
+    const uint64_t nwaves = uint64_t(G) * wpb;
+
+    unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
+#define P_STAMP(k)                                                         \
+    do {                                                                   \
+        if ((lead || blockIdx.x == 0) && tid == 0) {                       \
+            const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); \
+            (lead ? sync->dbg : sync->dbg2)[k] += t_now - t_prev;          \
+            t_prev = t_now;                                                \
+        }                                                                  \
+    } while (0)
+    for (;;) {
+        unsigned long long *evp = &sync->ev[epoch % 3];
+        if (lead && tid == 0) __hip_atomic_store(&sync->ev[(epoch + 1) % 3], SEL_NONE, RLX_AGENT);
+        const uint64_t end = umin64(st.cursor + uint64_t(st.window), st.npos);
+        const uint64_t nrows = end - st.cursor;
+        // ================= scan
+        p_scan_rows<T>(mat, d.totals, d.rowH, sl, B, st, st.sumH - s_mH[st.li], evp,
+                       uint64_t(blockIdx.x) * wpb + wave, nwaves, nrows, lane, nread, nprecise);
+        P_STAMP(0);
+        if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
+        P_STAMP(1);
+        const uint64_t p = __hip_atomic_load(evp, RLX_AGENT);
+        st.n_windows++;
+        if (p == SEL_NONE) {
+            st.cursor = end;
+            if (end >= st.npos) { exit_status = SEL_DONE; break; }
+            st.window = sel_next_window(st.cursor, st.n, st.wmin, st.wmax);
+            epoch++;
+            continue;
+        }
+        // ================= resolve (every workgroup, identical arithmetic)
+        // Scores only need to land inside the decision band (4 B eps H), so the f64
+        // evaluations multiply by reciprocals; everything that feeds S / sl keeps the
+        // reference's exact add / subtract / clamp order.
+        const double dn = double(st.n), rn = 1.0 / dn;
+        const double tot = double(d.totals[p]);
+        const double cand_H = d.rowH[p];
+        const T *rp = mat + p * B;
+        double fr[P_J];  // the candidate's frequencies of this thread's bins (B <= P_J * 512)
+        double jsd, sm;
+        {
+            Ent e;
+            for (uint64_t b0 = 0; b0 < B; b0 += uint64_t(P_J) * P_THREADS) {
+#pragma unroll
+                for (int j = 0; j < P_J; j++) {
+                    const uint64_t i = b0 + uint64_t(j) * P_THREADS + tid;
+                    if (i < B) {
+                        const double f = cand_freq(rp, i, tot);
+                        if (CACHED) fr[j] = f;
+                        e.add((sl[i] + f) * rn);
+                    }
+                }
+            }
+            double h = e.h, mn = e.mn;
+            sm = e.sum;
+            block_red3(h, mn, sm, scratch);
+            const double mean_entropy = (st.sumH - s_mH[st.li] + cand_H) / dn;
+            jsd = (mn < 0.0) ? NAN : h - mean_entropy;
+        }
+        if (sum_risky(sm, B) || fabs(jsd - st.thr) <= st.band) {
+            st.n_windows--;  // the multi-launch resolve will count this window
+            exit_status = SEL_ARBITER;
+            arb_stage = ARB_RESOLVE;
+            arb_pos = p;
+            break;
+        }
+        st.n_events++;
+        if (!(jsd > st.thr)) {  // rejected (NaN included, records.rs:91)
+            st.cursor = p + 1;
+            if (st.cursor >= st.npos) { exit_status = SEL_DONE; break; }
+            epoch++;
+            continue;
+        }
+        P_STAMP(2);
+        // ================= replace_lowest (records.rs:94-147) + leave-one-out
+        st.n_accepts++;
+        const uint32_t n = st.n, li = st.li;
+        const uint32_t slot_low = s_slot[li];
+        const uint32_t old_lab = lead ? d.mLabel[slot_low] : 0;
+        __syncthreads();
+        if (tid == 0) {
+            double sh = st.sumH - s_mH[li];
+            sh += cand_H;
+            scratch[127] = sh;
+            for (uint32_t i = li; i + 1 < n; i++) {  // Vec::remove + push
+                s_slot[i] = s_slot[i + 1];
+                s_mH[i] = s_mH[i + 1];
+            }
+            s_slot[n - 1] = slot_low;
+            s_mH[n - 1] = cand_H;
+        }
+        __syncthreads();
+        st.sumH = scratch[127];
+        // One pass over the bins: S_new_i = clamp(S_i - low_i) + f_i feeds (a) the new set's
+        // total_jsd (every workgroup) and (b) the leave-one-out score of member r (workgroup r).
+        const double rdiv = 1.0 / (dn - 1.0);
+        bool ev_risky = false;
+        for (uint32_t r = blockIdx.x, pass = 0; pass == 0 || r < n; r += G, pass++) {
+            const bool has_member = r < n;
+            const bool is_new = r == n - 1;
+            const double *mrow = d.M + uint64_t(has_member ? s_slot[r] : 0) * B;
+            Ent e;
+            double h2 = 0.0, s2 = 0.0;
+            for (uint64_t b0 = 0; b0 < B; b0 += uint64_t(P_J) * P_THREADS) {
+#pragma unroll
+                for (int j = 0; j < P_J; j++) {
+                    const uint64_t i = b0 + uint64_t(j) * P_THREADS + tid;
+                    if (i < B) {
+                        double v = sl[i];
+                        if (v <= DVS_EPS) v = 0.0;
+                        const double f = CACHED ? fr[j] : cand_freq(rp, i, tot);
+                        const double sn = v + f;
+                        if (pass == 0) {
+                            e.add(sn * rn);
+                            if (lead) {
+                                d.S[i] = sn;
+                                d.M[uint64_t(slot_low) * B + i] = f;
+                            }
+                        }
+                        if (has_member) {
+                            double u = (sn - (is_new ? f : mrow[i])) * rdiv;  // updated_mean_freqs
+                            if (u <= DVS_EPS) u = 0.0;
+                            if (u > 0.0) h2 -= u * log2_acc(u);
+                            s2 += u;
+                        }
+                    }
+                }
+            }
+            double h = e.h, mn = e.mn, sm2 = e.sum;
+            block_red5(h, mn, sm2, h2, s2, scratch);
+            if (pass == 0) {
+                const double hm = (mn < 0.0) ? NAN : h;
+                st.total_jsd = hm - st.sumH / dn;
+                ev_risky = sum_risky(sm2, B) || !(hm == hm);
+            }
+            if (has_member && tid == 0) {
+                const double mean_entropy = (st.sumH - s_mH[r]) * rdiv;
+                d.dtmp[r] = st.total_jsd - (h2 - mean_entropy);
+                d.dsum[r] = s2;
+            }
+        }
+        st.cursor = p + 1;
+        if (lead && tid == 0) {  // post-resolve mirror (what resolve_kernel leaves behind)
+            ctl->sum_entropy = st.sumH;
+            ctl->total_jsd = st.total_jsd;
+            if (old_lab < d.nlabels) d.inset[old_lab] = 0;
+            if (uint32_t(p) < d.nlabels) d.inset[uint32_t(p)] = 1;
+            for (uint32_t i = 0; i < n; i++) d.ord[i] = s_slot[i];
+            d.mH[slot_low] = cand_H;
+            d.mLabel[slot_low] = uint32_t(p);
+            d.mPos[slot_low] = p;
+            d.evlog_pos[ctl->n_logged] = p;
+            d.evlog_kind[ctl->n_logged] = 1;
+            ctl->n_logged++;
+            ctl->cursor = st.cursor;
+            ctl->event_pos = SEL_NONE;
+            ctl->last_jsd = jsd;
+            ctl->ev_n = n;
+            ctl->ev_risky = ev_risky ? 1 : 0;
+        }
+        P_STAMP(3);
+        if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
+        P_STAMP(4);
+        // ================= finalize (every workgroup): argmin, strict '<' from 1e6
+        uint32_t lowest;
+        double dmin, dsecond, mean, sd;
+        int any_risky;
+        if (n <= 64) {  // one wave holds every score: shuffles only, one barrier to share
+            if (wave == 0) {
+                const bool on = lane < n;
+                const double v = on ? d.dtmp[lane] : NAN;
+                const bool rk = on && sum_risky(d.dsum[lane], B);
+                const double vb = (on && v < 1e6) ? v : 1e6;
+                const double mnv = dvs_wave_min(vb);
+                const double fi = (mnv < 1e6 && on && v == mnv) ? double(lane) : 4294967295.0;
+                const double first = dvs_wave_min(fi);
+                const uint32_t lw = (first < 4294967295.0) ? uint32_t(first) : 0u;
+                const double sec = dvs_wave_min((on && lane != lw && v < 1e6) ? v : 1e6);
+                const double mu = dvs_wave_sum(on ? v : 0.0) / dn;
+                const double t = on ? v - mu : 0.0;
+                const double var = dvs_wave_sum(t * t);
+                const unsigned long long anyr = __ballot(rk);
+                if (lane == 0) {
+                    scratch[100] = mnv;
+                    scratch[101] = double(lw);
+                    scratch[102] = sec;
+                    scratch[103] = mu;
+                    scratch[104] = sqrt(var / (dn - 1.0));
+                    scratch[105] = anyr ? 1.0 : 0.0;
+                }
+            }
+            __syncthreads();
+            dmin = scratch[100];
+            lowest = uint32_t(scratch[101]);
+            dsecond = scratch[102];
+            mean = scratch[103];
+            sd = scratch[104];
+            any_risky = scratch[105] != 0.0;
+            __syncthreads();
+        } else {
+            bool risky = false;
+            double best = 1e6;
+            for (uint32_t r = tid; r < n; r += P_THREADS) {
+                const double v = d.dtmp[r];
+                if (sum_risky(d.dsum[r], B)) risky = true;
+                if (v < best) best = v;
+            }
+            dmin = dvs_block_min(best, scratch);
+            double fi = 4294967295.0;
+            for (uint32_t r = tid; r < n; r += P_THREADS)
+                if (dmin < 1e6 && d.dtmp[r] == dmin) fi = fmin(fi, double(r));
+            const double dfirst = dvs_block_min(fi, scratch);
+            lowest = (dfirst < 4294967295.0) ? uint32_t(dfirst) : 0u;
+            double second = 1e6;
+            for (uint32_t r = tid; r < n; r += P_THREADS) {
+                const double v = d.dtmp[r];
+                if (r != lowest && v < second) second = v;
+            }
+            dsecond = dvs_block_min(second, scratch);
+            any_risky = __syncthreads_or(risky ? 1 : 0);
+            double acc = 0.0;
+            for (uint32_t r = tid; r < n; r += P_THREADS) acc += d.dtmp[r];
+            mean = dvs_block_sum(acc, scratch) / dn;
+            acc = 0.0;
+            for (uint32_t r = tid; r < n; r += P_THREADS) {
+                const double t = d.dtmp[r] - mean;
+                acc += t * t;
+            }
+            sd = sqrt(dvs_block_sum(acc, scratch) / (dn - 1.0));
+        }
+        const double band = sel_band(st.total_jsd + st.sumH / dn, B);
+        if (any_risky || ev_risky || (n > 1 && dsecond - dmin <= band && dsecond < 1e6)) {
+            exit_status = SEL_ARBITER;  // argmin too close to call: loo + finalize kernels resume
+            arb_stage = ARB_FINALIZE;
+            arb_pos = p;
+            pend_kind = 1;
+            break;
+        }
+        st.li = lowest;
+        st.band = band;
+        st.thr = st.total_jsd + DVS_EPS;
+        {   // sl <- S_new - new lowest, in place (each thread owns its bins)
+            const bool low_is_new = lowest == n - 1;
+            const double *lrow = d.M + uint64_t(s_slot[lowest]) * B;
+            for (uint64_t b0 = 0; b0 < B; b0 += uint64_t(P_J) * P_THREADS) {
+#pragma unroll
+                for (int j = 0; j < P_J; j++) {
+                    const uint64_t i = b0 + uint64_t(j) * P_THREADS + tid;
+                    if (i < B) {
+                        double v = sl[i];
+                        if (v <= DVS_EPS) v = 0.0;
+                        const double f = CACHED ? fr[j] : cand_freq(rp, i, tot);
+                        const double sn = v + f;
+                        const double nv = sn - (low_is_new ? f : lrow[i]);
+                        sl[i] = nv;
+                        if (lead) d.base[i] = nv / dn;
+                    }
+                }
+            }
+        }
+        if (lead) {
+            for (uint32_t r = tid; r < n; r += P_THREADS) d.mDelta[r] = d.dtmp[r];
+            if (tid == 0) {
+                ctl->lowest = lowest;
+                ctl->mean_delta = mean;
+                ctl->std_delta = sd;
+                ctl->cov_delta = sd / mean;
+                ctl->band = band;
+                ctl->he_base = st.sumH - s_mH[lowest];
+                ctl->thr = st.thr;
+                ctl->ev_risky = 0;
+            }
+        }
+        __syncthreads();
+        P_STAMP(5);
+        if (st.cursor >= st.npos) { exit_status = SEL_DONE; break; }
+        st.window = sel_next_window(st.cursor, st.n, st.wmin, st.wmax);
+        epoch++;
+    }
+
+    // ---- exit: counters, and the lead block's scalar mirror
+    if (lane == 0 && nread) {
+        atomicAdd(&ctl->rows_scored, (unsigned long long)nread);
+        if (nprecise) atomicAdd(&ctl->rows_rechecked, (unsigned long long)nprecise);
+    }
+    if (lead && tid == 0) {
+        ctl->cursor = st.cursor;
+        ctl->window = st.window;
+        ctl->n_windows += st.n_windows;
+        ctl->n_events += st.n_events;
+        ctl->n_accepts += st.n_accepts;
+        ctl->ev_kind = pend_kind;
+        if (exit_status == SEL_ARBITER) {
+            ctl->arb_stage = arb_stage;
+            ctl->arb_pos = arb_pos;
+            if (arb_stage == ARB_RESOLVE) ctl->event_pos = arb_pos;  // resolve_kernel re-evaluates it
+        }
+        ctl->status = exit_status == SEL_RUN ? SEL_ERROR : exit_status;
+    }
+}
+
+}  // namespace
+
+// One persistent launch.  Returns DVS_OK with *ran = false when the selection does not
+// qualify (the caller then uses the multi-launch engine).
+template <typename T>
+static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
+    const SelDev &d = s->dev;
+    PSync init;
+    memset(&init, 0, sizeof init);
+    for (int i = 0; i < 4; i++) init.ev[i] = SEL_NONE;
+    DVS_HIP(ctx, hipMemcpyAsync(s->psync, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (s->time_scan) {
+        if (s->ev_used + 2 > s->ev_pool.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            s->ev_pool.push_back(a);
+            s->ev_pool.push_back(b);
+        }
+        e0 = s->ev_pool[s->ev_used];
+        e1 = s->ev_pool[s->ev_used + 1];
+        s->ev_used += 2;
+        (void)hipEventRecord(e0, ctx->stream);
+    }
+    if (d.B <= uint64_t(P_J) * P_THREADS)
+        hipLaunchKernelGGL((persist_nmost_kernel<T, true>), dim3(s->persist_grid), dim3(P_THREADS),
+                           s->persist_lds, ctx->stream, d, mat, static_cast<PSync *>(s->psync),
+                           s->persist_grid);
+    else
+        hipLaunchKernelGGL((persist_nmost_kernel<T, false>), dim3(s->persist_grid), dim3(P_THREADS),
+                           s->persist_lds, ctx->stream, d, mat, static_cast<PSync *>(s->psync),
+                           s->persist_grid);
+    if (s->time_scan) (void)hipEventRecord(e1, ctx->stream);
+    DVS_HIP(ctx, hipGetLastError());
+    return DVS_OK;
+}
+
+int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
+    const uint64_t B = s->dev.B;
+    s->persist = false;
+    if (getenv("DVS_NO_PERSIST")) return DVS_OK;
+    if (s->params.mode != DVS_MODE_NMOST || !s->h_order.empty() || !s->h_labels.empty()) return DVS_OK;
+    if (s->cap > P_MAXN) return DVS_OK;
+    const size_t lds = ((B + 1) & ~1ull) * 8 + 128 * 8 + P_MAXN * 12 + 64;
+    if (lds > ctx->lds_per_block || lds > 150 * 1024) return DVS_OK;
+    s->persist_lds = lds;
+    s->persist_grid = uint32_t(ctx->n_cu);  // one 512-thread workgroup per CU: all resident
+    const bool cached = B <= uint64_t(P_J) * P_THREADS;
+    const void *fn =
+        s->mat_kind == 0
+            ? (cached ? reinterpret_cast<const void *>(persist_nmost_kernel<uint32_t, true>)
+                      : reinterpret_cast<const void *>(persist_nmost_kernel<uint32_t, false>))
+            : (cached ? reinterpret_cast<const void *>(persist_nmost_kernel<double, true>)
+                      : reinterpret_cast<const void *>(persist_nmost_kernel<double, false>));
+    if (lds > 48 * 1024)
+        DVS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    int rc = dvs_dev_alloc(ctx, &s->psync, sizeof(PSync), "persistent sync block");
+    if (rc) return rc;
+    s->persist = true;
+    return DVS_OK;
+}
+
+int dvs_persist_launch(dvs_ctx *ctx, dvs_select *s) {
+    return s->mat_kind == 0 ? persist_launch<uint32_t>(ctx, s, s->mat->d_counts)
+                            : persist_launch<double>(ctx, s, s->mat->d_freqs);
+}

@@ -79,6 +79,11 @@ struct dvs_select {
     bool base_in_lds = true;
     bool scan_hot = false;
     bool fused = false;  // resolve + leave-one-out + finalize in one launch (small sets)
+    // persistent single-launch engine (persist.hip)
+    bool persist = false;
+    uint32_t persist_grid = 0;
+    size_t persist_lds = 0;
+    void *psync = nullptr;
     int batch = 16;
     // timing
     bool time_scan = false;
@@ -94,3 +99,7 @@ struct dvs_select {
 // and write the forced outcome + status RUN back to the device control block.
 int dvs_select_arbitrate(dvs_ctx *ctx, dvs_select *s);
 void dvs_select_arbiter_free(dvs_select *s);
+
+// persist.hip
+int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s);
+int dvs_persist_launch(dvs_ctx *ctx, dvs_select *s);

@@ -24,6 +24,7 @@
 // f64 operation order.
 #include "dvs_internal.h"
 #include "select.h"
+#include "select_dev.h"
 
 #include <algorithm>
 #include <cmath>
@@ -35,132 +36,6 @@ namespace {
 constexpr int SCAN_THREADS = 512;   // 8 waves share one LDS copy of the state vector
 constexpr int WIDE_THREADS = 1024;  // single-block state kernels
 constexpr int LOO_THREADS = 256;
-
-// sum_{x>0} -x log2 x over the bins a thread owns, plus what the reference's
-// entropy() (src/record.rs:86-106) is sensitive to: a negative bin (log2 -> NaN)
-// and the sum of the bins (the |sum - 1| <= len * eps check).
-struct Ent {
-    double h = 0.0, sum = 0.0, mn = 0.0;
-    __device__ __forceinline__ void add(double x) {
-        if (x > 0.0) h -= x * log2(x);
-        sum += x;
-        mn = fmin(mn, x);
-    }
-};
-
-__device__ __forceinline__ uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
-
-// Width of the zone in which the device's score and the reference's (sequential
-// f64 sum over B bins, src/record.rs:92-98) cannot be told apart: the reference's
-// own worst-case summation error is ~ B * eps/2 * H.
-__device__ __forceinline__ double sel_band(double hmean, uint64_t B) {
-    return 4.0 * double(B) * DVS_EPS * fmax(1.0, fabs(hmean));
-}
-
-__device__ __forceinline__ double row_value(const uint32_t *row, uint64_t i) { return double(row[i]); }
-__device__ __forceinline__ double row_value(const double *row, uint64_t i) { return row[i]; }
-
-// ---------------------------------------------------------------- scan kernel
-// One wavefront per candidate row; lane l owns bins 4*(j*64 + l) .. +3 so that a
-// wave instruction reads 1 KiB (16 B per lane) of the row.  The per-state vector
-// b_i = (S_i - low_i) / size is staged once per workgroup in LDS (8 waves share it).
-//   x_i = b_i + c_i / (total * size)      (reference: (S_i - low_i + f_i) / size)
-//   jsd = sum_i -x_i log2 x_i - (sumH - H_low + H_c) / size
-//
-// Two tiers.  FAST: x in f64, log2 x = exponent + v_log_f32(mantissa) -- the
-// mantissa is rounded to f32 (<= 2^-24 relative -> <= 8.6e-8 in log2) and
-// v_log_f32 is good to ~1 ulp of a result in [-1, 0] (<= 6e-8), so each log is
-// off by < 1.5e-7 and, as sum x_i = 1, so is the row's entropy (FAST_BAND below;
-// the bound on v_log_f32 is measured exhaustively by dvs_selftest_fast_log2).
-// A row whose fast score clears thr + band + FAST_BAND is an event outright; a
-// row within FAST_BAND (+ band) of the threshold is re-evaluated by the same wave
-// in full f64 (PRECISE) and is an event <=> precise jsd > thr - band.  Either way
-// the resolve kernel re-evaluates the first event in f64 before acting (NaN
-// compares false everywhere: the reference rejects too).
-constexpr double FAST_BAND = 4e-7;
-constexpr int SCAN_CH = 16;  // chunks (1 KiB per wave instruction) requested per batch
-
-__device__ __forceinline__ double fast_neg_xlog2x(double x) {
-    const double xm = fmax(x, 1e-300);  // x <= 0 contributes ~0 here; sign handled via min(x)
-    const double m = __builtin_amdgcn_frexp_mant(xm);       // [0.5, 1)
-    const int e = __builtin_amdgcn_frexp_exp(xm);
-    const float l = __builtin_amdgcn_logf(float(m));        // v_log_f32 = log2
-    return -xm * (double(e) + double(l));
-}
-
-// 4 consecutive bins as they sit in memory (converted to f64 only when consumed, so a
-// batch of in-flight chunks costs 4 VGPRs each for a count matrix)
-template <typename T> struct Raw4;
-template <> struct Raw4<uint32_t> {
-    uint4 c;
-    __device__ __forceinline__ void load(const uint32_t *p) { c = *reinterpret_cast<const uint4 *>(p); }
-    __device__ __forceinline__ void get(double &v0, double &v1, double &v2, double &v3) const {
-        v0 = double(c.x); v1 = double(c.y); v2 = double(c.z); v3 = double(c.w);
-    }
-};
-template <> struct Raw4<double> {
-    double2 a, b;
-    __device__ __forceinline__ void load(const double *p) {
-        a = *reinterpret_cast<const double2 *>(p);
-        b = *reinterpret_cast<const double2 *>(p + 2);
-    }
-    __device__ __forceinline__ void get(double &v0, double &v1, double &v2, double &v3) const {
-        v0 = a.x; v1 = a.y; v2 = b.x; v3 = b.y;
-    }
-};
-
-template <typename T>
-__device__ __forceinline__ void load4(const T *rp, uint64_t i, double &v0, double &v1, double &v2,
-                                      double &v3) {
-    if constexpr (sizeof(T) == 4) {
-        const uint4 c = *reinterpret_cast<const uint4 *>(rp + i);
-        v0 = double(c.x); v1 = double(c.y); v2 = double(c.z); v3 = double(c.w);
-    } else {
-        const double2 a = *reinterpret_cast<const double2 *>(rp + i);
-        const double2 b = *reinterpret_cast<const double2 *>(rp + i + 2);
-        v0 = a.x; v1 = a.y; v2 = b.x; v3 = b.y;
-    }
-}
-
-// per-launch constants of the scan, read once from the control block
-struct ScanState {
-    uint64_t cursor, nrows;
-    double thr_lo, thr_fast, thr_sure, he_base, dsize;
-};
-
-__device__ __forceinline__ void fast4(const double2 b01, const double2 b23, double v0, double v1,
-                                      double v2, double v3, double rinv, double &a0, double &a1,
-                                      double &a2, double &a3, double &xmin) {
-    const double x0 = fma(v0, rinv, b01.x), x1 = fma(v1, rinv, b01.y);
-    const double x2 = fma(v2, rinv, b23.x), x3 = fma(v3, rinv, b23.y);
-    a0 += fast_neg_xlog2x(x0);
-    a1 += fast_neg_xlog2x(x1);
-    a2 += fast_neg_xlog2x(x2);
-    a3 += fast_neg_xlog2x(x3);
-    xmin = fmin(fmin(xmin, fmin(x0, x1)), fmin(x2, x3));
-}
-
-// PRECISE tier for one row (rare): same bins, f64 log2; true if it clears thr - band
-template <typename T>
-__device__ __forceinline__ bool precise_row(const T *rp, const double *bvec, uint64_t B, double rinv,
-                                            double mean_entropy, double thr_lo, uint32_t lane) {
-    Ent e;
-    if ((B & 255) == 0) {
-        for (uint64_t i0 = 0; i0 < B; i0 += 256) {
-            const uint64_t i = i0 + lane * 4;
-            double v0, v1, v2, v3;
-            load4(rp, i, v0, v1, v2, v3);
-            e.add(fma(v0, rinv, bvec[i]));
-            e.add(fma(v1, rinv, bvec[i + 1]));
-            e.add(fma(v2, rinv, bvec[i + 2]));
-            e.add(fma(v3, rinv, bvec[i + 3]));
-        }
-    } else {
-        for (uint64_t i = lane; i < B; i += 64) e.add(fma(row_value(rp, i), rinv, bvec[i]));
-    }
-    const double h = dvs_wave_sum(e.h);
-    return h - mean_entropy > thr_lo;
-}
 
 // Hot row loop of one wave: identity order, unique ids, B a multiple of 256 * SCAN_CH
 // bins.  A row is consumed in batches of SCAN_CH chunks of 1 KiB per wave instruction,
@@ -349,37 +224,6 @@ __global__ void fast_log2_selftest_kernel(double *out) {
 }
 
 // ------------------------------------------------------------- state kernels
-__device__ __forceinline__ double cand_freq(const uint32_t *row, uint64_t i, double tot) {
-    return double(row[i]) / tot;  // record.rs:139, correctly rounded
-}
-__device__ __forceinline__ double cand_freq(const double *row, uint64_t i, double) { return row[i]; }
-
-// (sum, min, sum) over the block in ONE barrier pair; every thread gets the result.
-// scratch: >= 3 * 16 doubles.  Fixed tree -> same inputs, same bits.
-__device__ __forceinline__ void block_red3(double &h, double &mn, double &sm, double *scratch) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nwave = (blockDim.x + 63) >> 6;
-    h = dvs_wave_sum(h);
-    mn = dvs_wave_min(mn);
-    sm = dvs_wave_sum(sm);
-    __syncthreads();  // scratch may still be read from a previous call
-    if (lane == 0) {
-        scratch[wave] = h;
-        scratch[16 + wave] = mn;
-        scratch[32 + wave] = sm;
-    }
-    __syncthreads();
-    double a = 0.0, b = scratch[16], c = 0.0;
-    for (int i = 0; i < nwave; i++) {
-        a += scratch[i];
-        b = fmin(b, scratch[16 + i]);
-        c += scratch[32 + i];
-    }
-    h = a;
-    mn = b;
-    sm = c;
-}
-
 // JSD of the set with `lowest` swapped for the candidate in d.cand
 // (src/records.rs:70-84), all threads of the block get the result.
 __device__ double block_delta_jsd(const SelDev &d, const SelCtl *ctl, double cand_H,
@@ -408,24 +252,6 @@ __device__ double block_entropy_div(const double *vec, double div, uint64_t B, d
     return (mn < 0.0) ? NAN : h;
 }
 
-__device__ __forceinline__ void ctl_next_window(SelCtl *ctl) {
-    // accept probability at stream position i is ~ size / i: widen the window as
-    // events thin out (bounded by what one launch covers)
-    uint64_t w = ctl->cursor / (2ull * max(1u, ctl->size));
-    w = max<uint64_t>(w, ctl->window_min);
-    w = min<uint64_t>(w, ctl->window_max);
-    ctl->window = uint32_t(w);
-}
-
-// sum-to-one guard of entropy() (record.rs:99-104): the device cannot decide a
-// borderline case, so anything past a quarter of the tolerance goes to the arbiter
-__device__ __forceinline__ bool sum_risky(double sum, uint64_t B) {
-    return !(fabs(sum - 1.0) <= 0.25 * double(B) * DVS_EPS);
-}
-
-// Resolves the first event of the window: fetch the candidate, re-evaluate its
-// score with the reference's per-bin operation order, decide, and apply
-// replace_lowest (or stage a tentative push for MODE_MAX).  One 1024-thread block.
 template <typename T>
 __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, uint32_t scan_grid,
                              double *scratch, int &s_action) {
@@ -803,7 +629,7 @@ __device__ void loo_small(const SelDev &d, double *scratch, uint32_t *s_slot) {
             if (r < n) {
                 double v = (sv - d.M[uint64_t(s_slot[r]) * d.B + i]) / div;
                 if (v <= DVS_EPS) v = 0.0;
-                if (v > 0.0) h[r] -= v * log2(v);
+                if (v > 0.0) h[r] -= v * log2_acc(v);
                 sm[r] += v;
             }
         }
@@ -919,6 +745,7 @@ static void sel_free(dvs_select *s) {
         dvs_dev_free(s->ctx, p);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
+    dvs_dev_free(s->ctx, s->psync);
     dvs_select_arbiter_free(s);
     delete s;
 }
@@ -988,6 +815,16 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat) {
             }
             s->ev_used = 0;
         }
+        if (s->persist && s->psync && getenv("DVS_PERSIST_DEBUG")) {
+            unsigned long long dbg[24];
+            if (hipMemcpy(dbg, s->psync, sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
+                for (int w = 0; w < 2; w++)
+                    fprintf(stderr, "[dvs persist %s] us: scan %.1f bar1 %.1f resolve %.1f loo %.1f bar2 %.1f finalize %.1f\n",
+                            w ? "mirror block" : "block 0", dbg[6 + 8 * w] / 100.0, dbg[7 + 8 * w] / 100.0,
+                            dbg[8 + 8 * w] / 100.0, dbg[9 + 8 * w] / 100.0, dbg[10 + 8 * w] / 100.0,
+                            dbg[11 + 8 * w] / 100.0);
+            }
+        }
         if (c.status == SEL_DONE) return DVS_OK;
         if (c.status == SEL_ARBITER) {
             if (s->params.flags & DVS_SELECT_NO_ARBITER)
@@ -1001,8 +838,17 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat) {
             DVS_HIP(ctx, hipGetLastError());
             continue;
         }
+        if (c.status == SEL_ERROR)
+            return dvs_set_error(ctx, DVS_ERR_RUNTIME,
+                                 "persistent selection kernel gave up at a grid barrier (not all "
+                                 "workgroups resident?); set DVS_NO_PERSIST=1 for the multi-launch engine");
         if (c.status != SEL_RUN)
             return dvs_set_error(ctx, DVS_ERR_RUNTIME, "selection engine in state %u", c.status);
+        if (s->persist) {
+            rc = dvs_persist_launch(ctx, s);
+            if (rc) return rc;
+            continue;
+        }
         for (int i = 0; i < s->batch; i++) launch_iteration<T>(ctx, s, mat, 0);
         DVS_HIP(ctx, hipGetLastError());
     }
@@ -1160,12 +1006,21 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
         return dvs_hip_fail(ctx, he, "hipHostMalloc(ctl)");
     }
 
+    {
+        int prc = dvs_persist_setup(ctx, s);
+        if (prc) {
+            sel_free(s);
+            return prc;
+        }
+    }
     SelCtl c;
     std::memset(&c, 0, sizeof c);
     c.cursor = n_seed;
     c.npos = npos;
     c.event_pos = SEL_NONE;
-    const uint32_t wdef = params->window ? params->window : 4096;
+    // default window: one row per wave of the persistent grid, else 4096 rows per scan launch
+    const uint32_t wdef = params->window ? params->window
+                                         : (s->persist ? s->persist_grid * 8u : 4096u);
     c.window_min = wdef;
     c.window_max = std::max<uint32_t>(wdef, s->scan_grid * (SCAN_THREADS / 64) * 8);
     c.window = wdef;
@@ -1268,6 +1123,40 @@ extern "C" int dvs_select_delta_jsd(dvs_ctx *ctx, const dvs_select *s, const dvs
     DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     (void)hipFree(d_out);
     if (d_lab) (void)hipFree(d_lab);
+    return DVS_OK;
+}
+
+// max |log2_acc(x) - log2(x)| / max(1, |log2 x|) over 2^17 mantissas x 80 exponents
+__global__ void log2_acc_selftest_kernel(double *out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;  // 2^17 threads
+    double worst = 0.0;
+    for (int e = -78; e <= 1; e++) {
+        // mantissas spread over [1, 2), plus a dense cluster around sqrt(2) and 1
+        const double m = 1.0 + double(t) / 131072.0;
+        const double xs[3] = {ldexp(m, e), ldexp(1.4142135623730951 + (double(t) - 65536.0) * 1e-12, e),
+                              ldexp(1.0 + (double(t) - 65536.0) * 2.2e-16, e)};
+        for (int q = 0; q < 3; q++) {
+            const double ref = log2(xs[q]);
+            const double err = fabs(log2_acc(xs[q]) - ref) / fmax(1.0, fabs(ref));
+            worst = fmax(worst, err);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o, 64));
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(reinterpret_cast<unsigned long long *>(out), (unsigned long long)__double_as_longlong(worst));
+}
+
+extern "C" int dvs_selftest_log2_acc(dvs_ctx *ctx, double *max_rel_err) {
+    if (!ctx || !max_rel_err) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    double *d = nullptr;
+    DVS_HIP(ctx, hipMalloc(&d, 8));
+    DVS_HIP(ctx, hipMemsetAsync(d, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(log2_acc_selftest_kernel, dim3(512), dim3(256), 0, ctx->stream, d);
+    DVS_HIP(ctx, hipGetLastError());
+    DVS_HIP(ctx, hipMemcpyAsync(max_rel_err, d, 8, hipMemcpyDeviceToHost, ctx->stream));
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d);
     return DVS_OK;
 }
 

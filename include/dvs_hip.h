@@ -157,6 +157,9 @@ int dvs_ctx_set_timing(dvs_ctx *ctx, int on);
 /* diagnostic: max |v_log_f32(m) - log2(m)| over every f32 m in [0.5, 1), the
  * hardware term of the scan kernel's fast-tier error bound (select.hip FAST_BAND) */
 int dvs_selftest_fast_log2(dvs_ctx *ctx, double *max_abs_err);
+/* diagnostic: max |log2_acc(x) - log2(x)| / max(1, |log2 x|) of the f64 log2 the precise
+ * evaluations use (select_dev.h), over 2^17 mantissas x 80 binades */
+int dvs_selftest_log2_acc(dvs_ctx *ctx, double *max_rel_err);
 
 /* ---- mash ----------------------------------------------------------------- *
  * dvs_mash_sketch replaces _dvs.mash_sketch (src/distance.rs:136-182) for a

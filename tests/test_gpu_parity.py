@@ -519,3 +519,13 @@ def test_fast_log2_error_bound(ctx):
     ctx.check(ctx._L.dvs_selftest_fast_log2(ctx._h, C.byref(err)))
     assert 0.0 < err.value < 1.5e-7, err.value
     print("max |v_log_f32 - log2| on [0.5,1):", err.value)
+
+
+def test_log2_acc_error_bound(ctx):
+    """the f64 log2 of the precise evaluations agrees with ocml's to ~1 ulp of the result"""
+    import ctypes as C
+
+    err = C.c_double()
+    ctx.check(ctx._L.dvs_selftest_log2_acc(ctx._h, C.byref(err)))
+    print("max rel |log2_acc - log2|:", err.value)
+    assert 0.0 <= err.value < 1e-15, err.value
