@@ -67,7 +67,7 @@ def main():
     torch.cuda.synchronize()
 
     stats = {"rows_scored": 0, "scan_ms": 0.0, "scan_launches": 0, "n_accepts": 0,
-             "n_windows": 0, "n_arbitrated": 0, "hist_ms": 0.0}
+             "n_windows": 0, "n_arbitrated": 0, "hist_ms": 0.0, "engine": 0}
 
     def step(collect: bool):
         t0 = time.perf_counter()
@@ -83,6 +83,7 @@ def main():
                         "n_arbitrated"):
                 stats[key] += getattr(s, key)
             stats["hist_ms"] += (t1 - t0) * 1e3
+            stats["engine"] = s.engine
         sel.close()
         m.close()
 
@@ -140,7 +141,9 @@ def main():
                 "tie_arbitrations": stats["n_arbitrated"],
             },
             "roofline": {
-                "kernel": "scan_kernel<uint32>",
+                "kernel": ("persist_nmost_kernel<uint32> (one launch per selection: windowed delta-JSD scan + "
+                           "in-kernel set updates behind grid barriers)") if stats["engine"] == 1
+                          else "scan_kernel<uint32> (one launch per window)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": peak,
@@ -151,6 +154,17 @@ def main():
                 "avg_launch_us": stats["scan_ms"] * 1e3 / max(1, stats["scan_launches"]),
             },
         }
+        # HBM traffic of the dominant kernel: measured separately with rocprofv3 PMC passes
+        # (bench.py cannot run under the profiler and time itself); committed in profiles/
+        try:
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                              "pmc_traffic.json")))
+            if (pmc.get("workload") == f"nmost n={a.n}, {a.nseq} x {a.length} bp, k={a.k}"
+                    and stats["engine"] == 1):
+                out["roofline"]["traffic"] = pmc["persist_nmost_kernel"]["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, KiB -> B)"
+        except (OSError, KeyError, ValueError):
+            pass
         if world == 1 and not a.no_cpu_baseline:
             import oracle
 

@@ -46,7 +46,8 @@ class SelectSummary(C.Structure):
                 ("rows_scored", C.c_uint64), ("rows_rechecked", C.c_uint64),
                 ("n_windows", C.c_uint32), ("n_events", C.c_uint32),
                 ("n_accepts", C.c_uint32), ("n_arbitrated", C.c_uint32),
-                ("scan_ms", C.c_double), ("scan_launches", C.c_uint64)]
+                ("scan_ms", C.c_double), ("scan_launches", C.c_uint64),
+                ("engine", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class DvsLibraryMissing(RuntimeError):

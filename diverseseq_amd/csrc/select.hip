@@ -1066,6 +1066,7 @@ extern "C" int dvs_select_get_summary(dvs_ctx *ctx, const dvs_select *s, dvs_sel
     out->n_arbitrated = s->n_arbitrated;
     out->scan_ms = s->scan_ms;
     out->scan_launches = s->scan_launches;
+    out->engine = s->persist ? 1u : 0u;
     return DVS_OK;
 }
 

@@ -132,6 +132,8 @@ typedef struct dvs_select_summary {
     uint32_t n_windows, n_events, n_accepts, n_arbitrated;
     double scan_ms;          /* sum of scan-kernel durations (HIP events) when timing is on, else 0 */
     uint64_t scan_launches;  /* scan-kernel launches the events bracket (no-op launches included) */
+    uint32_t engine;         /* 0: one scan launch per window + state kernels; 1: persistent single launch */
+    uint32_t reserved;
 } dvs_select_summary;
 
 int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t *order,
