@@ -161,8 +161,9 @@ static int matrix_alloc(dvs_ctx *ctx, dvs_matrix *m) {
     const size_t cells = size_t(m->nrows) * m->nbins;
     const size_t bytes = cells * (m->kind == 0 ? 4 : 8);
     size_t free_b = 0, total_b = 0;
-    DVS_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
-    if (bytes + size_t(m->nrows) * 12 + (64u << 20) > free_b + ctx->pool_bytes)
+    const bool cached = ctx->pool.count(((bytes ? bytes : 4) + 4095) & ~size_t(4095)) > 0;
+    if (!cached) DVS_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+    if (!cached && bytes + size_t(m->nrows) * 12 + (64u << 20) > free_b + ctx->pool_bytes)
         return dvs_set_error(ctx, DVS_ERR_NOMEM,
                              "%u x %llu matrix needs %zu bytes of HBM, %zu free", m->nrows,
                              (unsigned long long)m->nbins, bytes, free_b);

@@ -892,23 +892,34 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     if (params->mode != DVS_MODE_MAX) max_size = n_seed;
 
     // usable seeds: rows with at least one valid k-mer (records.rs:299-306)
-    std::vector<uint32_t> h_totals(m->nrows);
-    DVS_HIP(ctx, hipMemcpyAsync(h_totals.data(), m->d_totals, size_t(m->nrows) * 4,
-                                hipMemcpyDeviceToHost, ctx->stream));
-    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     uint32_t nlabels = 0;
-    for (uint64_t p = 0; p < npos; p++) {
-        const uint32_t row = order ? order[p] : uint32_t(p);
-        if (row >= m->nrows)
-            return dvs_set_error(ctx, DVS_ERR_VALUE, "order[%llu] = %u out of range",
-                                 (unsigned long long)p, row);
-        const uint32_t lab = labels ? labels[p] : row;
-        if (lab != 0xFFFFFFFFu) nlabels = std::max(nlabels, lab + 1);
+    if (order || labels) {
+        for (uint64_t p = 0; p < npos; p++) {
+            const uint32_t row = order ? order[p] : uint32_t(p);
+            if (row >= m->nrows)
+                return dvs_set_error(ctx, DVS_ERR_VALUE, "order[%llu] = %u out of range",
+                                     (unsigned long long)p, row);
+            const uint32_t lab = labels ? labels[p] : row;
+            if (lab != 0xFFFFFFFFu) nlabels = std::max(nlabels, lab + 1);
+        }
+    } else {
+        nlabels = uint32_t(npos);  // label = row = position
     }
+    // only the seed rows' totals are needed on the host
     std::vector<uint64_t> seeds;
-    for (uint64_t p = 0; p < n_seed; p++) {
-        const uint32_t row = order ? order[p] : uint32_t(p);
-        if (h_totals[row] > 0) seeds.push_back(p);
+    {
+        std::vector<uint32_t> h_tot(n_seed);
+        if (!order && n_seed) {
+            DVS_HIP(ctx, hipMemcpyAsync(h_tot.data(), m->d_totals, size_t(n_seed) * 4,
+                                        hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            for (uint64_t p = 0; p < n_seed; p++)
+                DVS_HIP(ctx, hipMemcpyAsync(&h_tot[p], m->d_totals + order[p], 4, hipMemcpyDeviceToHost,
+                                            ctx->stream));
+        }
+        DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint64_t p = 0; p < n_seed; p++)
+            if (h_tot[p] > 0) seeds.push_back(p);
     }
     if (seeds.empty()) return dvs_set_error(ctx, DVS_ERR_VALUE, "records cannot be empty");  // :28-30
     if (seeds.size() < 2) return dvs_set_error(ctx, DVS_ERR_VALUE, "must have > 1 KmerSeq");  // :227-230
@@ -932,8 +943,8 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     s->cap = cap;
     const size_t need = size_t(cap) * B * 8 + 5 * B * 8 + size_t(npos) * 8 + nlabels + (1 << 20);
     size_t free_b = 0, total_b = 0;
-    DVS_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
-    if (need > free_b + ctx->pool_bytes) {
+    if (need > (size_t(1) << 30)) DVS_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+    if (need > (size_t(1) << 30) && need > free_b + ctx->pool_bytes) {
         delete s;
         return dvs_set_error(ctx, DVS_ERR_NOMEM, "selection state needs %zu bytes, %zu free", need,
                              free_b);

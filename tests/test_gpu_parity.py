@@ -529,3 +529,34 @@ def test_log2_acc_error_bound(ctx):
     ctx.check(ctx._L.dvs_selftest_log2_acc(ctx._h, C.byref(err)))
     print("max rel |log2_acc - log2|:", err.value)
     assert 0.0 <= err.value < 1e-15, err.value
+
+
+# ------------------------------------------------ genome-scale rows (configs C3 / C5, scaled down)
+def test_genome_length_sequences_max_and_sketch(ctx):
+    """C3 / C5 shapes at reduced N: ~3 Mb sequences (92 tiles each), `max` min_size 5 and
+    k=12 / s=3000 sketches, all against the oracle"""
+    from diverseseq_amd import distance
+
+    rng = np.random.default_rng(31)
+    seqs = []
+    for i in range(16):
+        p = rng.dirichlet(np.ones(4) * 5.0)
+        s = rng.choice(4, size=int(rng.integers(2_500_000, 3_500_000)), p=p).astype(np.uint8)
+        s[rng.integers(0, s.size, size=300)] = 4
+        seqs.append(s)
+    m = ctx.build_matrix(seqs, 6, 4)
+    exp_counts = np.stack([oracle.count_kmers(s, 4, 6) for s in seqs[:3]])
+    assert (m.counts(0, 3).astype(np.uint64) == exp_counts).all()
+    _assert_selection(m.max_divergent(5, 16, "stdev"), oracle.max_divergent(seqs, 5, 16, 6, 4, "stdev"))
+    _assert_selection(m.nmost(4), oracle.nmost(seqs, 4, 6, 4))
+    sk, lens = distance.sketch_batch(seqs[:4], 12, 3000, 4, True)
+    for i in range(4):
+        assert (sk[i, : lens[i]] == oracle.mash_sketch(seqs[i], 12, 3000, 4, True)).all()
+
+
+def test_config_c4_k7(ctx):
+    """C4's bin count (k=7, 16384 bins: 64 KB LDS histogram, 128 KB state vector) at 3000 rows"""
+    seqs = synth_seqs(3000, 5000, 44, invalid_frac=0.0005)
+    m = ctx.build_matrix(seqs, 7, 4)
+    assert (m.counts(17, 2).astype(np.uint64) == _oracle_counts(seqs[17:19], 4, 7)).all()
+    _assert_selection(m.nmost(25), oracle.nmost(seqs, 25, 7, 4))
