@@ -32,6 +32,10 @@ def parse():
     ap.add_argument("-k", type=int, default=6)
     ap.add_argument("-n", type=int, default=10, help="size of the divergent set")
     ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--mode", choices=("chunk", "exact"), default="chunk",
+                    help="multi-GPU scheme: 'chunk' = the reference's -np G (independent greedy per GPU + "
+                         "one all_gather + final_nmost); 'exact' = rows sharded block-cyclically, set state "
+                         "replicated, one MIN + one SUM all-reduce per greedy step (same answer as 1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000,
                     help="sequences of the same workload the 1-thread CPU oracle is timed on")
@@ -55,15 +59,35 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from diverseseq_amd import engine
-    from diverseseq_amd.parallel import merge_nmost
+    from diverseseq_amd.parallel import merge_nmost, nmost_exact, shard_order
 
-    ctx = engine.Context(local)
+    exact = a.mode == "exact"
+    stream = torch.cuda.Stream() if exact else None
+    if exact:  # kernels and collectives ordered on one torch stream
+        torch.cuda.set_stream(stream)
+        ctx = engine.Context(local, stream=stream.cuda_stream)
+    else:
+        ctx = engine.Context(local)
     B = 4 ** a.k
     # synthetic input, generated in HBM: i.i.d. uniform symbols, 1 byte per base
     g = torch.Generator(device=dev)
-    g.manual_seed(20260421 + rank)
-    seqs = torch.randint(0, 4, (a.nseq * a.length,), dtype=torch.uint8, device=dev, generator=g)
-    offsets = np.arange(a.nseq + 1, dtype=np.uint64) * np.uint64(a.length)
+    order = None
+    if exact:
+        # global stream of world * nseq positions; the n seeds are replicated, the rest owned
+        # block-cyclically: this rank's matrix = [seeds, owned rows]
+        npos = a.nseq * world
+        owned, order = shard_order(npos, a.n, rank, world)
+        nlocal = a.n + owned.size
+        g.manual_seed(20260421)  # the same seed rows on every rank
+        seed_part = torch.randint(0, 4, (a.n * a.length,), dtype=torch.uint8, device=dev, generator=g)
+        g.manual_seed(20260422 + rank)
+        rest = torch.randint(0, 4, (owned.size * a.length,), dtype=torch.uint8, device=dev, generator=g)
+        seqs = torch.cat([seed_part, rest])
+        offsets = np.arange(nlocal + 1, dtype=np.uint64) * np.uint64(a.length)
+    else:
+        g.manual_seed(20260421 + rank)
+        seqs = torch.randint(0, 4, (a.nseq * a.length,), dtype=torch.uint8, device=dev, generator=g)
+        offsets = np.arange(a.nseq + 1, dtype=np.uint64) * np.uint64(a.length)
     torch.cuda.synchronize()
 
     stats = {"rows_scored": 0, "scan_ms": 0.0, "scan_launches": 0, "n_accepts": 0,
@@ -73,8 +97,11 @@ def main():
         t0 = time.perf_counter()
         m = ctx.build_matrix_device(seqs.data_ptr(), offsets, a.k, 4)
         t1 = time.perf_counter()
-        sel = m.nmost(a.n, window=a.window)
-        if world > 1:
+        if exact:
+            sel = nmost_exact(ctx, m, order, a.n, dev, world, window=a.window)
+        else:
+            sel = m.nmost(a.n, window=a.window)
+        if world > 1 and not exact:
             merged = merge_nmost(ctx, sel, a.n, rank, world, rank * a.nseq, dev)
             merged.close()
         if collect:
@@ -131,8 +158,11 @@ def main():
                              f"{a.nseq} x {a.length} bp synthetic DNA per GPU, k={a.k} ({B} bins), "
                              "inputs resident in HBM (north-star shape)"),
                 "nseq_per_gpu": a.nseq, "length": a.length, "k": a.k, "n": a.n,
-                "parallelism": (f"{world} shards, independent greedy per GPU + one RCCL all_gather "
-                                "+ final_nmost merge (reference -np semantics)") if world > 1 else "single GPU",
+                "parallelism": ("single GPU" if world == 1 and not exact else
+                                (f"{world} ranks, rows sharded block-cyclically, replicated set state, one MIN + one "
+                                 "SUM RCCL all-reduce per greedy step (same answer as 1 GPU)") if exact else
+                                (f"{world} shards, independent greedy per GPU + one RCCL all_gather "
+                                 "+ final_nmost merge (reference -np semantics)")),
                 "accepts_per_step": stats["n_accepts"] / a.steps,
                 "scan_launches_per_step": stats["scan_launches"] / a.steps,
                 "rows_scored_per_step": stats["rows_scored"] / a.steps,

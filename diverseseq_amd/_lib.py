@@ -20,6 +20,8 @@ OK, ERR_VALUE, ERR_RUNTIME, ERR_NOMEM, ERR_UNSUPPORTED, ERR_ZERODIV = range(6)
 MODE_NMOST, MODE_MAX, MODE_SET = 0, 1, 2
 STAT_STDEV, STAT_COV = 0, 1
 SELECT_NO_ARBITER = 1
+SELECT_STEPWISE = 2
+ROW_REMOTE = 0xFFFFFFFF
 
 # every symbol include/dvs_hip.h declares (tests/test_boundary.py checks the .so exports them)
 EXPORTS = (
@@ -29,7 +31,8 @@ EXPORTS = (
     "dvs_matrix_dev_totals", "dvs_matrix_dev_entropy", "dvs_matrix_get_counts",
     "dvs_matrix_get_totals", "dvs_matrix_get_entropy", "dvs_kmer_counts", "dvs_select_run",
     "dvs_select_destroy", "dvs_select_get_summary", "dvs_select_get_members",
-    "dvs_select_delta_jsd", "dvs_selftest_fast_log2", "dvs_selftest_log2_acc", "dvs_mash_sketch", "dvs_mash_distances", "dvs_euclidean_distances",
+    "dvs_select_delta_jsd", "dvs_select_step_scan", "dvs_select_step_fetch",
+    "dvs_select_step_apply", "dvs_select_step_poll", "dvs_selftest_fast_log2", "dvs_selftest_log2_acc", "dvs_mash_sketch", "dvs_mash_distances", "dvs_euclidean_distances",
 )
 
 
@@ -134,6 +137,10 @@ def load() -> C.CDLL:
         L.dvs_select_get_summary.argtypes = [vp, vp, C.POINTER(SelectSummary)]
         L.dvs_select_get_members.argtypes = [vp, vp, u64p, u32p, f64p, f64p, f64p]
         L.dvs_select_delta_jsd.argtypes = [vp, vp, vp, u32p, f64p]
+        L.dvs_select_step_scan.argtypes = [vp, vp, vp]
+        L.dvs_select_step_fetch.argtypes = [vp, vp, vp, vp]
+        L.dvs_select_step_apply.argtypes = [vp, vp, vp]
+        L.dvs_select_step_poll.argtypes = [vp, vp, u32p, u64p]
         L.dvs_selftest_fast_log2.argtypes = [vp, f64p]
         L.dvs_selftest_log2_acc.argtypes = [vp, f64p]
         L.dvs_mash_sketch.argtypes = [vp, vp, C.c_int, u64p, C.c_uint32, C.c_uint32, C.c_uint32,

@@ -60,6 +60,9 @@ struct SelDev {
     uint32_t *wg_rows = nullptr;         // rows actually read by each scan workgroup (last launch)
     unsigned long long *evlog_pos = nullptr;  // accepted events in order: stream position ...
     uint32_t *evlog_kind = nullptr;           // ... and kind (1 replace_lowest, 2 kept push)
+    // stepwise / distributed use: the candidate of the pending event as delivered by the
+    // exchange step (B frequencies + entropy), instead of a row of the local matrix
+    const double *cand_ext = nullptr;
 };
 
 struct dvs_select {

@@ -106,6 +106,7 @@ __device__ __forceinline__ void scan_rows_general(SelCtl *ctl, const T *__restri
         const uint64_t p = st.cursor + r;
         if (__hip_atomic_load(&ctl->event_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p) break;
         const uint32_t row = order ? order[p] : uint32_t(p);
+        if (row == DVS_ROW_REMOTE) continue;  // another rank scores this position
         const uint32_t tot = totals[row];
         if (tot == 0) continue;
         if (labels) {  // ids can only repeat when the caller passed labels (records.rs:87-89)
@@ -286,11 +287,19 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, uint32_t scan
         return;
     }
     const uint32_t row = d.order ? d.order[p] : uint32_t(p);
-    const uint32_t lab = d.labels ? d.labels[p] : row;
-    const double tot = double(d.totals[row]);
-    const double cand_H = d.rowH[row];
-    const T *rp = mat + uint64_t(row) * d.B;
-    for (uint64_t i = tid; i < d.B; i += WIDE) d.cand[i] = cand_freq(rp, i, tot);
+    uint32_t lab;
+    double cand_H;
+    if (d.cand_ext) {  // exchanged candidate (its row may live on another rank)
+        lab = (row == DVS_ROW_REMOTE) ? DVS_ROW_REMOTE : (d.labels ? d.labels[p] : row);
+        cand_H = d.cand_ext[d.B];
+        for (uint64_t i = tid; i < d.B; i += WIDE) d.cand[i] = d.cand_ext[i];
+    } else {
+        lab = d.labels ? d.labels[p] : row;
+        const double tot = double(d.totals[row]);
+        cand_H = d.rowH[row];
+        const T *rp = mat + uint64_t(row) * d.B;
+        for (uint64_t i = tid; i < d.B; i += WIDE) d.cand[i] = cand_freq(rp, i, tot);
+    }
     __syncthreads();
     double sm;
     const double jsd = block_delta_jsd(d, ctl, cand_H, scratch, &sm);
@@ -732,6 +741,36 @@ __global__ __launch_bounds__(LOO_THREADS) void score_kernel(SelDev d, const T *_
     }
 }
 
+// ---- stepwise (distributed) helpers: the event word as int64 for a MIN all-reduce and the
+// candidate row for a SUM all-reduce (the owner contributes the row, everyone else zeros)
+__global__ void export_event_kernel(const SelCtl *ctl, long long *dst) {
+    const unsigned long long v = ctl->event_pos;
+    *dst = (v == SEL_NONE) ? 0x7FFFFFFFFFFFFFFFll : (long long)v;
+}
+__global__ void import_event_kernel(SelCtl *ctl, const long long *src) {
+    const long long v = *src;
+    ctl->event_pos = (v == 0x7FFFFFFFFFFFFFFFll) ? SEL_NONE : (unsigned long long)v;
+}
+template <typename T>
+__global__ __launch_bounds__(LOO_THREADS) void fetch_candidate_kernel(SelDev d, const T *__restrict__ mat,
+                                                                     double *__restrict__ out) {
+    const SelCtl *ctl = d.ctl;
+    const unsigned long long p = ctl->event_pos;
+    uint32_t row = DVS_ROW_REMOTE;
+    if (ctl->status == SEL_RUN && p != SEL_NONE) row = d.order ? d.order[p] : uint32_t(p);
+    if (row == DVS_ROW_REMOTE) {
+        for (uint64_t i = threadIdx.x; i < d.B + 2; i += LOO_THREADS) out[i] = 0.0;
+        return;
+    }
+    const double tot = double(d.totals[row]);
+    const T *rp = mat + uint64_t(row) * d.B;
+    for (uint64_t i = threadIdx.x; i < d.B; i += LOO_THREADS) out[i] = cand_freq(rp, i, tot);
+    if (threadIdx.x == 0) {
+        out[d.B] = d.rowH[row];
+        out[d.B + 1] = 1.0;  // exactly one rank owns the position
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ host side
@@ -868,6 +907,7 @@ static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat, const std::vecto
     DVS_HIP(ctx, hipGetLastError());
     DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     dvs_dev_free(ctx, d_seed);
+    if (s->params.flags & DVS_SELECT_STEPWISE) return sel_poll(ctx, s);
     return sel_run_loop<T>(ctx, s, mat);
 }
 
@@ -896,6 +936,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     if (order || labels) {
         for (uint64_t p = 0; p < npos; p++) {
             const uint32_t row = order ? order[p] : uint32_t(p);
+            if (row == DVS_ROW_REMOTE) continue;
             if (row >= m->nrows)
                 return dvs_set_error(ctx, DVS_ERR_VALUE, "order[%llu] = %u out of range",
                                      (unsigned long long)p, row);
@@ -906,6 +947,12 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
         nlabels = uint32_t(npos);  // label = row = position
     }
     // only the seed rows' totals are needed on the host
+    if (order)
+        for (uint64_t p = 0; p < n_seed; p++)
+            if (order[p] == DVS_ROW_REMOTE)
+                return dvs_set_error(ctx, DVS_ERR_VALUE,
+                                     "seed position %llu is not local: the first n rows must be replicated",
+                                     (unsigned long long)p);
     std::vector<uint64_t> seeds;
     {
         std::vector<uint32_t> h_tot(n_seed);
@@ -929,6 +976,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     s->params = *params;
     s->params.n_seed = n_seed;
     s->params.max_size = max_size;
+    if (s->params.flags & DVS_SELECT_STEPWISE) s->params.flags |= DVS_SELECT_NO_ARBITER;
     s->mat = m;
     s->mat_kind = m->kind;
     s->npos = npos;
@@ -1183,5 +1231,65 @@ extern "C" int dvs_selftest_fast_log2(dvs_ctx *ctx, double *max_abs_err) {
     DVS_HIP(ctx, hipMemcpyAsync(max_abs_err, d, 8, hipMemcpyDeviceToHost, ctx->stream));
     DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     (void)hipFree(d);
+    return DVS_OK;
+}
+
+// ---- stepwise driving (one process per GPU; the collectives between the steps are the
+// host framework's: an int64 MIN all-reduce of the event word, a SUM all-reduce of the row)
+template <typename T>
+static int step_scan(dvs_ctx *ctx, dvs_select *s, const T *mat) {
+    const SelDev &d = s->dev;
+    hipLaunchKernelGGL((scan_kernel<T, false>), dim3(s->scan_grid), dim3(SCAN_THREADS), s->scan_lds,
+                       ctx->stream, d.ctl, mat, d.totals, d.rowH, d.order, d.labels, d.inset, d.nlabels,
+                       d.base, d.wg_rows, d.B, s->base_in_lds ? 1 : 0);
+    DVS_HIP(ctx, hipGetLastError());
+    return DVS_OK;
+}
+
+extern "C" int dvs_select_step_scan(dvs_ctx *ctx, dvs_select *s, void *d_event_i64) {
+    if (!ctx || !s || !d_event_i64) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    int rc = s->mat_kind == 0 ? step_scan<uint32_t>(ctx, s, s->mat->d_counts)
+                              : step_scan<double>(ctx, s, s->mat->d_freqs);
+    if (rc) return rc;
+    hipLaunchKernelGGL(export_event_kernel, dim3(1), dim3(1), 0, ctx->stream, s->dev.ctl,
+                       static_cast<long long *>(d_event_i64));
+    DVS_HIP(ctx, hipGetLastError());
+    return DVS_OK;
+}
+
+extern "C" int dvs_select_step_fetch(dvs_ctx *ctx, dvs_select *s, const void *d_event_i64, double *d_row) {
+    if (!ctx || !s || !d_event_i64 || !d_row) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    hipLaunchKernelGGL(import_event_kernel, dim3(1), dim3(1), 0, ctx->stream, s->dev.ctl,
+                       static_cast<const long long *>(d_event_i64));
+    if (s->mat_kind == 0)
+        hipLaunchKernelGGL((fetch_candidate_kernel<uint32_t>), dim3(1), dim3(LOO_THREADS), 0, ctx->stream,
+                           s->dev, s->mat->d_counts, d_row);
+    else
+        hipLaunchKernelGGL((fetch_candidate_kernel<double>), dim3(1), dim3(LOO_THREADS), 0, ctx->stream,
+                           s->dev, s->mat->d_freqs, d_row);
+    DVS_HIP(ctx, hipGetLastError());
+    return DVS_OK;
+}
+
+extern "C" int dvs_select_step_apply(dvs_ctx *ctx, dvs_select *s, const double *d_row) {
+    if (!ctx || !s || !d_row) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    s->dev.cand_ext = d_row;
+    if (s->mat_kind == 0) launch_iteration<uint32_t>(ctx, s, s->mat->d_counts, 1);
+    else launch_iteration<double>(ctx, s, s->mat->d_freqs, 1);
+    DVS_HIP(ctx, hipGetLastError());
+    return DVS_OK;
+}
+
+extern "C" int dvs_select_step_poll(dvs_ctx *ctx, dvs_select *s, uint32_t *status, uint64_t *cursor) {
+    if (!ctx || !s) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    int rc = sel_poll(ctx, s);
+    if (rc) return rc;
+    if (status) *status = s->h_ctl->status;
+    if (cursor) *cursor = s->h_ctl->cursor;
+    if (s->h_ctl->status == SEL_ARBITER)
+        return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED,
+                             "ambiguous decision at stream position %llu: the stepwise (distributed) "
+                             "mode has no tie arbitration",
+                             (unsigned long long)s->h_ctl->arb_pos);
     return DVS_OK;
 }

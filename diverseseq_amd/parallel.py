@@ -82,3 +82,62 @@ def merge_max(ctx, sel, min_size: int, max_size: int, stat: str, chunk_start: in
     merged.global_ids = gids
     merged._keep = m
     return merged
+
+
+# ---------------------------------------------------------------------------------------
+# Exact multi-GPU selection (same answer as one GPU / the reference's `-np 1`): rows are
+# sharded block-cyclically by global candidate order, the set state is replicated, and each
+# greedy step costs two small collectives:
+#   MIN all-reduce of the first event position, SUM all-reduce of that candidate's 4^k
+#   frequency row (the owner contributes the row, everyone else zeros).
+ROW_REMOTE = 0xFFFFFFFF
+
+
+def shard_order(npos: int, n_seed: int, rank: int, world: int, block: int = 256):
+    """Block-cyclic ownership of stream positions >= n_seed; positions < n_seed (the seeds) are
+    replicated on every rank.  Returns (owned positions ascending, order[npos] uint32) where
+    order[p] is the row in THIS rank's matrix (seeds first, then the owned rows) or ROW_REMOTE."""
+    pos = np.arange(n_seed, npos, dtype=np.int64)
+    mine = ((pos - n_seed) // block) % world == rank
+    owned = pos[mine]
+    order = np.full(npos, ROW_REMOTE, dtype=np.uint32)
+    order[:n_seed] = np.arange(n_seed, dtype=np.uint32)
+    order[owned] = n_seed + np.arange(owned.size, dtype=np.uint32)
+    return owned, order
+
+
+def nmost_exact(ctx, matrix, order: np.ndarray, n: int, device, world: int, *, window: int = 0,
+                poll_every: int = 8):
+    """Greedy nmost over a row-sharded stream.  `ctx` must have been created on the torch stream
+    that is current here (Context(device, stream=torch.cuda.current_stream().cuda_stream)), so the
+    library's kernels and the collectives are ordered on one stream with no host syncs in between.
+    Returns the Selection; its member positions are global stream positions."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+
+    from . import _lib
+
+    L = ctx._L
+    B = matrix.nbins
+    ev = torch.full((1,), 2**63 - 1, dtype=torch.int64, device=device)
+    row = torch.zeros(B + 2, dtype=torch.float64, device=device)
+    sel = matrix.select(_lib.MODE_NMOST, n, order=order, window=window or 4096 * world,
+                        flags=_lib.SELECT_STEPWISE)
+    status, cursor = C.c_uint32(), C.c_uint64()
+    while True:
+        ctx.check(L.dvs_select_step_poll(ctx._h, sel._h, C.byref(status), C.byref(cursor)))
+        if status.value == 1:
+            return sel
+        if status.value != 0:
+            raise RuntimeError(f"selection engine in state {status.value}")
+        for _ in range(poll_every):
+            ctx.check(L.dvs_select_step_scan(ctx._h, sel._h, C.c_void_p(ev.data_ptr())))
+            if world > 1:
+                dist.all_reduce(ev, op=dist.ReduceOp.MIN)
+            ctx.check(L.dvs_select_step_fetch(ctx._h, sel._h, C.c_void_p(ev.data_ptr()),
+                                              C.c_void_p(row.data_ptr())))
+            if world > 1:
+                dist.all_reduce(row, op=dist.ReduceOp.SUM)
+            ctx.check(L.dvs_select_step_apply(ctx._h, sel._h, C.c_void_p(row.data_ptr())))

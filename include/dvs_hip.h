@@ -121,6 +121,9 @@ typedef struct dvs_select_params {
     uint32_t flags;    /* DVS_SELECT_* */
 } dvs_select_params;
 #define DVS_SELECT_NO_ARBITER 1u /* fail with DVS_ERR_UNSUPPORTED instead of host tie arbitration */
+#define DVS_SELECT_STEPWISE 2u   /* dvs_select_run builds the initial set and returns; the caller drives
+                                    dvs_select_step_* (row-sharded multi-GPU runs, see below) */
+#define DVS_ROW_REMOTE 0xFFFFFFFFu /* order[p]: the row of stream position p lives on another rank */
 
 typedef struct dvs_select_summary {
     uint32_t size;
@@ -152,6 +155,24 @@ int dvs_select_get_members(dvs_ctx *ctx, const dvs_select *s, uint64_t *position
  * without valid k-mers (the python layer raises, src/records_py.rs:111-120). */
 int dvs_select_delta_jsd(dvs_ctx *ctx, const dvs_select *s, const dvs_matrix *queries,
                          const uint32_t *qlabels, double *out);
+/* ---- stepwise driving: rows sharded over ranks, set state replicated -------- *
+ * The exact multi-GPU form of select_nmost_divergent: every rank
+ * holds the rows of its share of the stream (order[p] = DVS_ROW_REMOTE for the
+ * others; the first n_seed rows replicated everywhere) and an identical copy of
+ * the set.  Per greedy step, all enqueued on the ctx stream with no host sync:
+ *   dvs_select_step_scan   scan this rank's rows of the current window; the first
+ *                          local event position goes to *d_event_i64 (INT64_MAX: none)
+ *   [host framework: MIN all-reduce of d_event_i64 -- RCCL]
+ *   dvs_select_step_fetch  the owner of that position writes its frequency row,
+ *                          entropy and a 1.0 marker to d_row[nbins + 2], others zeros
+ *   [host framework: SUM all-reduce of d_row -- the row reaches every rank]
+ *   dvs_select_step_apply  resolve + leave-one-out + finalize with that candidate
+ * dvs_select_step_poll syncs and returns the status (0 running, 1 done) / cursor. */
+int dvs_select_step_scan(dvs_ctx *ctx, dvs_select *s, void *d_event_i64);
+int dvs_select_step_fetch(dvs_ctx *ctx, dvs_select *s, const void *d_event_i64, double *d_row);
+int dvs_select_step_apply(dvs_ctx *ctx, dvs_select *s, const double *d_row);
+int dvs_select_step_poll(dvs_ctx *ctx, dvs_select *s, uint32_t *status, uint64_t *cursor);
+
 /* when on, every scan launch is bracketed by a pair of HIP events recorded on the
  * ctx stream (no extra host sync); they are read once the selection has finished
  * and summed into dvs_select_summary.scan_ms / scan_launches */

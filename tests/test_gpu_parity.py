@@ -560,3 +560,65 @@ def test_config_c4_k7(ctx):
     m = ctx.build_matrix(seqs, 7, 4)
     assert (m.counts(17, 2).astype(np.uint64) == _oracle_counts(seqs[17:19], 4, 7)).all()
     _assert_selection(m.nmost(25), oracle.nmost(seqs, 25, 7, 4))
+
+
+# ------------------------------------------------------ exact row-sharded mode
+def _exact_worker(rank, world, port, q):
+    import os
+    import sys
+
+    sys.path.insert(0, str(__import__("conftest").ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+
+    from diverseseq_amd import engine, parallel
+
+    torch.cuda.set_device(0)  # both ranks share the one GPU of the test box; gloo moves the words
+    dev = torch.device("cuda", 0)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx = engine.Context(0, stream=stream.cuda_stream)
+        seqs = synth_seqs(1500, 600, 123, invalid_frac=0.001, ragged=True)
+        n, k = 12, 5
+        owned, order = parallel.shard_order(len(seqs), n, rank, world, block=32)
+        local = seqs[:n] + [seqs[int(p)] for p in owned]
+        m = ctx.build_matrix(local, k, 4)
+        sel = parallel.nmost_exact(ctx, m, order, n, dev, world, window=256 * world, poll_every=4)
+        mem = sel.members(with_freqs=False)
+        s = sel.summary()
+        q.put((rank, mem.positions.tolist(), mem.delta_jsd.tolist(), s.total_jsd))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_exact_row_sharded_mode(world):
+    """rows sharded over ranks + replicated set state + one MIN and one SUM all-reduce per greedy
+    step must give the single-process answer (ids bit-exact)"""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_exact_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seqs = synth_seqs(1500, 600, 123, invalid_frac=0.001, ragged=True)
+    exp = oracle.nmost(seqs, 12, 5, 4)
+    elab, edelta, _, _ = exp.members()
+    for rank, pos, delta, total in res:
+        assert pos == elab.tolist()
+        np.testing.assert_allclose(delta, edelta, rtol=RTOL, atol=1e-13)
+        np.testing.assert_allclose(total, exp.total_jsd, rtol=RTOL)
+    assert res[0][1:] == res[-1][1:]  # replicas are bit-identical
