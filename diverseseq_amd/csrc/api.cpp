@@ -66,6 +66,37 @@ void dvs_dev_free(dvs_ctx *ctx, void *ptr) {
     ctx->live.erase(it);
 }
 
+int dvs_pinned_get(dvs_ctx *ctx, void **ptr) {
+    if (!ctx->pinned_pool.empty()) {
+        *ptr = ctx->pinned_pool.back();
+        ctx->pinned_pool.pop_back();
+        return DVS_OK;
+    }
+    hipError_t e = hipHostMalloc(ptr, 4096, hipHostMallocDefault);
+    if (e != hipSuccess) return dvs_hip_fail(ctx, e, "hipHostMalloc");
+    return DVS_OK;
+}
+void dvs_pinned_put(dvs_ctx *ctx, void *ptr) {
+    if (!ptr) return;
+    if (ctx) ctx->pinned_pool.push_back(ptr);
+    else (void)hipHostFree(ptr);
+}
+hipEvent_t dvs_event_get(dvs_ctx *ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void dvs_event_put(dvs_ctx *ctx, hipEvent_t e) {
+    if (!e) return;
+    if (ctx) ctx->event_pool.push_back(e);
+    else (void)hipEventDestroy(e);
+}
+
 void dvs_dev_trim(dvs_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->pool) (void)hipFree(kv.second);
@@ -121,6 +152,8 @@ void dvs_ctx_destroy(dvs_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     dvs_dev_trim(ctx);
+    for (void *p : ctx->pinned_pool) (void)hipHostFree(p);
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -27,6 +27,8 @@ struct dvs_ctx {
     // destroy) performs no hipMalloc / hipFree.  Released for real in
     // dvs_ctx_destroy, dvs_ctx_trim or when an allocation fails.
     std::multimap<size_t, void *> pool;
+    std::vector<void *> pinned_pool;       // 4 KiB pinned host blocks (control-block mirrors)
+    std::vector<hipEvent_t> event_pool;    // recycled HIP events
     std::map<void *, size_t> live;
     size_t pool_bytes = 0;
 };
@@ -34,6 +36,10 @@ struct dvs_ctx {
 int dvs_dev_alloc(dvs_ctx *ctx, void **ptr, size_t bytes, const char *what);
 void dvs_dev_free(dvs_ctx *ctx, void *ptr);
 void dvs_dev_trim(dvs_ctx *ctx);
+int dvs_pinned_get(dvs_ctx *ctx, void **ptr);  // 4 KiB pinned block from the ctx cache
+void dvs_pinned_put(dvs_ctx *ctx, void *ptr);
+hipEvent_t dvs_event_get(dvs_ctx *ctx);
+void dvs_event_put(dvs_ctx *ctx, hipEvent_t e);
 
 int dvs_set_error(dvs_ctx *ctx, int code, const char *fmt, ...);
 int dvs_hip_fail(dvs_ctx *ctx, hipError_t e, const char *what);

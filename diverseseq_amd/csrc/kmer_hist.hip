@@ -258,9 +258,12 @@ __global__ __launch_bounds__(HIST_THREADS) void freq_entropy_kernel(
 
 template <typename K>
 int set_dyn_lds(dvs_ctx *ctx, K kernel, size_t bytes) {
-    if (bytes > 48 * 1024)
-        DVS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+    static std::map<const void *, size_t> set_lds;
+    const void *fn = reinterpret_cast<const void *>(kernel);
+    if (bytes > 48 * 1024 && set_lds[fn] < bytes) {
+        DVS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+        set_lds[fn] = bytes;
+    }
     return DVS_OK;
 }
 

@@ -44,6 +44,7 @@ constexpr int P_THREADS = 512;
 constexpr int P_J = 8;                      // bins per thread kept in registers (B <= 4096)
 constexpr int P_CH = 16;                    // row chunks requested per burst (4096 bins)
 constexpr uint32_t P_MAXN = 512;            // members the LDS replica holds
+constexpr uint32_t P_JOBS = P_MAXN + 1;     // leave-one-out jobs per event: (n + 1) * K <= max(G - 1, n + 1)
 constexpr uint32_t P_SPIN_LIMIT = 1u << 22;  // ~0.5 s of polling
 
 struct PSync {
@@ -60,7 +61,7 @@ struct PState {  // replicated scalars (identical in every workgroup)
     uint64_t cursor, npos;
     uint32_t window, wmin, wmax;
     uint32_t n, li;
-    double sumH, total_jsd, thr, band;
+    double sumH, total_jsd, thr, band, wscale;
     uint32_t n_windows, n_events, n_accepts;
 };
 
@@ -184,18 +185,24 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
     }
 }
 
-// LDS: [sl B f64][scratch 128 f64][s_mH P_MAXN f64][s_slot P_MAXN u32][flags]
+// LDS: [sl B f64][scratch 128 f64][s_mH P_MAXN f64][s_slot P_MAXN u32][s_dl, s_ds P_MAXN f64]
+//      [s_ph, s_ps, s_pm P_JOBS f64][flags]
 // CACHED: B <= P_J * 512, so a thread's share of the candidate row stays in registers
 template <typename T, bool CACHED>
 __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, const T *__restrict__ mat,
-                                                                    PSync *sync, uint32_t G) {
+                                                                    PSync *sync, double *part, uint32_t G) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint64_t B = d.B;
     double *sl = reinterpret_cast<double *>(smem);
     double *scratch = sl + ((B + 1) & ~1ull);
     double *s_mH = scratch + 128;
     uint32_t *s_slot = reinterpret_cast<uint32_t *>(s_mH + P_MAXN);
-    int *s_flag = reinterpret_cast<int *>(s_slot + P_MAXN);
+    double *s_dl = reinterpret_cast<double *>(s_slot + P_MAXN);  // delta_jsd per member
+    double *s_ds = s_dl + P_MAXN;                                 // sum of each member's mean vector
+    double *s_ph = s_ds + P_MAXN;                                 // job partials: h, sum, min
+    double *s_ps = s_ph + P_JOBS;
+    double *s_pm = s_ps + P_JOBS;
+    int *s_flag = reinterpret_cast<int *>(s_pm + P_JOBS);
     SelCtl *ctl = d.ctl;
     const int tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -216,6 +223,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     st.total_jsd = ctl->total_jsd;
     st.thr = ctl->thr;
     st.band = ctl->band;
+    st.wscale = ctl->wscale;
     st.n_windows = st.n_events = st.n_accepts = 0;
     if (ctl->status != SEL_RUN || ctl->ev_kind != 0 || st.n > P_MAXN || st.n < 2) return;
     for (uint32_t r = tid; r < st.n; r += P_THREADS) {
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         if (p == SEL_NONE) {
             st.cursor = end;
             if (end >= st.npos) { exit_status = SEL_DONE; break; }
-            st.window = sel_next_window(st.cursor, st.n, st.wmin, st.wmax);
+            st.window = sel_next_window(st.cursor, st.n, st.wmin, st.wmax, st.wscale);
             epoch++;
             continue;
         }
@@ -330,16 +338,9 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         }
         __syncthreads();
         st.sumH = scratch[127];
-        // One pass over the bins: S_new_i = clamp(S_i - low_i) + f_i feeds (a) the new set's
-        // total_jsd (every workgroup) and (b) the leave-one-out score of member r (workgroup r).
-        const double rdiv = 1.0 / (dn - 1.0);
-        bool ev_risky = false;
-        for (uint32_t r = blockIdx.x, pass = 0; pass == 0 || r < n; r += G, pass++) {
-            const bool has_member = r < n;
-            const bool is_new = r == n - 1;
-            const double *mrow = d.M + uint64_t(has_member ? s_slot[r] : 0) * B;
-            Ent e;
-            double h2 = 0.0, s2 = 0.0;
+        // S_new_i = clamp(S_i - low_i) + f_i.  The mirror block writes it, and the new member's
+        // row, to global memory (it takes no job below, so this overlaps the others' arithmetic).
+        if (lead) {
             for (uint64_t b0 = 0; b0 < B; b0 += uint64_t(P_J) * P_THREADS) {
 #pragma unroll
                 for (int j = 0; j < P_J; j++) {
@@ -348,40 +349,56 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                         double v = sl[i];
                         if (v <= DVS_EPS) v = 0.0;
                         const double f = CACHED ? fr[j] : cand_freq(rp, i, tot);
-                        const double sn = v + f;
-                        if (pass == 0) {
-                            e.add(sn * rn);
-                            if (lead) {
-                                d.S[i] = sn;
-                                d.M[uint64_t(slot_low) * B + i] = f;
-                            }
-                        }
-                        if (has_member) {
-                            double u = (sn - (is_new ? f : mrow[i])) * rdiv;  // updated_mean_freqs
-                            if (u <= DVS_EPS) u = 0.0;
-                            if (u > 0.0) h2 -= u * log2_acc(u);
-                            s2 += u;
-                        }
+                        d.S[i] = v + f;
+                        d.M[uint64_t(slot_low) * B + i] = f;
                     }
                 }
             }
-            double h = e.h, mn = e.mn, sm2 = e.sum;
-            block_red5(h, mn, sm2, h2, s2, scratch);
-            if (pass == 0) {
-                const double hm = (mn < 0.0) ? NAN : h;
-                st.total_jsd = hm - st.sumH / dn;
-                ev_risky = sum_risky(sm2, B) || !(hm == hm);
+        }
+        // ================= leave-one-out as (n + 1) * K jobs over the workgroups.
+        // Job (r, part): the entropy terms of bins [part * Bs, (part + 1) * Bs) of the mean
+        // vector without member r (r < n; updated_mean_freqs, records.rs:276-286) or of the
+        // whole new set (r == n; gives total_jsd).  K = (G - 1) / (n + 1) workgroups share one
+        // r, so the pass shrinks from 4^k bins per workgroup to 4^k / K; the K partial sums of
+        // each r are added in a fixed order after the barrier.
+        const double rdiv = 1.0 / (dn - 1.0);
+        const uint32_t K = (n + 1 < G) ? min((G - 1) / (n + 1), 32u) : 1u;
+        const uint32_t jobs = (n + 1) * K;
+        const uint64_t Bs = (B + K - 1) / K;
+        for (uint32_t job = blockIdx.x; job < jobs; job += G) {
+            if (lead && jobs <= G - 1) break;
+            const uint32_t r = job / K, part_i = job % K;
+            const uint64_t lo = uint64_t(part_i) * Bs, hi = umin64(B, lo + Bs);
+            const bool is_new = r == n - 1;
+            const double *mrow = d.M + uint64_t(r < n ? s_slot[r] : 0) * B;
+            double h = 0.0, sv = 0.0, mn = 0.0;
+            for (uint64_t i = lo + tid; i < hi; i += P_THREADS) {
+                double v = sl[i];
+                if (v <= DVS_EPS) v = 0.0;
+                const double f = cand_freq(rp, i, tot);
+                const double sn = v + f;
+                double u;
+                if (r == n) {
+                    u = sn * rn;
+                } else {
+                    u = (sn - (is_new ? f : mrow[i])) * rdiv;
+                    if (u <= DVS_EPS) u = 0.0;
+                }
+                if (u > 0.0) h -= u * log2_acc(u);
+                sv += u;
+                mn = fmin(mn, u);
             }
-            if (has_member && tid == 0) {
-                const double mean_entropy = (st.sumH - s_mH[r]) * rdiv;
-                d.dtmp[r] = st.total_jsd - (h2 - mean_entropy);
-                d.dsum[r] = s2;
+            block_red3(h, mn, sv, scratch);
+            if (tid == 0) {
+                double *pp = part + uint64_t(job) * 4;
+                pp[0] = h;
+                pp[1] = sv;
+                pp[2] = mn;
             }
         }
         st.cursor = p + 1;
         if (lead && tid == 0) {  // post-resolve mirror (what resolve_kernel leaves behind)
             ctl->sum_entropy = st.sumH;
-            ctl->total_jsd = st.total_jsd;
             if (old_lab < d.nlabels) d.inset[old_lab] = 0;
             if (uint32_t(p) < d.nlabels) d.inset[uint32_t(p)] = 1;
             for (uint32_t i = 0; i < n; i++) d.ord[i] = s_slot[i];
@@ -395,11 +412,50 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             ctl->event_pos = SEL_NONE;
             ctl->last_jsd = jsd;
             ctl->ev_n = n;
-            ctl->ev_risky = ev_risky ? 1 : 0;
         }
         P_STAMP(3);
         if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
         P_STAMP(4);
+        // ================= combine: one load per job (a single memory round trip), then the K
+        // partials of each r are added in job order by one thread -> same bits in every workgroup
+        for (uint32_t j = tid; j < jobs; j += P_THREADS) {
+            const double *pp = part + uint64_t(j) * 4;
+            s_ph[j] = pp[0];
+            s_ps[j] = pp[1];
+            s_pm[j] = pp[2];
+        }
+        __syncthreads();
+        for (uint32_t r = tid; r <= n; r += P_THREADS) {
+            double h = 0.0, sv = 0.0, mn = 0.0;
+            for (uint32_t q = 0; q < K; q++) {
+                h += s_ph[r * K + q];
+                sv += s_ps[r * K + q];
+                mn = fmin(mn, s_pm[r * K + q]);
+            }
+            if (r == n) {
+                scratch[110] = (mn < 0.0) ? NAN : h;
+                scratch[111] = sv;
+            } else {
+                s_dl[r] = h - (st.sumH - s_mH[r]) * rdiv;  // JSD of the set without member r
+                s_ds[r] = sv;
+            }
+        }
+        __syncthreads();
+        const double hm = scratch[110];
+        st.total_jsd = hm - st.sumH / dn;
+        const bool ev_risky = sum_risky(scratch[111], B) || !(hm == hm);
+        for (uint32_t r = tid; r < n; r += P_THREADS) s_dl[r] = st.total_jsd - s_dl[r];  // delta_jsd
+        __syncthreads();
+        if (lead) {
+            for (uint32_t r = tid; r < n; r += P_THREADS) {
+                d.dtmp[r] = s_dl[r];
+                d.dsum[r] = s_ds[r];
+            }
+            if (tid == 0) {
+                ctl->total_jsd = st.total_jsd;
+                ctl->ev_risky = ev_risky ? 1 : 0;
+            }
+        }
         // ================= finalize (every workgroup): argmin, strict '<' from 1e6
         uint32_t lowest;
         double dmin, dsecond, mean, sd;
@@ -407,8 +463,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         if (n <= 64) {  // one wave holds every score: shuffles only, one barrier to share
             if (wave == 0) {
                 const bool on = lane < n;
-                const double v = on ? d.dtmp[lane] : NAN;
-                const bool rk = on && sum_risky(d.dsum[lane], B);
+                const double v = on ? s_dl[lane] : NAN;
+                const bool rk = on && sum_risky(s_ds[lane], B);
                 const double vb = (on && v < 1e6) ? v : 1e6;
                 const double mnv = dvs_wave_min(vb);
                 const double fi = (mnv < 1e6 && on && v == mnv) ? double(lane) : 4294967295.0;
@@ -440,29 +496,29 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             bool risky = false;
             double best = 1e6;
             for (uint32_t r = tid; r < n; r += P_THREADS) {
-                const double v = d.dtmp[r];
-                if (sum_risky(d.dsum[r], B)) risky = true;
+                const double v = s_dl[r];
+                if (sum_risky(s_ds[r], B)) risky = true;
                 if (v < best) best = v;
             }
             dmin = dvs_block_min(best, scratch);
             double fi = 4294967295.0;
             for (uint32_t r = tid; r < n; r += P_THREADS)
-                if (dmin < 1e6 && d.dtmp[r] == dmin) fi = fmin(fi, double(r));
+                if (dmin < 1e6 && s_dl[r] == dmin) fi = fmin(fi, double(r));
             const double dfirst = dvs_block_min(fi, scratch);
             lowest = (dfirst < 4294967295.0) ? uint32_t(dfirst) : 0u;
             double second = 1e6;
             for (uint32_t r = tid; r < n; r += P_THREADS) {
-                const double v = d.dtmp[r];
+                const double v = s_dl[r];
                 if (r != lowest && v < second) second = v;
             }
             dsecond = dvs_block_min(second, scratch);
             any_risky = __syncthreads_or(risky ? 1 : 0);
             double acc = 0.0;
-            for (uint32_t r = tid; r < n; r += P_THREADS) acc += d.dtmp[r];
+            for (uint32_t r = tid; r < n; r += P_THREADS) acc += s_dl[r];
             mean = dvs_block_sum(acc, scratch) / dn;
             acc = 0.0;
             for (uint32_t r = tid; r < n; r += P_THREADS) {
-                const double t = d.dtmp[r] - mean;
+                const double t = s_dl[r] - mean;
                 acc += t * t;
             }
             sd = sqrt(dvs_block_sum(acc, scratch) / (dn - 1.0));
@@ -498,7 +554,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             }
         }
         if (lead) {
-            for (uint32_t r = tid; r < n; r += P_THREADS) d.mDelta[r] = d.dtmp[r];
+            for (uint32_t r = tid; r < n; r += P_THREADS) d.mDelta[r] = s_dl[r];
             if (tid == 0) {
                 ctl->lowest = lowest;
                 ctl->mean_delta = mean;
@@ -513,7 +569,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         __syncthreads();
         P_STAMP(5);
         if (st.cursor >= st.npos) { exit_status = SEL_DONE; break; }
-        st.window = sel_next_window(st.cursor, st.n, st.wmin, st.wmax);
+        st.window = sel_next_window(st.cursor, st.n, st.wmin, st.wmax, st.wscale);
         epoch++;
     }
 
@@ -552,9 +608,7 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->time_scan) {
         if (s->ev_used + 2 > s->ev_pool.size()) {
-            hipEvent_t a = nullptr, b = nullptr;
-            (void)hipEventCreate(&a);
-            (void)hipEventCreate(&b);
+            hipEvent_t a = dvs_event_get(ctx), b = dvs_event_get(ctx);
             s->ev_pool.push_back(a);
             s->ev_pool.push_back(b);
         }
@@ -566,11 +620,11 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     if (d.B <= uint64_t(P_J) * P_THREADS)
         hipLaunchKernelGGL((persist_nmost_kernel<T, true>), dim3(s->persist_grid), dim3(P_THREADS),
                            s->persist_lds, ctx->stream, d, mat, static_cast<PSync *>(s->psync),
-                           s->persist_grid);
+                           static_cast<double *>(s->ppart), s->persist_grid);
     else
         hipLaunchKernelGGL((persist_nmost_kernel<T, false>), dim3(s->persist_grid), dim3(P_THREADS),
                            s->persist_lds, ctx->stream, d, mat, static_cast<PSync *>(s->psync),
-                           s->persist_grid);
+                           static_cast<double *>(s->ppart), s->persist_grid);
     if (s->time_scan) (void)hipEventRecord(e1, ctx->stream);
     DVS_HIP(ctx, hipGetLastError());
     return DVS_OK;
@@ -582,7 +636,7 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     if (getenv("DVS_NO_PERSIST")) return DVS_OK;
     if (s->params.mode != DVS_MODE_NMOST || !s->h_order.empty() || !s->h_labels.empty()) return DVS_OK;
     if (s->cap > P_MAXN) return DVS_OK;
-    const size_t lds = ((B + 1) & ~1ull) * 8 + 128 * 8 + P_MAXN * 12 + 64;
+    const size_t lds = ((B + 1) & ~1ull) * 8 + 128 * 8 + P_MAXN * 28 + P_JOBS * 24 + 64;
     if (lds > ctx->lds_per_block || lds > 150 * 1024) return DVS_OK;
     s->persist_lds = lds;
     s->persist_grid = uint32_t(ctx->n_cu);  // one 512-thread workgroup per CU: all resident
@@ -593,9 +647,14 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
                       : reinterpret_cast<const void *>(persist_nmost_kernel<uint32_t, false>))
             : (cached ? reinterpret_cast<const void *>(persist_nmost_kernel<double, true>)
                       : reinterpret_cast<const void *>(persist_nmost_kernel<double, false>));
-    if (lds > 48 * 1024)
+    static std::map<const void *, size_t> set_lds;
+    if (lds > 48 * 1024 && set_lds[fn] < lds) {
         DVS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        set_lds[fn] = lds;
+    }
+    if (uint32_t(ctx->n_cu) > P_JOBS) return DVS_OK;  // jobs <= max(G - 1, n + 1) must fit the LDS arrays
     int rc = dvs_dev_alloc(ctx, &s->psync, sizeof(PSync), "persistent sync block");
+    if (!rc) rc = dvs_dev_alloc(ctx, &s->ppart, size_t(P_JOBS) * 4 * sizeof(double), "leave-one-out partials");
     if (rc) return rc;
     s->persist = true;
     return DVS_OK;

@@ -31,6 +31,7 @@ struct SelCtl {
     double mean_delta, std_delta, cov_delta;
     double t_total_jsd, t_sum_entropy;  // tentative (MODE_MAX push) values
     double last_jsd;
+    double wscale;  // next window = cursor * wscale / size (expected rows to the next accept ~ cursor / size)
 };
 
 // Device pointers of one selection (passed to kernels by value).
@@ -87,6 +88,7 @@ struct dvs_select {
     uint32_t persist_grid = 0;
     size_t persist_lds = 0;
     void *psync = nullptr;
+    void *ppart = nullptr;
     int batch = 16;
     // timing
     bool time_scan = false;

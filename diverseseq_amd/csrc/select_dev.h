@@ -198,14 +198,14 @@ __device__ __forceinline__ void block_red3(double &h, double &mn, double &sm, do
 // accept probability at stream position i is ~ size / i: widen the window as events
 // thin out (bounded by what one launch covers)
 __device__ __forceinline__ uint32_t sel_next_window(uint64_t cursor, uint32_t size, uint32_t wmin,
-                                                    uint32_t wmax) {
-    uint64_t w = cursor / (2ull * (size ? size : 1u));
+                                                    uint32_t wmax, double wscale) {
+    uint64_t w = uint64_t(double(cursor) * wscale / double(size ? size : 1u));
     if (w < wmin) w = wmin;
     if (w > wmax) w = wmax;
     return uint32_t(w);
 }
 __device__ __forceinline__ void ctl_next_window(SelCtl *ctl) {
-    ctl->window = sel_next_window(ctl->cursor, ctl->size, ctl->window_min, ctl->window_max);
+    ctl->window = sel_next_window(ctl->cursor, ctl->size, ctl->window_min, ctl->window_max, ctl->wscale);
 }
 
 // sum-to-one guard of entropy() (record.rs:99-104): the device cannot decide a

@@ -1,0 +1,44 @@
+"""ctree: the reference's own topology assertions (tests/test_ctree.py:9-20)."""
+import numpy as np
+import pytest
+
+import oracle
+from diverseseq_amd import cluster
+
+EXPECT = {
+    ("Human", "Chimpanzee", "Rhesus", "Horse"): "(((Human, Chimpanzee), Rhesus), Horse);",
+    ("Human", "Chimpanzee", "Manatee", "Dugong"): "((Human, Chimpanzee), (Manatee, Dugong));",
+    ("Human", "Chimpanzee", "Manatee", "Dugong", "Rhesus"): "(((Human, Chimpanzee), Rhesus), (Manatee, Dugong));",
+}
+
+
+@pytest.mark.parametrize("sketch_size", [400, 4_000_000_000])
+def test_make_cluster_tree_on_oracle_distances(brca1, sketch_size):
+    """host part only (no GPU): oracle sketches/distances -> same topologies as the reference expects"""
+    for names, newick in EXPECT.items():
+        sk = [oracle.mash_sketch(brca1[n], 16, sketch_size, 4, False) for n in names]
+        d = oracle.mash_distances(sk, 16, sketch_size)
+        got = cluster.make_cluster_tree(list(names), d)
+        assert cluster.clades(got) == cluster.clades(newick), (got, newick)
+
+
+def test_ctree_argument_checks():
+    seqs = {"a": np.zeros(30, np.uint8), "b": np.ones(30, np.uint8)}
+    with pytest.raises(ValueError):
+        cluster.ctree(seqs, distance_mode="mash", sketch_size=None)
+    with pytest.raises(ValueError):
+        cluster.ctree(seqs, distance_mode="euclidean", sketch_size=10)
+    with pytest.raises(ValueError):
+        cluster.ctree(seqs, distance_mode="euclidean", sketch_size=None, mash_canonical_kmers=True)
+    with pytest.raises(ValueError):
+        cluster.ctree(seqs, distance_mode="manhattan")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,kw", [("mash", dict(k=16, sketch_size=400)),
+                                     ("mash", dict(k=16, sketch_size=4_000_000_000)),
+                                     ("euclidean", dict(k=5, sketch_size=None))])
+def test_ctree_gpu(brca1, mode, kw):
+    for names, newick in EXPECT.items():
+        got = cluster.ctree({n: brca1[n] for n in names}, distance_mode=mode, **kw)
+        assert cluster.clades(got) == cluster.clades(newick), (got, newick)
