@@ -134,6 +134,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if rank == 0 and not exact:
+        # outside the timed region: the scan arithmetic alone, one launch over the whole stream
+        m = ctx.build_matrix_device(seqs.data_ptr(), offsets, a.k, 4)
+        sel = m.nmost(a.n, window=a.window)
+        stats["scan_stream_ms"], stats["scan_stream_rows"] = sel.bench_scan(5)
+        sel.close()
+        m.close()
     if rank == 0:
         total_seqs = a.nseq * world * a.steps
         scan_s = stats["scan_ms"] / 1e3
@@ -184,6 +191,13 @@ def main():
                 "avg_launch_us": stats["scan_ms"] * 1e3 / max(1, stats["scan_launches"]),
             },
         }
+        if "scan_stream_ms" in stats:  # the scan arithmetic alone, streaming the whole matrix once
+            gbps = stats["scan_stream_rows"] * B * 4 / (stats["scan_stream_ms"] * 1e-3) / 1e9
+            out["roofline"]["scan_streaming"] = {
+                "what": "one scan_kernel launch over all streamed rows, no events (dvs_select_bench_scan)",
+                "ms": stats["scan_stream_ms"], "rows": stats["scan_stream_rows"],
+                "achieved": gbps, "unit": "GB/s", "frac": gbps / peak,
+            }
         # HBM traffic of the dominant kernel: measured separately with rocprofv3 PMC passes
         # (bench.py cannot run under the profiler and time itself); committed in profiles/
         try:

@@ -32,7 +32,7 @@ EXPORTS = (
     "dvs_matrix_get_totals", "dvs_matrix_get_entropy", "dvs_kmer_counts", "dvs_select_run",
     "dvs_select_destroy", "dvs_select_get_summary", "dvs_select_get_members",
     "dvs_select_delta_jsd", "dvs_select_step_scan", "dvs_select_step_fetch",
-    "dvs_select_step_apply", "dvs_select_step_poll", "dvs_selftest_fast_log2", "dvs_selftest_log2_acc", "dvs_mash_sketch", "dvs_mash_distances", "dvs_euclidean_distances",
+    "dvs_select_step_apply", "dvs_select_step_poll", "dvs_select_bench_scan", "dvs_selftest_fast_log2", "dvs_selftest_log2_acc", "dvs_mash_sketch", "dvs_mash_distances", "dvs_euclidean_distances",
 )
 
 
@@ -141,6 +141,7 @@ def load() -> C.CDLL:
         L.dvs_select_step_fetch.argtypes = [vp, vp, vp, vp]
         L.dvs_select_step_apply.argtypes = [vp, vp, vp]
         L.dvs_select_step_poll.argtypes = [vp, vp, u32p, u64p]
+        L.dvs_select_bench_scan.argtypes = [vp, vp, C.c_int, f64p, u64p]
         L.dvs_selftest_fast_log2.argtypes = [vp, f64p]
         L.dvs_selftest_log2_acc.argtypes = [vp, f64p]
         L.dvs_mash_sketch.argtypes = [vp, vp, C.c_int, u64p, C.c_uint32, C.c_uint32, C.c_uint32,

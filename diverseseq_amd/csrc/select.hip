@@ -1301,3 +1301,67 @@ extern "C" int dvs_select_step_poll(dvs_ctx *ctx, dvs_select *s, uint32_t *statu
                              (unsigned long long)s->h_ctl->arb_pos);
     return DVS_OK;
 }
+
+// Measurement aid: ONE scan_kernel launch over every streamed row against the set's current
+// state with an unreachable threshold (no events), timed with HIP events on the ctx stream.
+// This is the steady-state streaming rate of the scan arithmetic, without the greedy chain's
+// per-event latencies.  The selection's state is not touched (a scratch control block is used).
+extern "C" int dvs_select_bench_scan(dvs_ctx *ctx, const dvs_select *s, int repeats, double *ms_out,
+                                     uint64_t *rows_out) {
+    if (!ctx || !s || !ms_out || !rows_out || repeats < 1)
+        return dvs_set_error(ctx, DVS_ERR_VALUE, "bad argument");
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    SelCtl c = *s->h_ctl;
+    const uint64_t first = s->params.n_seed;
+    if (s->npos <= first) return dvs_set_error(ctx, DVS_ERR_VALUE, "nothing to scan");
+    c.status = SEL_RUN;
+    c.cursor = first;
+    c.window = uint32_t(std::min<uint64_t>(s->npos - first, 0xFFFFFFFFull));
+    c.event_pos = SEL_NONE;
+    c.thr = 1e300;
+    c.ev_kind = 0;
+    SelCtl *d_c = nullptr;
+    uint32_t *d_rows = nullptr;
+    int rc = dvs_dev_alloc(ctx, (void **)&d_c, sizeof(SelCtl), "scratch control block");
+    if (!rc) rc = dvs_dev_alloc(ctx, (void **)&d_rows, size_t(s->scan_grid) * 8, "scratch row counters");
+    if (rc) {
+        dvs_dev_free(ctx, d_c);
+        return rc;
+    }
+    hipEvent_t e0 = dvs_event_get(ctx), e1 = dvs_event_get(ctx);
+    const SelDev &d = s->dev;
+    auto launch = [&]() {
+        if (s->mat_kind == 0) {
+            if (s->scan_hot)
+                hipLaunchKernelGGL((scan_kernel<uint32_t, true>), dim3(s->scan_grid), dim3(SCAN_THREADS),
+                                   s->scan_lds, ctx->stream, d_c, s->mat->d_counts, d.totals, d.rowH, d.order,
+                                   d.labels, d.inset, d.nlabels, d.base, d_rows, d.B, s->base_in_lds ? 1 : 0);
+            else
+                hipLaunchKernelGGL((scan_kernel<uint32_t, false>), dim3(s->scan_grid), dim3(SCAN_THREADS),
+                                   s->scan_lds, ctx->stream, d_c, s->mat->d_counts, d.totals, d.rowH, d.order,
+                                   d.labels, d.inset, d.nlabels, d.base, d_rows, d.B, s->base_in_lds ? 1 : 0);
+        } else {
+            hipLaunchKernelGGL((scan_kernel<double, false>), dim3(s->scan_grid), dim3(SCAN_THREADS),
+                               s->scan_lds, ctx->stream, d_c, s->mat->d_freqs, d.totals, d.rowH, d.order,
+                               d.labels, d.inset, d.nlabels, d.base, d_rows, d.B, s->base_in_lds ? 1 : 0);
+        }
+    };
+    hipError_t e = hipMemcpyAsync(d_c, &c, sizeof c, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_rows, 0, size_t(s->scan_grid) * 8, ctx->stream);
+    launch();  // warm-up
+    if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+    for (int i = 0; i < repeats; i++) launch();
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e == hipSuccess) e = hipGetLastError();
+    dvs_event_put(ctx, e0);
+    dvs_event_put(ctx, e1);
+    dvs_dev_free(ctx, d_c);
+    dvs_dev_free(ctx, d_rows);
+    if (e != hipSuccess) return dvs_hip_fail(ctx, e, "scan benchmark");
+    *ms_out = double(ms) / repeats;
+    *rows_out = s->npos - first;
+    return DVS_OK;
+}

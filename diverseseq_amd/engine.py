@@ -221,6 +221,13 @@ class Selection:
             _lib.ptr(dl, C.c_double), _lib.ptr(en, C.c_double), _lib.ptr(fr, C.c_double)))
         return Members(pos, lab, dl, en, fr)
 
+    def bench_scan(self, repeats: int = 5) -> tuple[float, int]:
+        """(ms per launch, rows) of one scan launch over the whole stream, no events"""
+        ms, rows = C.c_double(), C.c_uint64()
+        self.ctx.check(self.ctx._L.dvs_select_bench_scan(self.ctx._h, self._h, repeats, C.byref(ms),
+                                                         C.byref(rows)))
+        return ms.value, rows.value
+
     def delta_jsd(self, queries: CountMatrix, qlabels=None) -> np.ndarray:
         out = np.zeros(queries.nrows, dtype=np.float64)
         ql = None if qlabels is None else np.ascontiguousarray(qlabels, dtype=np.uint32)

@@ -177,6 +177,11 @@ int dvs_select_step_poll(dvs_ctx *ctx, dvs_select *s, uint32_t *status, uint64_t
  * ctx stream (no extra host sync); they are read once the selection has finished
  * and summed into dvs_select_summary.scan_ms / scan_launches */
 int dvs_ctx_set_timing(dvs_ctx *ctx, int on);
+/* measurement aid: average duration of ONE scan_kernel launch over every streamed row of
+ * the selection's stream against its current state, with an unreachable threshold (no
+ * events, state untouched): the steady-state streaming rate of the scan arithmetic */
+int dvs_select_bench_scan(dvs_ctx *ctx, const dvs_select *s, int repeats, double *ms_out,
+                          uint64_t *rows_out);
 /* diagnostic: max |v_log_f32(m) - log2(m)| over every f32 m in [0.5, 1), the
  * hardware term of the scan kernel's fast-tier error bound (select.hip FAST_BAND) */
 int dvs_selftest_fast_log2(dvs_ctx *ctx, double *max_abs_err);
