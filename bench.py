@@ -44,6 +44,11 @@ def parse():
 
 def main():
     a = parse()
+    # RCCL prints a version banner on stdout when the process exits; the contract is ONE JSON
+    # line on stdout, so everything C-level goes to stderr and the line is written to the real
+    # stdout explicitly.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -54,8 +59,12 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dist = bool(os.environ.get("DVS_BENCH_FORCE_DIST"))  # exercise the RCCL path on 1 GPU
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from diverseseq_amd import engine
@@ -101,7 +110,7 @@ def main():
             sel = nmost_exact(ctx, m, order, a.n, dev, world, window=a.window)
         else:
             sel = m.nmost(a.n, window=a.window)
-        if world > 1 and not exact:
+        if (world > 1 or force_dist) and not exact:
             merged = merge_nmost(ctx, sel, a.n, rank, world, rank * a.nseq, dev)
             merged.close()
         if collect:
@@ -117,7 +126,7 @@ def main():
     for _ in range(a.warmup):
         step(False)
     ctx.set_timing(True)  # HIP-event pairs around every scan launch, read after the run
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ctx.sync()
@@ -126,10 +135,10 @@ def main():
         step(True)
     ctx.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -222,8 +231,8 @@ def main():
                 "sample": (f"the first {ns} sequences of the same workload, 1 thread, C restatement of the "
                            "Rust path (oracle/dvs_oracle.c), data in RAM"),
             }
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

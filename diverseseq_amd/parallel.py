@@ -65,7 +65,7 @@ def merge_nmost(ctx, sel, n: int, rank: int, world: int, chunk_start: int, devic
     ids = mem.positions.astype(np.int64) + chunk_start
     rows, gids = gather_winners(mem.kfreqs, ids, world, device, cap=n)
     m = ctx.matrix_from_freqs(rows)
-    merged = m.nmost(n, labels=np.arange(rows.shape[0], dtype=np.uint32))
+    merged = m.nmost(n)  # ids are unique across chunks: identity labels
     merged.global_ids = gids
     merged._keep = m  # the matrix must outlive the selection
     return merged

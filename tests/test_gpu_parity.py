@@ -622,3 +622,16 @@ def test_exact_row_sharded_mode(world):
         np.testing.assert_allclose(delta, edelta, rtol=RTOL, atol=1e-13)
         np.testing.assert_allclose(total, exp.total_jsd, rtol=RTOL)
     assert res[0][1:] == res[-1][1:]  # replicas are bit-identical
+
+
+def test_final_merge_identity_labels_persistent_engine(ctx, brca1):
+    """frequency-row matrix + identity labels: the persistent engine's f64-row instantiation"""
+    seqs = list(brca1.values())
+    rows = np.vstack([oracle.nmost(seqs[i:i + 11], 4, 4, 4).members(with_freqs=True)[3]
+                      for i in range(0, 55, 11)])
+    m = ctx.matrix_from_freqs(rows)
+    got = m.nmost(4)
+    assert got.summary().engine == 1
+    exp = oracle.final_nmost(rows, 4)
+    assert got.members().positions.tolist() == exp.members()[0].tolist()
+    np.testing.assert_allclose(got.members().delta_jsd, exp.members()[1], rtol=RTOL, atol=1e-13)
