@@ -47,14 +47,16 @@ constexpr uint32_t P_MAXN = 512;            // members the LDS replica holds
 constexpr uint32_t P_JOBS = P_MAXN + 1;     // leave-one-out jobs per event: (n + 1) * K <= max(G - 1, n + 1)
 constexpr uint32_t P_SPIN_LIMIT = 1u << 22;  // ~0.5 s of polling
 
-struct PSync {
+struct PSync {  // every polled word on a cache line of its own (256 B apart)
     uint32_t count;  // arrivals, monotonic over the launch
-    uint32_t gen;    // completed barriers
+    uint32_t pad0[63];
+    uint32_t gen;  // completed barriers
+    uint32_t pad1[63];
     uint32_t timeout;
-    uint32_t pad;
-    unsigned long long ev[4];  // event words, slot = epoch % 3
-    unsigned long long dbg2[8];  // block 0 (owns member 0): the same phases
-    unsigned long long dbg[8];  // lead block: 100 MHz ticks per phase (scan, bar1, resolve, loo, bar2, finalize)
+    uint32_t pad2[63];
+    unsigned long long ev[3][32];  // event words, slot = epoch % 3 (ev[s][0])
+    unsigned long long dbg2[8];    // block 0 (owns a job): phase ticks
+    unsigned long long dbg[8];     // mirror block: 100 MHz ticks per phase (scan, bar1, resolve, loo, bar2, finalize)
 };
 
 struct PState {  // replicated scalars (identical in every workgroup)
@@ -67,14 +69,20 @@ struct PState {  // replicated scalars (identical in every workgroup)
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-// returns false on timeout (every thread of the block gets the same answer)
+// returns false on timeout (every thread of the block gets the same answer).
+// FENCED: this barrier hands plain-stored data between workgroups (release before the arrival,
+// acquire after the release of the barrier).  The barrier after the scan phase hands over
+// nothing but an agent-scope atomic word, so it runs unfenced: a pure rendezvous.
+template <bool FENCED>
 __device__ bool grid_barrier(PSync *sync, uint32_t G, uint32_t &gen, int *s_ok) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have left
+    if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have left
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t target = gen + 1;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (FENCED) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         const uint32_t old = __hip_atomic_fetch_add(&sync->count, 1u, RLX_AGENT);
         int ok = 1;
         if (old == G * target - 1) {
@@ -82,16 +90,19 @@ __device__ bool grid_barrier(PSync *sync, uint32_t G, uint32_t &gen, int *s_ok) 
         } else {
             uint32_t spins = 0;
             while (__hip_atomic_load(&sync->gen, RLX_AGENT) < target) {
-                if (++spins > P_SPIN_LIMIT || __hip_atomic_load(&sync->timeout, RLX_AGENT)) {
+                if ((++spins & 255u) == 0 &&
+                    (spins > P_SPIN_LIMIT || __hip_atomic_load(&sync->timeout, RLX_AGENT))) {
                     __hip_atomic_store(&sync->timeout, 1u, RLX_AGENT);
                     ok = 0;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (FENCED) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         *s_ok = ok;
     }
     __syncthreads();
@@ -256,15 +267,19 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         }                                                                  \
     } while (0)
     for (;;) {
-        unsigned long long *evp = &sync->ev[epoch % 3];
-        if (lead && tid == 0) __hip_atomic_store(&sync->ev[(epoch + 1) % 3], SEL_NONE, RLX_AGENT);
+        unsigned long long *evp = &sync->ev[epoch % 3][0];
+        // the slot of the NEXT epoch is cleared now; an exchange (its result is consumed) has been
+        // performed before this thread's arrival at the barrier below can be
+        if (lead && tid == 0 &&
+            __hip_atomic_exchange(&sync->ev[(epoch + 1) % 3][0], SEL_NONE, RLX_AGENT) == 1ull)
+            sync->pad0[1] = 1;  // (consumes the result; position 1 is a seed, never an event)
         const uint64_t end = umin64(st.cursor + uint64_t(st.window), st.npos);
         const uint64_t nrows = end - st.cursor;
         // ================= scan
         p_scan_rows<T>(mat, d.totals, d.rowH, sl, B, st, st.sumH - s_mH[st.li], evp,
                        uint64_t(blockIdx.x) * wpb + wave, nwaves, nrows, lane, nread, nprecise);
         P_STAMP(0);
-        if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
+        if (!grid_barrier<false>(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
         P_STAMP(1);
         const uint64_t p = __hip_atomic_load(evp, RLX_AGENT);
         st.n_windows++;
@@ -414,7 +429,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             ctl->ev_n = n;
         }
         P_STAMP(3);
-        if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
+        if (!grid_barrier<true>(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
         P_STAMP(4);
         // ================= combine: one load per job (a single memory round trip), then the K
         // partials of each r are added in job order by one thread -> same bits in every workgroup
@@ -603,7 +618,7 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     const SelDev &d = s->dev;
     PSync init;
     memset(&init, 0, sizeof init);
-    for (int i = 0; i < 4; i++) init.ev[i] = SEL_NONE;
+    for (int i = 0; i < 3; i++) init.ev[i][0] = SEL_NONE;
     DVS_HIP(ctx, hipMemcpyAsync(s->psync, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->time_scan) {

@@ -854,13 +854,14 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat) {
             s->ev_used = 0;
         }
         if (s->persist && s->psync && getenv("DVS_PERSIST_DEBUG")) {
-            unsigned long long dbg[24];
-            if (hipMemcpy(dbg, s->psync, sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long dbg[16];
+            // PSync: 3 x 256 B of polled words, 3 x 256 B of event slots, then dbg2[8], dbg[8]
+            if (hipMemcpy(dbg, static_cast<char *>(s->psync) + 6 * 256, sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
                 for (int w = 0; w < 2; w++)
                     fprintf(stderr, "[dvs persist %s] us: scan %.1f bar1 %.1f resolve %.1f loo %.1f bar2 %.1f finalize %.1f\n",
-                            w ? "mirror block" : "block 0", dbg[6 + 8 * w] / 100.0, dbg[7 + 8 * w] / 100.0,
-                            dbg[8 + 8 * w] / 100.0, dbg[9 + 8 * w] / 100.0, dbg[10 + 8 * w] / 100.0,
-                            dbg[11 + 8 * w] / 100.0);
+                            w ? "mirror block" : "block 0", dbg[0 + 8 * w] / 100.0, dbg[1 + 8 * w] / 100.0,
+                            dbg[2 + 8 * w] / 100.0, dbg[3 + 8 * w] / 100.0, dbg[4 + 8 * w] / 100.0,
+                            dbg[5 + 8 * w] / 100.0);
             }
         }
         if (c.status == SEL_DONE) return DVS_OK;

@@ -635,3 +635,21 @@ def test_final_merge_identity_labels_persistent_engine(ctx, brca1):
     exp = oracle.final_nmost(rows, 4)
     assert got.members().positions.tolist() == exp.members()[0].tolist()
     np.testing.assert_allclose(got.members().delta_jsd, exp.members()[1], rtol=RTOL, atol=1e-13)
+
+
+def test_large_sets_and_other_alphabets(ctx):
+    """n beyond what the persistent engine replicates in LDS (multi-launch engine), a 20-state
+    alphabet (k=2, 400 bins: not a multiple of 256) and a tiny one (3 states, k=3)"""
+    seqs = synth_seqs(1400, 260, 909, ragged=True)
+    m = ctx.build_matrix(seqs, 3, 4)
+    sel = m.nmost(600)
+    assert sel.summary().engine == 0
+    _assert_selection(sel, oracle.nmost(seqs, 600, 3, 4))
+    rng = np.random.default_rng(21)
+    prot = [rng.integers(0, 21, size=int(rng.integers(150, 600)), dtype=np.uint8) for _ in range(500)]
+    mp = ctx.build_matrix(prot, 2, 20)
+    _assert_selection(mp.nmost(15), oracle.nmost(prot, 15, 2, 20))
+    _assert_selection(mp.max_divergent(6, 30, "stdev"), oracle.max_divergent(prot, 6, 30, 2, 20, "stdev"))
+    tri = [rng.integers(0, 4, size=int(rng.integers(60, 300)), dtype=np.uint8) for _ in range(400)]
+    mt = ctx.build_matrix(tri, 3, 3)
+    _assert_selection(mt.nmost(8), oracle.nmost(tri, 8, 3, 3))
