@@ -191,7 +191,11 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                 for (uint64_t i = lane; i < B; i += 64) e.add(fma(row_value(rp, i), rt, sl[i]) * rn);
                 hit = dvs_wave_sum(e.h) - mean_entropy > thr_lo;
             }
-            if (hit && lane == 0) atomicMin(evp, (unsigned long long)p);
+            if (hit && lane == 0) {
+                atomicMin(evp, (unsigned long long)p);
+                // above the threshold by more than every error bound: no f64 re-evaluation needed
+                if (jf > thr_sure) atomicMin(evp + 16, (unsigned long long)p);
+            }
         }
     }
 }
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     uint64_t arb_pos = 0;
     uint32_t pend_kind = 0;  // ev_kind left pending for the multi-launch kernels (finalize tie)
     const uint64_t wpb = P_THREADS / 64;
-    const uint64_t nwaves = uint64_t(G) * wpb;
+    const uint64_t nwaves = uint64_t(G > 1 ? G - 1 : 1) * wpb;  // scanning waves
 
     unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
 #define P_STAMP(k)                                                         \
@@ -271,13 +275,18 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // the slot of the NEXT epoch is cleared now; an exchange (its result is consumed) has been
         // performed before this thread's arrival at the barrier below can be
         if (lead && tid == 0 &&
-            __hip_atomic_exchange(&sync->ev[(epoch + 1) % 3][0], SEL_NONE, RLX_AGENT) == 1ull)
-            sync->pad0[1] = 1;  // (consumes the result; position 1 is a seed, never an event)
+            (__hip_atomic_exchange(&sync->ev[(epoch + 1) % 3][0], SEL_NONE, RLX_AGENT) == 1ull) +
+                    (__hip_atomic_exchange(&sync->ev[(epoch + 1) % 3][16], SEL_NONE, RLX_AGENT) == 1ull) ==
+                2)
+            sync->pad0[1] = 1;  // (consumes the results; position 1 is a seed, never an event)
         const uint64_t end = umin64(st.cursor + uint64_t(st.window), st.npos);
         const uint64_t nrows = end - st.cursor;
         // ================= scan
-        p_scan_rows<T>(mat, d.totals, d.rowH, sl, B, st, st.sumH - s_mH[st.li], evp,
-                       uint64_t(blockIdx.x) * wpb + wave, nwaves, nrows, lane, nread, nprecise);
+        // (the mirror block scans nothing when there are other blocks: its global stores of the
+        // previous event overlap the others' scan instead of delaying the rendezvous)
+        if (!lead || G == 1)
+            p_scan_rows<T>(mat, d.totals, d.rowH, sl, B, st, st.sumH - s_mH[st.li], evp,
+                           uint64_t(blockIdx.x) * wpb + wave, nwaves, nrows, lane, nread, nprecise);
         P_STAMP(0);
         if (!grid_barrier<false>(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
         P_STAMP(1);
@@ -300,7 +309,22 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         const T *rp = mat + p * B;
         double fr[P_J];  // the candidate's frequencies of this thread's bins (B <= P_J * 512)
         double jsd, sm;
-        {
+        // A sure event (fast score above thr + band + FAST_BAND, so the exact score is above
+        // thr + band) is accepted outright.  The sum-to-one guard needs no second look either:
+        // the candidate's mean vector sums to the previous whole-set sum up to ~B u, and that
+        // sum passed its guard at the last finalize.
+        const bool sure = __hip_atomic_load(evp + 16, RLX_AGENT) == p;
+        if (sure) {
+            if (CACHED) {
+#pragma unroll
+                for (int j = 0; j < P_J; j++) {
+                    const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                    if (i < B) fr[j] = cand_freq(rp, i, tot);
+                }
+            }
+            jsd = INFINITY;
+            sm = 1.0;
+        } else {
             Ent e;
             for (uint64_t b0 = 0; b0 < B; b0 += uint64_t(P_J) * P_THREADS) {
 #pragma unroll
@@ -618,7 +642,7 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     const SelDev &d = s->dev;
     PSync init;
     memset(&init, 0, sizeof init);
-    for (int i = 0; i < 3; i++) init.ev[i][0] = SEL_NONE;
+    for (int i = 0; i < 3; i++) init.ev[i][0] = init.ev[i][16] = SEL_NONE;
     DVS_HIP(ctx, hipMemcpyAsync(s->psync, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->time_scan) {

@@ -1084,9 +1084,10 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     c.cursor = n_seed;
     c.npos = npos;
     c.event_pos = SEL_NONE;
-    // default window: one row per wave of the persistent grid, else 4096 rows per scan launch
+    // default window: a quarter of the persistent grid's waves (measured best: early in the
+    // stream an accept comes every few hundred rows), else 4096 rows per scan launch
     const uint32_t wdef = params->window ? params->window
-                                         : (s->persist ? s->persist_grid * 8u : 4096u);
+                                         : (s->persist ? s->persist_grid * 2u : 4096u);
     c.window_min = wdef;
     c.window_max = std::max<uint32_t>(wdef, s->scan_grid * (SCAN_THREADS / 64) * 8);
     c.window = wdef;
@@ -1098,7 +1099,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     c.forced = FORCE_NONE;
     c.forced_lowest = 0xFFFFFFFFu;
     c.band = 0.0;
-    c.wscale = 2.0;  // measured best of {0.5, 1, 2, 4} on the north-star shape (flat within 3 %)
+    c.wscale = 4.0;  // measured best of {1, 2, 4} x window_min {256..2048} on the north-star shape
     if (const char *e = getenv("DVS_WINDOW_SCALE")) c.wscale = atof(e);
     DVS_HIP(ctx, hipMemcpyAsync(d.ctl, &c, sizeof c, hipMemcpyHostToDevice, ctx->stream));
     s->seed_positions = seeds;
