@@ -111,7 +111,8 @@ def main():
         else:
             sel = m.nmost(a.n, window=a.window)
         if (world > 1 or force_dist) and not exact:
-            merged = merge_nmost(ctx, sel, a.n, rank, world, rank * a.nseq, dev)
+            merged = merge_nmost(ctx, sel, a.n, rank, world, rank * a.nseq, dev,
+                                 chunk_starts=[r * a.nseq for r in range(world)])
             merged.close()
         if collect:
             s = sel.summary()

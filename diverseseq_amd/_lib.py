@@ -26,11 +26,12 @@ ROW_REMOTE = 0xFFFFFFFF
 # every symbol include/dvs_hip.h declares (tests/test_boundary.py checks the .so exports them)
 EXPORTS = (
     "dvs_abi_version", "dvs_ctx_create", "dvs_ctx_destroy", "dvs_last_error", "dvs_ctx_sync",
-    "dvs_ctx_trim", "dvs_ctx_device_info", "dvs_ctx_set_timing", "dvs_matrix_build", "dvs_matrix_from_freqs",
+    "dvs_ctx_trim", "dvs_ctx_device_info", "dvs_ctx_set_timing", "dvs_matrix_build", "dvs_matrix_from_freqs", "dvs_matrix_from_device_freqs",
     "dvs_matrix_destroy", "dvs_matrix_nrows", "dvs_matrix_nbins", "dvs_matrix_dev_counts",
     "dvs_matrix_dev_totals", "dvs_matrix_dev_entropy", "dvs_matrix_get_counts",
     "dvs_matrix_get_totals", "dvs_matrix_get_entropy", "dvs_kmer_counts", "dvs_select_run",
     "dvs_select_destroy", "dvs_select_get_summary", "dvs_select_get_members",
+    "dvs_select_gather_members",
     "dvs_select_delta_jsd", "dvs_select_step_scan", "dvs_select_step_fetch",
     "dvs_select_step_apply", "dvs_select_step_poll", "dvs_select_bench_scan", "dvs_selftest_fast_log2", "dvs_selftest_log2_acc", "dvs_mash_sketch", "dvs_mash_distances", "dvs_euclidean_distances",
 )
@@ -116,6 +117,8 @@ def load() -> C.CDLL:
         L.dvs_matrix_build.argtypes = [vp, vp, C.c_int, u64p, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.POINTER(vp)]
         L.dvs_matrix_from_freqs.argtypes = [vp, f64p, C.c_uint32, C.c_uint64, C.POINTER(vp)]
+        L.dvs_matrix_from_device_freqs.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint64, C.POINTER(vp)]
+        L.dvs_select_gather_members.argtypes = [vp, vp, vp, vp, C.c_uint32]
         L.dvs_matrix_destroy.argtypes = [vp]
         L.dvs_matrix_destroy.restype = None
         L.dvs_matrix_nrows.argtypes = [vp]

@@ -10,6 +10,7 @@ void dvs_matrix_free_fields(dvs_matrix *m);
 int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs, uint64_t nbytes,
                            const uint64_t *offsets);
 int dvs_matrix_fill_freq_entropy(dvs_ctx *ctx, dvs_matrix *m);
+int dvs_matrix_fill_freq_totals(dvs_ctx *ctx, dvs_matrix *m, const double *d_meta);
 
 static std::string g_create_err;
 
@@ -311,6 +312,39 @@ int dvs_matrix_from_freqs(dvs_ctx *ctx, const double *freqs, uint32_t nrows, uin
         if (!rc) rc = dvs_matrix_fill_freq_entropy(ctx, m);
         if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess)
             rc = dvs_set_error(ctx, DVS_ERR_RUNTIME, "stream sync failed");
+    }
+    if (rc) {
+        dvs_matrix_free_fields(m);
+        delete m;
+        return rc;
+    }
+    *out = m;
+    return DVS_OK;
+}
+
+// Frequency rows already in HBM (e.g. the all-gathered winners of a chunked run).  meta may be
+// NULL; otherwise meta[2 r + 1] == 0 marks row r as padding (it is given total 0 and skipped like
+// a sequence without valid k-mers).  The rows are copied; they are trusted to be frequency
+// vectors produced by this library (count / total rows always pass the reference's sum check).
+int dvs_matrix_from_device_freqs(dvs_ctx *ctx, const double *d_freqs, const double *d_meta, uint32_t nrows,
+                                 uint64_t nbins, dvs_matrix **out) {
+    if (!ctx || !out || (!d_freqs && nrows)) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    *out = nullptr;
+    if (nbins == 0)
+        return dvs_set_error(ctx, DVS_ERR_VALUE, "cannot calculate entropy as frequency vector empty");
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    dvs_matrix *m = new dvs_matrix();
+    m->kind = 1;
+    m->nrows = nrows;
+    m->nbins = nbins;
+    m->device = ctx->device;
+    int rc = matrix_alloc(ctx, m);
+    if (!rc && nrows) {
+        hipError_t e = hipMemcpyAsync(m->d_freqs, d_freqs, size_t(nrows) * nbins * 8, hipMemcpyDeviceToDevice,
+                                      ctx->stream);
+        if (e != hipSuccess) rc = dvs_hip_fail(ctx, e, "hipMemcpyAsync(freqs)");
+        if (!rc) rc = dvs_matrix_fill_freq_totals(ctx, m, d_meta);
+        if (!rc) rc = dvs_matrix_fill_freq_entropy(ctx, m);
     }
     if (rc) {
         dvs_matrix_free_fields(m);

@@ -256,6 +256,13 @@ __global__ __launch_bounds__(HIST_THREADS) void freq_entropy_kernel(
     if (threadIdx.x == 0) entropy[blockIdx.x] = h;
 }
 
+// totals of a frequency-row matrix: 1, or 0 for a padding row (meta[2 r + 1] == 0)
+__global__ void freq_totals_kernel(uint32_t *__restrict__ totals, const double *__restrict__ meta,
+                                   uint32_t nrows) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nrows) totals[r] = (!meta || meta[2 * r + 1] != 0.0) ? 1u : 0u;
+}
+
 template <typename K>
 int set_dyn_lds(dvs_ctx *ctx, K kernel, size_t bytes) {
     static std::map<const void *, size_t> set_lds;
@@ -389,6 +396,13 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
 int dvs_matrix_fill_freq_entropy(dvs_ctx *ctx, dvs_matrix *m) {
     hipLaunchKernelGGL(freq_entropy_kernel, dim3(m->nrows), dim3(HIST_THREADS), 0, ctx->stream,
                        m->d_freqs, m->d_entropy, m->nbins);
+    DVS_HIP(ctx, hipGetLastError());
+    return DVS_OK;
+}
+
+int dvs_matrix_fill_freq_totals(dvs_ctx *ctx, dvs_matrix *m, const double *d_meta) {
+    hipLaunchKernelGGL(freq_totals_kernel, dim3((m->nrows + 255) / 256), dim3(256), 0, ctx->stream,
+                       m->d_totals, d_meta, m->nrows);
     DVS_HIP(ctx, hipGetLastError());
     return DVS_OK;
 }

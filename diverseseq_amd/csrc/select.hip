@@ -741,6 +741,25 @@ __global__ __launch_bounds__(LOO_THREADS) void score_kernel(SelDev d, const T *_
     }
 }
 
+// members in set order -> a dense device buffer (for the device-side chunk merge)
+__global__ __launch_bounds__(LOO_THREADS) void gather_members_kernel(SelDev d, double *__restrict__ rows,
+                                                                    double *__restrict__ meta) {
+    const uint32_t r = blockIdx.x, n = d.ctl->size;
+    double *out = rows + uint64_t(r) * d.B;
+    if (r >= n) {
+        for (uint64_t i = threadIdx.x; i < d.B; i += LOO_THREADS) out[i] = 0.0;
+        if (threadIdx.x == 0) meta[2 * r] = meta[2 * r + 1] = 0.0;
+        return;
+    }
+    const uint32_t slot = d.ord[r];
+    const double *src = d.M + uint64_t(slot) * d.B;
+    for (uint64_t i = threadIdx.x; i < d.B; i += LOO_THREADS) out[i] = src[i];
+    if (threadIdx.x == 0) {
+        meta[2 * r] = double(d.mPos[slot]);  // stream position (exact below 2^53)
+        meta[2 * r + 1] = 1.0;
+    }
+}
+
 // ---- stepwise (distributed) helpers: the event word as int64 for a MIN all-reduce and the
 // candidate row for a SUM all-reduce (the owner contributes the row, everyone else zeros)
 __global__ void export_event_kernel(const SelCtl *ctl, long long *dst) {
@@ -1365,5 +1384,21 @@ extern "C" int dvs_select_bench_scan(dvs_ctx *ctx, const dvs_select *s, int repe
     if (e != hipSuccess) return dvs_hip_fail(ctx, e, "scan benchmark");
     *ms_out = double(ms) / repeats;
     *rows_out = s->npos - first;
+    return DVS_OK;
+}
+
+// Members in set order into caller-provided DEVICE buffers: rows[cap_rows x nbins] and
+// meta[cap_rows x 2] = (stream position, 1.0) -- rows beyond the set's size are zeroed with
+// meta (0, 0).  Enqueued on the ctx stream; the caller orders it against its own streams.
+extern "C" int dvs_select_gather_members(dvs_ctx *ctx, const dvs_select *s, double *d_rows, double *d_meta,
+                                         uint32_t cap_rows) {
+    if (!ctx || !s || !d_rows || !d_meta) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (cap_rows < s->h_ctl->size)
+        return dvs_set_error(ctx, DVS_ERR_VALUE, "buffer of %u rows for a set of %u", cap_rows, s->h_ctl->size);
+    if (!cap_rows) return DVS_OK;
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(gather_members_kernel, dim3(cap_rows), dim3(LOO_THREADS), 0, ctx->stream, s->dev,
+                       d_rows, d_meta);
+    DVS_HIP(ctx, hipGetLastError());
     return DVS_OK;
 }

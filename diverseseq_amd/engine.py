@@ -100,6 +100,16 @@ class Context:
                                                  f.shape[1], C.byref(h)))
         return CountMatrix(self, h, 0, 0)
 
+    def matrix_from_device_freqs(self, dev_ptr: int, nrows: int, nbins: int,
+                                 meta_ptr: int | None = None) -> "CountMatrix":
+        """frequency rows already in HBM (f64 [nrows, nbins]); meta (f64 [nrows, 2]) marks
+        padding rows with meta[r, 1] == 0"""
+        h = C.c_void_p()
+        self.check(self._L.dvs_matrix_from_device_freqs(self._h, C.c_void_p(dev_ptr),
+                                                        C.c_void_p(meta_ptr) if meta_ptr else None,
+                                                        nrows, nbins, C.byref(h)))
+        return CountMatrix(self, h, 0, 0)
+
     def kmer_counts(self, seqs, k: int, num_states: int = 4):
         """-> (counts uint32 [n, ns^k], totals uint32 [n], entropy f64 [n])"""
         m = self.build_matrix(seqs, k, num_states)
@@ -220,6 +230,12 @@ class Selection:
             self.ctx._h, self._h, _lib.ptr(pos, C.c_uint64), _lib.ptr(lab, C.c_uint32),
             _lib.ptr(dl, C.c_double), _lib.ptr(en, C.c_double), _lib.ptr(fr, C.c_double)))
         return Members(pos, lab, dl, en, fr)
+
+    def gather_members(self, rows_ptr: int, meta_ptr: int, cap_rows: int):
+        """members in set order into device buffers rows[cap, nbins], meta[cap, 2] (position, valid);
+        enqueued on the context's stream"""
+        self.ctx.check(self.ctx._L.dvs_select_gather_members(self.ctx._h, self._h, C.c_void_p(rows_ptr),
+                                                             C.c_void_p(meta_ptr), cap_rows))
 
     def bench_scan(self, repeats: int = 5) -> tuple[float, int]:
         """(ms per launch, rows) of one scan launch over the whole stream, no events"""

@@ -58,9 +58,49 @@ def gather_winners(rows: np.ndarray, ids: np.ndarray, world: int, device, cap: i
     return np.concatenate(out_rows), np.concatenate(out_ids)
 
 
-def merge_nmost(ctx, sel, n: int, rank: int, world: int, chunk_start: int, device):
+def gather_winners_device(ctx, sel, world: int, device, cap: int):
+    """The same exchange with no host round trip: the members are gathered on the device
+    straight into the all_gather's send buffer.  Returns device tensors (rows [world*cap, B],
+    meta [world*cap, 2] = (chunk-local position, valid)); ranks with fewer than `cap` members
+    contribute zero rows flagged invalid, which the merge skips."""
+    import torch
+    import torch.distributed as dist
+
+    B = sel.matrix.nbins
+    t_rows = torch.empty((cap, B), dtype=torch.float64, device=device)
+    t_meta = torch.empty((cap, 2), dtype=torch.float64, device=device)
+    all_rows = torch.empty((world * cap, B), dtype=torch.float64, device=device)
+    all_meta = torch.empty((world * cap, 2), dtype=torch.float64, device=device)
+    torch.cuda.current_stream().synchronize()  # the buffers exist before the library writes them
+    sel.gather_members(t_rows.data_ptr(), t_meta.data_ptr(), cap)
+    ctx.sync()
+    dist.all_gather_into_tensor(all_rows, t_rows)
+    dist.all_gather_into_tensor(all_meta, t_meta)
+    torch.cuda.current_stream().synchronize()
+    return all_rows, all_meta
+
+
+def _global_ids(all_meta, chunk_starts, cap: int) -> np.ndarray:
+    """global stream position of every gathered row (-1 for padding)"""
+    meta = all_meta.cpu().numpy()
+    starts = np.repeat(np.asarray(chunk_starts, dtype=np.int64), cap)
+    return np.where(meta[:, 1] != 0, meta[:, 0].astype(np.int64) + starts, -1)
+
+
+def merge_nmost(ctx, sel, n: int, rank: int, world: int, chunk_start: int, device,
+                chunk_starts=None):
     """exchange the winners and run final_nmost on the device; returns the merged Selection
-    (its member positions index the gathered row list; see `gather_winners`)."""
+    (its member positions index the gathered row list; `merged.global_ids` maps them to
+    global stream positions).  With `chunk_starts` (every rank's chunk start) on a GPU the
+    rows never leave HBM."""
+    if chunk_starts is not None and getattr(device, "type", str(device)) == "cuda":
+        all_rows, all_meta = gather_winners_device(ctx, sel, world, device, cap=n)
+        m = ctx.matrix_from_device_freqs(all_rows.data_ptr(), world * n, sel.matrix.nbins,
+                                         all_meta.data_ptr())
+        merged = m.nmost(n)
+        merged.global_ids = _global_ids(all_meta, chunk_starts, n)
+        merged._keep = m
+        return merged
     mem = sel.members(with_freqs=True)
     ids = mem.positions.astype(np.int64) + chunk_start
     rows, gids = gather_winners(mem.kfreqs, ids, world, device, cap=n)

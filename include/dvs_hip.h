@@ -75,6 +75,11 @@ int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device,
  * (src/record.rs:99-104). */
 int dvs_matrix_from_freqs(dvs_ctx *ctx, const double *freqs, uint32_t nrows,
                           uint64_t nbins, dvs_matrix **out);
+/* the same for rows already in HBM (the all-gathered winners of a chunked multi-GPU run);
+ * d_meta may be NULL, else d_meta[2 r + 1] == 0 marks row r as padding (skipped like a
+ * sequence without valid k-mers).  Rows are copied; no host round trip. */
+int dvs_matrix_from_device_freqs(dvs_ctx *ctx, const double *d_freqs, const double *d_meta,
+                                 uint32_t nrows, uint64_t nbins, dvs_matrix **out);
 void dvs_matrix_destroy(dvs_matrix *m);
 uint32_t dvs_matrix_nrows(const dvs_matrix *m);
 uint64_t dvs_matrix_nbins(const dvs_matrix *m);
@@ -150,6 +155,11 @@ int dvs_select_get_summary(dvs_ctx *ctx, const dvs_select *s, dvs_select_summary
 int dvs_select_get_members(dvs_ctx *ctx, const dvs_select *s, uint64_t *positions,
                            uint32_t *labels, double *delta_jsd, double *entropy,
                            double *freqs);
+/* the same members into caller-provided DEVICE buffers, enqueued on the ctx stream:
+ * d_rows[cap_rows x nbins] frequency rows, d_meta[cap_rows x 2] = (stream position, 1.0);
+ * rows beyond the set's size are zeroed with meta (0, 0). */
+int dvs_select_gather_members(dvs_ctx *ctx, const dvs_select *s, double *d_rows, double *d_meta,
+                              uint32_t cap_rows);
 /* SummedRecords::delta_jsd (src/records.rs:70-84) for every row of `queries`
  * against the set: 0.0 when qlabels[i] is a member's label, NaN for a row
  * without valid k-mers (the python layer raises, src/records_py.rs:111-120). */

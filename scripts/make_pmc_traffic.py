@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from the two PMC summaries (scripts/rocpd_summary.py pmc ...):
+
+  python scripts/make_pmc_traffic.py profiles/r01_e_pmc_fetch_size.csv profiles/r01_e_pmc_write_size.csv r01_e
+
+HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> B): rocprofv3 reports both in KiB and,
+on gfx950, FETCH_SIZE prices the 128-B requests of wide coalesced reads at 64 B
+(MI355X_MICROARCH.md, HBM section), hence the factor 2 on the read side.
+"""
+import csv
+import json
+import sys
+
+KERNELS = {"persist_nmost_kernel": "persist_nmost_kernel", "kmer_hist_kernel": "kmer_hist_kernel",
+           "scan_kernel": "scan_kernel_streaming"}
+
+
+def load(path):
+    out = {}
+    for row in csv.DictReader(open(path)):
+        for key, label in KERNELS.items():
+            if key + "<" in row["Kernel"]:
+                out[label] = float(row["MeanValue"])
+    return out
+
+
+fetch, write = load(sys.argv[1]), load(sys.argv[2])
+tag = sys.argv[3]
+doc = {
+    "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), "
+              f"bench.py --steps 2 --warmup 1, MI355X (round 1, build {tag}); summaries in "
+              f"profiles/{tag}_pmc_fetch_size.csv and profiles/{tag}_pmc_write_size.csv",
+    "units": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts the 128-B "
+             "requests of wide coalesced reads as 64 B, so read bytes = 2 x FETCH_SIZE "
+             "(MI355X_MICROARCH.md, HBM section). Checks: kmer_hist_kernel WRITE_SIZE vs the "
+             "100000 x 4096 x 4 B matrix = 1600000 KiB, its 2 x FETCH_SIZE vs 488281 KiB of sequence "
+             "bytes; scan_kernel_streaming (one pass over 99990 rows = 1599840 KiB algorithmic).",
+    "workload": "nmost n=10, 100000 x 5000 bp, k=6",
+}
+for label in KERNELS.values():
+    f, w = fetch[label], write[label]
+    doc[label] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2 * f + w) * 1024}
+json.dump(doc, open("profiles/pmc_traffic.json", "w"), indent=1)
+print(json.dumps({k: doc[k] for k in KERNELS.values()}, indent=1))

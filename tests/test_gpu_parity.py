@@ -637,6 +637,76 @@ def test_final_merge_identity_labels_persistent_engine(ctx, brca1):
     np.testing.assert_allclose(got.members().delta_jsd, exp.members()[1], rtol=RTOL, atol=1e-13)
 
 
+def test_device_side_chunk_merge(ctx, brca1):
+    """the multi-GPU merge without a host round trip: dvs_select_gather_members into the
+    all_gather buffer, dvs_matrix_from_device_freqs on the gathered rows (padding rows of a short
+    chunk are skipped), final_nmost -- against the oracle's chunk + merge"""
+    import torch
+
+    from diverseseq_amd.parallel import _global_ids
+
+    seqs = list(brca1.values())
+    bounds = [(0, 25), (25, 28), (28, 55)]  # the middle chunk has fewer than n sequences
+    n, cap, k = 5, 5, 4
+    B = 4 ** k
+    dev = torch.device("cuda:0")
+    all_rows = torch.full((3 * cap, B), -7.0, dtype=torch.float64, device=dev)
+    all_meta = torch.full((3 * cap, 2), -7.0, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    erows, eids = [], []
+    for r, (a, b) in enumerate(bounds):
+        m = ctx.build_matrix(seqs[a:b], k, 4)
+        sel = m.nmost(min(n, b - a))
+        sel.gather_members(all_rows[r * cap:].data_ptr(), all_meta[r * cap:].data_ptr(), cap)
+        ctx.sync()
+        o = oracle.nmost(seqs[a:b], min(n, b - a), k, 4)
+        l, _, _, f = o.members(with_freqs=True)
+        erows.append(f)
+        eids.append(l + a)
+    erows, eids = np.vstack(erows), np.concatenate(eids)
+    meta = all_meta.cpu().numpy()
+    assert meta[:, 1].tolist() == [1] * 5 + [1] * 3 + [0] * 2 + [1] * 5
+    np.testing.assert_array_equal(all_rows.cpu().numpy()[meta[:, 1] != 0], erows)
+    assert not all_rows.cpu().numpy()[meta[:, 1] == 0].any()
+    gids = _global_ids(all_meta, [a for a, _ in bounds], cap)
+    assert gids[gids >= 0].tolist() == eids.tolist()
+    mm = ctx.matrix_from_device_freqs(all_rows.data_ptr(), 3 * cap, B, all_meta.data_ptr())
+    got = mm.nmost(n)
+    exp = oracle.final_nmost(erows, n, labels=eids)
+    gm = got.members()
+    assert [int(gids[p]) for p in gm.positions] == exp.members()[0].tolist()
+    np.testing.assert_allclose(gm.delta_jsd, exp.members()[1], rtol=RTOL, atol=1e-13)
+    np.testing.assert_allclose(got.summary().total_jsd, exp.total_jsd, rtol=RTOL)
+    with pytest.raises(ValueError, match="buffer of"):
+        sel.gather_members(all_rows.data_ptr(), all_meta.data_ptr(), 2)
+
+
+def test_merge_nmost_over_rccl_world1(ctx, brca1):
+    """parallel.merge_nmost end to end on the RCCL backend (world 1): device path == host path"""
+    import torch
+    import torch.distributed as dist
+
+    from diverseseq_amd.parallel import merge_nmost
+
+    seqs = list(brca1.values())
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29617", rank=0, world_size=1)
+    try:
+        m = ctx.build_matrix(seqs, 4, 4)
+        sel = m.nmost(6)
+        a = merge_nmost(ctx, sel, 6, 0, 1, 100, dev, chunk_starts=[100])
+        b = merge_nmost(ctx, sel, 6, 0, 1, 100, dev)
+        pa, pb = a.members(False).positions, b.members(False).positions
+        assert [int(a.global_ids[p]) for p in pa] == [int(b.global_ids[p]) for p in pb]
+        assert a.summary().total_jsd == b.summary().total_jsd
+        exp = oracle.final_nmost(oracle.nmost(seqs, 6, 4, 4).members(with_freqs=True)[3], 6)
+        assert pa.tolist() == exp.members()[0].tolist()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_large_sets_and_other_alphabets(ctx):
     """n beyond what the persistent engine replicates in LDS (multi-launch engine), a 20-state
     alphabet (k=2, 400 bins: not a multiple of 256) and a tiny one (3 states, k=3)"""
