@@ -15,26 +15,31 @@
 //     deterministically (same code, same reduction tree -> same bits, so no
 //     broadcast is needed): exact delta_jsd of the candidate, decision,
 //     replace_lowest, new total_jsd;
-//   * leave-one-out: workgroup r scores member r (get_lowest_record_index,
-//     src/records.rs:220-252); grid barrier; every workgroup reads the n scores,
+//   * leave-one-out as (n + 1) * K jobs over the workgroups (get_lowest_record_index,
+//     src/records.rs:220-252); grid barrier; every workgroup reads the job partials,
 //     takes the argmin, rebuilds sl in its LDS and scans on from the event + 1.
-//   * workgroup 0 additionally mirrors the state into the global SelDev / SelCtl
+//   * the LAST workgroup additionally mirrors the state into the global SelDev / SelCtl
 //     arrays (what the host reads back, and what the multi-launch kernels resume
-//     from).
+//     from) and takes no share of the scan.
 //
 // Two grid barriers per accepted event and none of the launch latencies.  Any decision
 // inside the rounding band stops the kernel with SEL_ARBITER; the host arbitrates and
 // runs that one event through the multi-launch kernels, then relaunches this one.
 //
-// Inter-workgroup protocol (MI355X: 8 XCDs, private L2s): a monotonic arrival counter;
-// barrier k is complete when it reaches G*k and the last arriver publishes gen = k.
-// Every workgroup: all waves drain (s_waitcnt vmcnt(0)), __syncthreads, lane 0 does an
-// agent-scope release, the counter add, polls gen relaxed with s_sleep, then an
-// agent-scope acquire, __syncthreads.  All polled words are agent-scope atomics and
-// are zeroed by the host before every launch; every spin is bounded (a grid that is
-// not fully resident ends with SEL_ERROR instead of hanging).
+// Inter-workgroup protocol (MI355X: 8 XCDs, private L2s).  Nothing a workgroup stores
+// with plain stores is read by another workgroup during the launch: the matrix, totals
+// and row entropies are read-only (a member's frequency row is re-derived from its matrix
+// row, whose position every workgroup keeps in LDS), the set state is replicated, and the
+// only words that cross workgroups -- the event words and the leave-one-out partials --
+// are agent-scope atomics whose RMW result the writer consumes before it arrives at the
+// barrier.  So the barrier needs no fences (no L2 write-back / invalidate), only a
+// rendezvous: two-level monotonic arrival counters (per group of blockIdx % 8, then one
+// top counter) and a generation word per group, all on their own cache lines, zeroed by
+// the host before every launch; every spin is bounded (a grid that is not fully resident
+// ends with SEL_ERROR instead of hanging).
 #include "select_dev.h"
 
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 
@@ -47,11 +52,16 @@ constexpr uint32_t P_MAXN = 512;            // members the LDS replica holds
 constexpr uint32_t P_JOBS = P_MAXN + 1;     // leave-one-out jobs per event: (n + 1) * K <= max(G - 1, n + 1)
 constexpr uint32_t P_SPIN_LIMIT = 1u << 22;  // ~0.5 s of polling
 
-struct PSync {  // every polled word on a cache line of its own (256 B apart)
-    uint32_t count;  // arrivals, monotonic over the launch
+struct PLine {  // a polled word on a cache line of its own (256 B apart)
+    uint32_t v;
+    uint32_t pad[63];
+};
+
+struct PSync {
+    uint32_t count;  // top-level arrivals (one per group and barrier), monotonic over the launch
     uint32_t pad0[63];
-    uint32_t gen;  // completed barriers
-    uint32_t pad1[63];
+    PLine gcount[8];  // arrivals of group g = blockIdx % 8 (workgroups are dealt round-robin to the 8 XCDs)
+    PLine ggen[8];    // completed barriers, one copy per group so 32 pollers share a line, not 256
     uint32_t timeout;
     uint32_t pad2[63];
     unsigned long long ev[3][32];  // event words, slot = epoch % 3 (ev[s][0])
@@ -70,26 +80,32 @@ struct PState {  // replicated scalars (identical in every workgroup)
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 // returns false on timeout (every thread of the block gets the same answer).
-// FENCED: this barrier hands plain-stored data between workgroups (release before the arrival,
-// acquire after the release of the barrier).  The barrier after the scan phase hands over
-// nothing but an agent-scope atomic word, so it runs unfenced: a pure rendezvous.
-template <bool FENCED>
+// Two levels: a workgroup arrives on its group's counter, the last of a group arrives on the top
+// counter, the last group publishes the generation to all eight group words.  Measured on MI355X
+// (scripts/micro/barrier_bench.hip, 256 workgroups): 1.9 us against 3.7 us for one counter + one
+// word -- the 256 same-address atomics serialise at ~11 ns each.
+// The barrier is a pure rendezvous: no fences.  Everything handed between workgroups across it
+// is an agent-scope atomic word whose RMW result the writer consumed before arriving (the event
+// words, the leave-one-out partials); the matrix is read-only for the whole launch, and what the
+// mirror block stores to global memory is read by nobody before the kernel ends.  (An agent-scope
+// release + acquire pair around the barrier -- L2 write-back and invalidate on every XCD -- cost
+// another 4 us per barrier.)
 __device__ bool grid_barrier(PSync *sync, uint32_t G, uint32_t &gen, int *s_ok) {
-    if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have left
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t target = gen + 1;
-        if (FENCED) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        const uint32_t old = __hip_atomic_fetch_add(&sync->count, 1u, RLX_AGENT);
+        const uint32_t x = blockIdx.x & 7u, ng = G < 8u ? G : 8u;
+        const uint32_t gsz = (G - x + 7u) >> 3;  // workgroups with blockIdx % 8 == x
         int ok = 1;
-        if (old == G * target - 1) {
-            __hip_atomic_store(&sync->gen, target, RLX_AGENT);
-        } else {
+        bool released = false;
+        if (__hip_atomic_fetch_add(&sync->gcount[x].v, 1u, RLX_AGENT) == gsz * target - 1 &&
+            __hip_atomic_fetch_add(&sync->count, 1u, RLX_AGENT) == ng * target - 1) {
+            for (uint32_t g = 0; g < ng; g++) __hip_atomic_store(&sync->ggen[g].v, target, RLX_AGENT);
+            released = true;
+        }
+        if (!released) {
             uint32_t spins = 0;
-            while (__hip_atomic_load(&sync->gen, RLX_AGENT) < target) {
+            while (__hip_atomic_load(&sync->ggen[x].v, RLX_AGENT) < target) {
                 if ((++spins & 255u) == 0 &&
                     (spins > P_SPIN_LIMIT || __hip_atomic_load(&sync->timeout, RLX_AGENT))) {
                     __hip_atomic_store(&sync->timeout, 1u, RLX_AGENT);
@@ -98,10 +114,6 @@ __device__ bool grid_barrier(PSync *sync, uint32_t G, uint32_t &gen, int *s_ok) 
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
-        }
-        if (FENCED) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         *s_ok = ok;
     }
@@ -201,11 +213,11 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
 }
 
 // LDS: [sl B f64][scratch 128 f64][s_mH P_MAXN f64][s_slot P_MAXN u32][s_dl, s_ds P_MAXN f64]
-//      [s_ph, s_ps, s_pm P_JOBS f64][flags]
+//      [s_ph, s_ps, s_pm P_JOBS f64][s_pos P_MAXN u64][flags]
 // CACHED: B <= P_J * 512, so a thread's share of the candidate row stays in registers
 template <typename T, bool CACHED>
 __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, const T *__restrict__ mat,
-                                                                    PSync *sync, double *part, uint32_t G) {
+                                                                    PSync *sync, unsigned long long *part, uint32_t G) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint64_t B = d.B;
     double *sl = reinterpret_cast<double *>(smem);
@@ -217,7 +229,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     double *s_ph = s_ds + P_MAXN;                                 // job partials: h, sum, min
     double *s_ps = s_ph + P_JOBS;
     double *s_pm = s_ps + P_JOBS;
-    int *s_flag = reinterpret_cast<int *>(s_pm + P_JOBS);
+    uint64_t *s_pos = reinterpret_cast<uint64_t *>(s_pm + P_JOBS);  // matrix row of each member
+    int *s_flag = reinterpret_cast<int *>(s_pos + P_MAXN);
     SelCtl *ctl = d.ctl;
     const int tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -244,6 +257,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     for (uint32_t r = tid; r < st.n; r += P_THREADS) {
         s_slot[r] = d.ord[r];
         s_mH[r] = d.mH[d.ord[r]];
+        s_pos[r] = d.mPos[d.ord[r]];
     }
     __syncthreads();
     {
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             p_scan_rows<T>(mat, d.totals, d.rowH, sl, B, st, st.sumH - s_mH[st.li], evp,
                            uint64_t(blockIdx.x) * wpb + wave, nwaves, nrows, lane, nread, nprecise);
         P_STAMP(0);
-        if (!grid_barrier<false>(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
+        if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
         P_STAMP(1);
         const uint64_t p = __hip_atomic_load(evp, RLX_AGENT);
         st.n_windows++;
@@ -371,9 +385,11 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             for (uint32_t i = li; i + 1 < n; i++) {  // Vec::remove + push
                 s_slot[i] = s_slot[i + 1];
                 s_mH[i] = s_mH[i + 1];
+                s_pos[i] = s_pos[i + 1];
             }
             s_slot[n - 1] = slot_low;
             s_mH[n - 1] = cand_H;
+            s_pos[n - 1] = p;
         }
         __syncthreads();
         st.sumH = scratch[127];
@@ -409,7 +425,11 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             const uint32_t r = job / K, part_i = job % K;
             const uint64_t lo = uint64_t(part_i) * Bs, hi = umin64(B, lo + Bs);
             const bool is_new = r == n - 1;
-            const double *mrow = d.M + uint64_t(r < n ? s_slot[r] : 0) * B;
+            // a member's frequency row = its (read-only) matrix row over its total, the very
+            // values d.M holds: no workgroup ever reads what another one stored during the launch
+            const uint64_t mp = r < n ? s_pos[r] : 0;
+            const T *mrow = mat + mp * B;
+            const double mtot = double(d.totals[mp]);
             double h = 0.0, sv = 0.0, mn = 0.0;
             for (uint64_t i = lo + tid; i < hi; i += P_THREADS) {
                 double v = sl[i];
@@ -420,7 +440,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 if (r == n) {
                     u = sn * rn;
                 } else {
-                    u = (sn - (is_new ? f : mrow[i])) * rdiv;
+                    u = (sn - (is_new ? f : cand_freq(mrow, i, mtot))) * rdiv;
                     if (u <= DVS_EPS) u = 0.0;
                 }
                 if (u > 0.0) h -= u * log2_acc(u);
@@ -428,11 +448,12 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 mn = fmin(mn, u);
             }
             block_red3(h, mn, sv, scratch);
-            if (tid == 0) {
-                double *pp = part + uint64_t(job) * 4;
-                pp[0] = h;
-                pp[1] = sv;
-                pp[2] = mn;
+            if (tid == 0) {  // three exchanges in flight, results consumed before the arrival below
+                unsigned long long *pp = part + uint64_t(job) * 4;
+                const unsigned long long o0 = __hip_atomic_exchange(pp, (unsigned long long)__double_as_longlong(h), RLX_AGENT);
+                const unsigned long long o1 = __hip_atomic_exchange(pp + 1, (unsigned long long)__double_as_longlong(sv), RLX_AGENT);
+                const unsigned long long o2 = __hip_atomic_exchange(pp + 2, (unsigned long long)__double_as_longlong(mn), RLX_AGENT);
+                if ((o0 & o1 & o2) == 0x7ff8dead0000beefull) sync->pad0[2] = 1;  // (never: consumes them)
             }
         }
         st.cursor = p + 1;
@@ -453,15 +474,15 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             ctl->ev_n = n;
         }
         P_STAMP(3);
-        if (!grid_barrier<true>(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
+        if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
         P_STAMP(4);
         // ================= combine: one load per job (a single memory round trip), then the K
         // partials of each r are added in job order by one thread -> same bits in every workgroup
         for (uint32_t j = tid; j < jobs; j += P_THREADS) {
-            const double *pp = part + uint64_t(j) * 4;
-            s_ph[j] = pp[0];
-            s_ps[j] = pp[1];
-            s_pm[j] = pp[2];
+            const unsigned long long *pp = part + uint64_t(j) * 4;
+            s_ph[j] = __longlong_as_double((long long)__hip_atomic_load(pp, RLX_AGENT));
+            s_ps[j] = __longlong_as_double((long long)__hip_atomic_load(pp + 1, RLX_AGENT));
+            s_pm[j] = __longlong_as_double((long long)__hip_atomic_load(pp + 2, RLX_AGENT));
         }
         __syncthreads();
         for (uint32_t r = tid; r <= n; r += P_THREADS) {
@@ -575,7 +596,9 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         st.thr = st.total_jsd + DVS_EPS;
         {   // sl <- S_new - new lowest, in place (each thread owns its bins)
             const bool low_is_new = lowest == n - 1;
-            const double *lrow = d.M + uint64_t(s_slot[lowest]) * B;
+            const uint64_t lp = s_pos[lowest];
+            const T *lrow = mat + lp * B;
+            const double ltot = double(d.totals[lp]);
             for (uint64_t b0 = 0; b0 < B; b0 += uint64_t(P_J) * P_THREADS) {
 #pragma unroll
                 for (int j = 0; j < P_J; j++) {
@@ -585,7 +608,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                         if (v <= DVS_EPS) v = 0.0;
                         const double f = CACHED ? fr[j] : cand_freq(rp, i, tot);
                         const double sn = v + f;
-                        const double nv = sn - (low_is_new ? f : lrow[i]);
+                        const double nv = sn - (low_is_new ? f : cand_freq(lrow, i, ltot));
                         sl[i] = nv;
                         if (lead) d.base[i] = nv / dn;
                     }
@@ -659,11 +682,11 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     if (d.B <= uint64_t(P_J) * P_THREADS)
         hipLaunchKernelGGL((persist_nmost_kernel<T, true>), dim3(s->persist_grid), dim3(P_THREADS),
                            s->persist_lds, ctx->stream, d, mat, static_cast<PSync *>(s->psync),
-                           static_cast<double *>(s->ppart), s->persist_grid);
+                           static_cast<unsigned long long *>(s->ppart), s->persist_grid);
     else
         hipLaunchKernelGGL((persist_nmost_kernel<T, false>), dim3(s->persist_grid), dim3(P_THREADS),
                            s->persist_lds, ctx->stream, d, mat, static_cast<PSync *>(s->psync),
-                           static_cast<double *>(s->ppart), s->persist_grid);
+                           static_cast<unsigned long long *>(s->ppart), s->persist_grid);
     if (s->time_scan) (void)hipEventRecord(e1, ctx->stream);
     DVS_HIP(ctx, hipGetLastError());
     return DVS_OK;
@@ -675,7 +698,7 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     if (getenv("DVS_NO_PERSIST")) return DVS_OK;
     if (s->params.mode != DVS_MODE_NMOST || !s->h_order.empty() || !s->h_labels.empty()) return DVS_OK;
     if (s->cap > P_MAXN) return DVS_OK;
-    const size_t lds = ((B + 1) & ~1ull) * 8 + 128 * 8 + P_MAXN * 28 + P_JOBS * 24 + 64;
+    const size_t lds = ((B + 1) & ~1ull) * 8 + 128 * 8 + P_MAXN * 36 + P_JOBS * 24 + 64;
     if (lds > ctx->lds_per_block || lds > 150 * 1024) return DVS_OK;
     s->persist_lds = lds;
     s->persist_grid = uint32_t(ctx->n_cu);  // one 512-thread workgroup per CU: all resident
@@ -698,6 +721,8 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     s->persist = true;
     return DVS_OK;
 }
+
+size_t dvs_persist_dbg_offset(void) { return offsetof(PSync, dbg2); }  // dbg2[8] then dbg[8]
 
 int dvs_persist_launch(dvs_ctx *ctx, dvs_select *s) {
     return s->mat_kind == 0 ? persist_launch<uint32_t>(ctx, s, s->mat->d_counts)

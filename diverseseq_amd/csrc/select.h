@@ -108,3 +108,4 @@ void dvs_select_arbiter_free(dvs_select *s);
 // persist.hip
 int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s);
 int dvs_persist_launch(dvs_ctx *ctx, dvs_select *s);
+size_t dvs_persist_dbg_offset(void);

@@ -874,8 +874,7 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat) {
         }
         if (s->persist && s->psync && getenv("DVS_PERSIST_DEBUG")) {
             unsigned long long dbg[16];
-            // PSync: 3 x 256 B of polled words, 3 x 256 B of event slots, then dbg2[8], dbg[8]
-            if (hipMemcpy(dbg, static_cast<char *>(s->psync) + 6 * 256, sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (hipMemcpy(dbg, static_cast<char *>(s->psync) + dvs_persist_dbg_offset(), sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
                 for (int w = 0; w < 2; w++)
                     fprintf(stderr, "[dvs persist %s] us: scan %.1f bar1 %.1f resolve %.1f loo %.1f bar2 %.1f finalize %.1f\n",
                             w ? "mirror block" : "block 0", dbg[0 + 8 * w] / 100.0, dbg[1 + 8 * w] / 100.0,
