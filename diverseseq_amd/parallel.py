@@ -181,3 +181,57 @@ def nmost_exact(ctx, matrix, order: np.ndarray, n: int, device, world: int, *, w
             if world > 1:
                 dist.all_reduce(row, op=dist.ReduceOp.SUM)
             ctx.check(L.dvs_select_step_apply(ctx._h, sel._h, C.c_void_p(row.data_ptr())))
+
+
+# ---------------------------------------------------------------------------------------
+# ctree distances over ranks (diverse_seq/cluster.py:607-644 `dvs_par_ctree`):
+# each rank sketches its contiguous share of the sequences, ONE all_gather hands every rank
+# all N sketches (N x s u32; 12 MB at N=1000, s=3000), rank g fills rows g, g+G, ... of the
+# lower triangle (the reference's stride, which balances the triangle), and a SUM all-reduce
+# of the N x N f64 assembles it; symmetrise as cluster.py:294 does (D + D^T - diag).
+def mash_distances_sharded(seqs, k: int, sketch_size: int, rank: int, world: int, device, *,
+                           num_states: int = 4, mash_canonical: bool = False,
+                           sketcher=None, pair_rows=None) -> np.ndarray:
+    """`seqs`: the full list (every rank sees the store, as the reference's workers do); only
+    this rank's chunk is sketched here.  `sketcher(chunk) -> (uint32 [m, stride], uint32 [m])`
+    and `pair_rows(sk, lens, row_start, row_stride) -> N x N lower-triangle rows` default to the
+    HIP kernels (dvs_mash_sketch / dvs_mash_distances); the CPU tests inject the oracle."""
+    import torch
+    import torch.distributed as dist
+
+    from . import distance
+
+    n = len(seqs)
+    if sketcher is None:
+        def sketcher(chunk):
+            return distance.sketch_batch(chunk, k, sketch_size, num_states, mash_canonical)
+    if pair_rows is None:
+        def pair_rows(sk, lens, row_start, row_stride):
+            return distance.distances_from_sketches(sk, lens, k, sketch_size, row_start=row_start,
+                                                    row_stride=row_stride, symmetric=False)
+    longest = max((len(s) for s in seqs), default=0) - k + 1
+    stride = max(1, min(int(sketch_size), max(0, longest)))  # same on every rank
+    bounds = chunk_bounds(n, world)
+    lo, hi = bounds[rank]
+    cap = max(1, max(e - s for s, e in bounds))
+    sk_pad = np.zeros((cap, stride), dtype=np.uint32)
+    len_pad = np.zeros(cap, dtype=np.int32)
+    if hi > lo:
+        sk, lens = sketcher(seqs[lo:hi])
+        sk_pad[: hi - lo, : sk.shape[1]] = sk[:, :stride]
+        len_pad[: hi - lo] = lens
+    t_sk = torch.from_numpy(sk_pad.view(np.int32)).to(device)
+    t_len = torch.from_numpy(len_pad).to(device)
+    all_sk = torch.empty((world * cap, stride), dtype=torch.int32, device=device)
+    all_len = torch.empty((world * cap,), dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(all_sk, t_sk)
+    dist.all_gather_into_tensor(all_len, t_len)
+    all_sk = all_sk.cpu().numpy().view(np.uint32).reshape(world, cap, stride)
+    all_len = all_len.cpu().numpy().astype(np.uint32).reshape(world, cap)
+    sk_all = np.concatenate([all_sk[r, : e - s] for r, (s, e) in enumerate(bounds)])
+    len_all = np.concatenate([all_len[r, : e - s] for r, (s, e) in enumerate(bounds)])
+    part = pair_rows(sk_all, len_all, rank, world)  # rows rank, rank + world, ...
+    t_d = torch.from_numpy(np.ascontiguousarray(part)).to(device)
+    dist.all_reduce(t_d, op=dist.ReduceOp.SUM)  # every entry is written by exactly one rank
+    lower = t_d.cpu().numpy()
+    return lower + lower.T - np.diag(np.diag(lower))

@@ -624,6 +624,52 @@ def test_exact_row_sharded_mode(world):
     assert res[0][1:] == res[-1][1:]  # replicas are bit-identical
 
 
+def _mash_shard_worker(rank, world, port, q):
+    import os
+    import sys
+
+    sys.path.insert(0, str(__import__("conftest").ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+
+    from diverseseq_amd import parallel
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seqs = synth_seqs(41, 3000, 77, invalid_frac=0.002, ragged=True)
+    d = parallel.mash_distances_sharded(seqs, 10, 200, rank, world, torch.device("cpu"),
+                                        mash_canonical=True)
+    q.put((rank, d))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_sharded_mash_distances(world):
+    """ctree over ranks on the HIP kernels: chunked dvs_mash_sketch, all_gather,
+    strided dvs_mash_distances rows, SUM all-reduce == one-process matrix == oracle"""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_mash_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seqs = synth_seqs(41, 3000, 77, invalid_frac=0.002, ragged=True)
+    exp = oracle.mash_distances([oracle.mash_sketch(x, 10, 200, 4, True) for x in seqs], 10, 200)
+    for _, d in res:
+        np.testing.assert_allclose(d, exp, rtol=1e-12, atol=0)
+    np.testing.assert_array_equal(res[0][1], res[-1][1])
+
+
 def test_final_merge_identity_labels_persistent_engine(ctx, brca1):
     """frequency-row matrix + identity labels: the persistent engine's f64-row instantiation"""
     seqs = list(brca1.values())

@@ -78,3 +78,62 @@ def test_gather_and_merge_world2():
         assert got_ids == ids[epos].tolist()
         assert got_delta == edelta.tolist()
         assert got_total == exp.total_jsd
+
+
+def _mash_worker(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+
+    import oracle
+    from diverseseq_amd import parallel
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seqs = synth_seqs(23, 400, 5, ragged=True)
+    k, s = 8, 64
+
+    def sketcher(chunk):
+        sk = np.zeros((len(chunk), s), dtype=np.uint32)
+        lens = np.zeros(len(chunk), dtype=np.uint32)
+        for i, x in enumerate(chunk):
+            h = oracle.mash_sketch(x, k, s)
+            sk[i, : len(h)] = h
+            lens[i] = len(h)
+        return sk, lens
+
+    def pair_rows(sk, lens, row_start, row_stride):
+        n = sk.shape[0]
+        out = np.zeros((n, n))
+        for i in range(row_start, n, row_stride):  # cluster.py:640-644
+            for j in range(i):
+                out[i, j] = oracle.mash_distance(sk[i, : lens[i]], sk[j, : lens[j]], k, s)
+        return out
+
+    d = parallel.mash_distances_sharded(seqs, k, s, rank, world, torch.device("cpu"),
+                                        sketcher=sketcher, pair_rows=pair_rows)
+    q.put((rank, d))
+    dist.destroy_process_group()
+
+
+def test_sharded_mash_distances_world2():
+    """ctree over ranks: chunked sketching, all_gather, strided triangle rows,
+    SUM all-reduce, symmetrise == the one-process matrix"""
+    import torch.multiprocessing as mp
+
+    import oracle
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mash_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=90) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seqs = synth_seqs(23, 400, 5, ragged=True)
+    exp = oracle.mash_distances([oracle.mash_sketch(x, 8, 64) for x in seqs], 8, 64)
+    for _, d in res:
+        np.testing.assert_array_equal(d, exp)
