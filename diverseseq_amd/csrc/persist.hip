@@ -39,6 +39,7 @@
 // ends with SEL_ERROR instead of hanging).
 #include "select_dev.h"
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
@@ -48,8 +49,11 @@ namespace {
 constexpr int P_THREADS = 512;
 constexpr int P_J = 8;                      // bins per thread kept in registers (B <= 4096)
 constexpr int P_CH = 16;                    // row chunks requested per burst (4096 bins)
-constexpr uint32_t P_MAXN = 512;            // members the LDS replica holds
-constexpr uint32_t P_JOBS = P_MAXN + 1;     // leave-one-out jobs per event: (n + 1) * K <= max(G - 1, n + 1)
+constexpr uint32_t P_MAXN = 512;            // members the LDS replica holds when 4^k <= 4096 ...
+constexpr uint32_t P_MAXN_BIG = 256;        // ... and beyond (k = 7: 128 KB of LDS go to the set state)
+constexpr uint32_t p_maxn(bool cached) { return cached ? P_MAXN : P_MAXN_BIG; }
+// leave-one-out jobs per event: (n + 1) * K <= max(G - 1, n + 1) <= maxn + 1 (G <= maxn + 2 is checked)
+constexpr uint32_t p_maxjobs(bool cached) { return p_maxn(cached) + 1; }
 constexpr uint32_t P_SPIN_LIMIT = 1u << 22;  // ~0.5 s of polling
 
 struct PLine {  // a polled word on a cache line of its own (256 B apart)
@@ -212,25 +216,82 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
     }
 }
 
-// LDS: [sl B f64][scratch 128 f64][s_mH P_MAXN f64][s_slot P_MAXN u32][s_dl, s_ds P_MAXN f64]
-//      [s_ph, s_ps, s_pm P_JOBS f64][s_pos P_MAXN u64][flags]
+// argmin (strict '<' from 1e6, first index), runner-up, mean and standard deviation of the
+// members' delta_jsd by ONE wave: lane l owns members l, l + 64, ... (Q per lane; re-read from LDS
+// in every pass when Q > 1 -- registers are the scan loop's).
+// scratch[100..105] = min, index, second, mean, sd, any-risky.
+template <uint32_t Q>
+__device__ __forceinline__ void p_argmin(const double *s_dl, const double *s_ds, uint32_t n, uint64_t B,
+                                         uint32_t lane, double *scratch) {
+    const double v0 = lane < n ? s_dl[lane] : 1e6;
+    auto val = [&](uint32_t q) { return (Q == 1 || q == 0) ? v0 : s_dl[lane + 64 * q]; };
+    double best = 1e6, acc = 0.0;
+    bool rk = false;
+#pragma unroll
+    for (uint32_t q = 0; q < Q; q++) {
+        const uint32_t r = lane + 64 * q;
+        if (r < n) {
+            const double v = val(q);
+            rk |= sum_risky(s_ds[r], B);
+            acc += v;
+            if (v < best) best = v;
+        }
+    }
+    const double dn = double(n);
+    const double mnv = dvs_wave_min(best);
+    double fi = 4294967295.0;
+#pragma unroll
+    for (uint32_t q = 0; q < Q; q++)
+        if (mnv < 1e6 && lane + 64 * q < n && val(q) == mnv) fi = fmin(fi, double(lane + 64 * q));
+    const double first = dvs_wave_min(fi);
+    const uint32_t lw = (first < 4294967295.0) ? uint32_t(first) : 0u;
+    const double mu = dvs_wave_sum(acc) / dn;
+    double sec = 1e6, tv = 0.0;
+#pragma unroll
+    for (uint32_t q = 0; q < Q; q++) {
+        const uint32_t r = lane + 64 * q;
+        if (r < n) {
+            const double v = val(q);
+            if (r != lw && v < sec) sec = v;
+            const double t = v - mu;
+            tv += t * t;
+        }
+    }
+    sec = dvs_wave_min(sec);
+    const double var = dvs_wave_sum(tv);
+    const unsigned long long anyr = __ballot(rk);
+    if (lane == 0) {
+        scratch[100] = mnv;
+        scratch[101] = double(lw);
+        scratch[102] = sec;
+        scratch[103] = mu;
+        scratch[104] = sqrt(var / (dn - 1.0));
+        scratch[105] = anyr ? 1.0 : 0.0;
+    }
+}
+
+// LDS: [sl B f64][scratch 128 f64][s_mH maxn f64][s_slot maxn u32][s_dl, s_ds maxn f64]
+//      [s_ph, s_ps, s_pm maxjobs f64][s_pos maxn u64][flags]
+// maxn / maxjobs = p_maxn(CACHED) / p_maxjobs(CACHED): compile-time offsets (runtime ones cost
+// registers the scan loop needs), smaller beyond 4096 bins so that 4^7 bins (128 KB of sl) still fit.
 // CACHED: B <= P_J * 512, so a thread's share of the candidate row stays in registers
 template <typename T, bool CACHED>
 __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, const T *__restrict__ mat,
                                                                     PSync *sync, unsigned long long *part, uint32_t G) {
+    constexpr uint32_t maxn = p_maxn(CACHED), maxjobs = p_maxjobs(CACHED);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint64_t B = d.B;
     double *sl = reinterpret_cast<double *>(smem);
     double *scratch = sl + ((B + 1) & ~1ull);
     double *s_mH = scratch + 128;
-    uint32_t *s_slot = reinterpret_cast<uint32_t *>(s_mH + P_MAXN);
-    double *s_dl = reinterpret_cast<double *>(s_slot + P_MAXN);  // delta_jsd per member
-    double *s_ds = s_dl + P_MAXN;                                 // sum of each member's mean vector
-    double *s_ph = s_ds + P_MAXN;                                 // job partials: h, sum, min
-    double *s_ps = s_ph + P_JOBS;
-    double *s_pm = s_ps + P_JOBS;
-    uint64_t *s_pos = reinterpret_cast<uint64_t *>(s_pm + P_JOBS);  // matrix row of each member
-    int *s_flag = reinterpret_cast<int *>(s_pos + P_MAXN);
+    uint32_t *s_slot = reinterpret_cast<uint32_t *>(s_mH + maxn);
+    double *s_dl = reinterpret_cast<double *>(s_slot + maxn);  // delta_jsd per member
+    double *s_ds = s_dl + maxn;                                 // sum of each member's mean vector
+    double *s_ph = s_ds + maxn;                                 // job partials: h, sum, min
+    double *s_ps = s_ph + maxjobs;
+    double *s_pm = s_ps + maxjobs;
+    uint64_t *s_pos = reinterpret_cast<uint64_t *>(s_pm + maxjobs);  // matrix row of each member
+    int *s_flag = reinterpret_cast<int *>(s_pos + maxn);
     SelCtl *ctl = d.ctl;
     const int tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -253,7 +314,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     st.band = ctl->band;
     st.wscale = ctl->wscale;
     st.n_windows = st.n_events = st.n_accepts = 0;
-    if (ctl->status != SEL_RUN || ctl->ev_kind != 0 || st.n > P_MAXN || st.n < 2) return;
+    if (ctl->status != SEL_RUN || ctl->ev_kind != 0 || st.n > maxn || st.n < 2) return;
     for (uint32_t r = tid; r < st.n; r += P_THREADS) {
         s_slot[r] = d.ord[r];
         s_mH[r] = d.mH[d.ord[r]];
@@ -378,18 +439,36 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         const uint32_t slot_low = s_slot[li];
         const uint32_t old_lab = lead ? d.mLabel[slot_low] : 0;
         __syncthreads();
-        if (tid == 0) {
-            double sh = st.sumH - s_mH[li];
-            sh += cand_H;
-            scratch[127] = sh;
-            for (uint32_t i = li; i + 1 < n; i++) {  // Vec::remove + push
-                s_slot[i] = s_slot[i + 1];
-                s_mH[i] = s_mH[i + 1];
-                s_pos[i] = s_pos[i + 1];
+        {   // Vec::remove(li) + push: every thread moves its members one place down
+            uint32_t mv_slot[(maxn + P_THREADS - 1) / P_THREADS];
+            double mv_H[(maxn + P_THREADS - 1) / P_THREADS];
+            uint64_t mv_pos[(maxn + P_THREADS - 1) / P_THREADS];
+#pragma unroll
+            for (uint32_t q = 0; q < (maxn + P_THREADS - 1) / P_THREADS; q++) {
+                const uint32_t i = li + q * P_THREADS + tid;
+                if (i + 1 < n) {
+                    mv_slot[q] = s_slot[i + 1];
+                    mv_H[q] = s_mH[i + 1];
+                    mv_pos[q] = s_pos[i + 1];
+                }
             }
-            s_slot[n - 1] = slot_low;
-            s_mH[n - 1] = cand_H;
-            s_pos[n - 1] = p;
+            const double sh = (st.sumH - s_mH[li]) + cand_H;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t q = 0; q < (maxn + P_THREADS - 1) / P_THREADS; q++) {
+                const uint32_t i = li + q * P_THREADS + tid;
+                if (i + 1 < n) {
+                    s_slot[i] = mv_slot[q];
+                    s_mH[i] = mv_H[q];
+                    s_pos[i] = mv_pos[q];
+                }
+            }
+            if (tid == 0) {
+                scratch[127] = sh;
+                s_slot[n - 1] = slot_low;
+                s_mH[n - 1] = cand_H;
+                s_pos[n - 1] = p;
+            }
         }
         __syncthreads();
         st.sumH = scratch[127];
@@ -457,11 +536,12 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             }
         }
         st.cursor = p + 1;
+        if (lead)
+            for (uint32_t i = tid; i < n; i += P_THREADS) d.ord[i] = s_slot[i];
         if (lead && tid == 0) {  // post-resolve mirror (what resolve_kernel leaves behind)
             ctl->sum_entropy = st.sumH;
             if (old_lab < d.nlabels) d.inset[old_lab] = 0;
             if (uint32_t(p) < d.nlabels) d.inset[uint32_t(p)] = 1;
-            for (uint32_t i = 0; i < n; i++) d.ord[i] = s_slot[i];
             d.mH[slot_low] = cand_H;
             d.mLabel[slot_low] = uint32_t(p);
             d.mPos[slot_low] = p;
@@ -517,72 +597,20 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             }
         }
         // ================= finalize (every workgroup): argmin, strict '<' from 1e6
-        uint32_t lowest;
-        double dmin, dsecond, mean, sd;
-        int any_risky;
-        if (n <= 64) {  // one wave holds every score: shuffles only, one barrier to share
-            if (wave == 0) {
-                const bool on = lane < n;
-                const double v = on ? s_dl[lane] : NAN;
-                const bool rk = on && sum_risky(s_ds[lane], B);
-                const double vb = (on && v < 1e6) ? v : 1e6;
-                const double mnv = dvs_wave_min(vb);
-                const double fi = (mnv < 1e6 && on && v == mnv) ? double(lane) : 4294967295.0;
-                const double first = dvs_wave_min(fi);
-                const uint32_t lw = (first < 4294967295.0) ? uint32_t(first) : 0u;
-                const double sec = dvs_wave_min((on && lane != lw && v < 1e6) ? v : 1e6);
-                const double mu = dvs_wave_sum(on ? v : 0.0) / dn;
-                const double t = on ? v - mu : 0.0;
-                const double var = dvs_wave_sum(t * t);
-                const unsigned long long anyr = __ballot(rk);
-                if (lane == 0) {
-                    scratch[100] = mnv;
-                    scratch[101] = double(lw);
-                    scratch[102] = sec;
-                    scratch[103] = mu;
-                    scratch[104] = sqrt(var / (dn - 1.0));
-                    scratch[105] = anyr ? 1.0 : 0.0;
-                }
-            }
-            __syncthreads();
-            dmin = scratch[100];
-            lowest = uint32_t(scratch[101]);
-            dsecond = scratch[102];
-            mean = scratch[103];
-            sd = scratch[104];
-            any_risky = scratch[105] != 0.0;
-            __syncthreads();
-        } else {
-            bool risky = false;
-            double best = 1e6;
-            for (uint32_t r = tid; r < n; r += P_THREADS) {
-                const double v = s_dl[r];
-                if (sum_risky(s_ds[r], B)) risky = true;
-                if (v < best) best = v;
-            }
-            dmin = dvs_block_min(best, scratch);
-            double fi = 4294967295.0;
-            for (uint32_t r = tid; r < n; r += P_THREADS)
-                if (dmin < 1e6 && s_dl[r] == dmin) fi = fmin(fi, double(r));
-            const double dfirst = dvs_block_min(fi, scratch);
-            lowest = (dfirst < 4294967295.0) ? uint32_t(dfirst) : 0u;
-            double second = 1e6;
-            for (uint32_t r = tid; r < n; r += P_THREADS) {
-                const double v = s_dl[r];
-                if (r != lowest && v < second) second = v;
-            }
-            dsecond = dvs_block_min(second, scratch);
-            any_risky = __syncthreads_or(risky ? 1 : 0);
-            double acc = 0.0;
-            for (uint32_t r = tid; r < n; r += P_THREADS) acc += s_dl[r];
-            mean = dvs_block_sum(acc, scratch) / dn;
-            acc = 0.0;
-            for (uint32_t r = tid; r < n; r += P_THREADS) {
-                const double t = s_dl[r] - mean;
-                acc += t * t;
-            }
-            sd = sqrt(dvs_block_sum(acc, scratch) / (dn - 1.0));
+        // one wave holds every score (lane l owns members l, l + 64, ...): shuffles only, one
+        // barrier to share the result
+        if (wave == 0) {
+            if (n <= 64) p_argmin<1>(s_dl, s_ds, n, B, lane, scratch);
+            else p_argmin<(maxn + 63) / 64>(s_dl, s_ds, n, B, lane, scratch);
         }
+        __syncthreads();
+        const double dmin = scratch[100];
+        const uint32_t lowest = uint32_t(scratch[101]);
+        const double dsecond = scratch[102];
+        const double mean = scratch[103];
+        const double sd = scratch[104];
+        const int any_risky = scratch[105] != 0.0;
+        __syncthreads();
         const double band = sel_band(st.total_jsd + st.sumH / dn, B);
         if (any_risky || ev_risky || (n > 1 && dsecond - dmin <= band && dsecond < 1e6)) {
             exit_status = SEL_ARBITER;  // argmin too close to call: loo + finalize kernels resume
@@ -697,12 +725,15 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     s->persist = false;
     if (getenv("DVS_NO_PERSIST")) return DVS_OK;
     if (s->params.mode != DVS_MODE_NMOST || !s->h_order.empty() || !s->h_labels.empty()) return DVS_OK;
-    if (s->cap > P_MAXN) return DVS_OK;
-    const size_t lds = ((B + 1) & ~1ull) * 8 + 128 * 8 + P_MAXN * 36 + P_JOBS * 24 + 64;
-    if (lds > ctx->lds_per_block || lds > 150 * 1024) return DVS_OK;
-    s->persist_lds = lds;
     s->persist_grid = uint32_t(ctx->n_cu);  // one 512-thread workgroup per CU: all resident
     const bool cached = B <= uint64_t(P_J) * P_THREADS;
+    s->persist_maxn = p_maxn(cached);
+    s->persist_maxjobs = p_maxjobs(cached);
+    if (s->cap > s->persist_maxn || s->persist_grid > s->persist_maxjobs + 1) return DVS_OK;
+    const size_t lds = ((B + 1) & ~1ull) * 8 + 128 * 8 + size_t(s->persist_maxn) * 36 +
+                       size_t(s->persist_maxjobs) * 24 + 64;
+    if (lds > ctx->lds_per_block) return DVS_OK;
+    s->persist_lds = lds;
     const void *fn =
         s->mat_kind == 0
             ? (cached ? reinterpret_cast<const void *>(persist_nmost_kernel<uint32_t, true>)
@@ -714,9 +745,8 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
         DVS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         set_lds[fn] = lds;
     }
-    if (uint32_t(ctx->n_cu) > P_JOBS) return DVS_OK;  // jobs <= max(G - 1, n + 1) must fit the LDS arrays
     int rc = dvs_dev_alloc(ctx, &s->psync, sizeof(PSync), "persistent sync block");
-    if (!rc) rc = dvs_dev_alloc(ctx, &s->ppart, size_t(P_JOBS) * 4 * sizeof(double), "leave-one-out partials");
+    if (!rc) rc = dvs_dev_alloc(ctx, &s->ppart, size_t(s->persist_maxjobs) * 4 * sizeof(double), "leave-one-out partials");
     if (rc) return rc;
     s->persist = true;
     return DVS_OK;

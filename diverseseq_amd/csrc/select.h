@@ -85,7 +85,7 @@ struct dvs_select {
     bool fused = false;  // resolve + leave-one-out + finalize in one launch (small sets)
     // persistent single-launch engine (persist.hip)
     bool persist = false;
-    uint32_t persist_grid = 0;
+    uint32_t persist_grid = 0, persist_maxn = 0, persist_maxjobs = 0;
     size_t persist_lds = 0;
     void *psync = nullptr;
     void *ppart = nullptr;

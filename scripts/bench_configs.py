@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""The BASELINE.json configurations that fit one MI355X, one JSON line each:
+C2 (10k x 2 kb, k=6, nmost n=10 / n=100), C3 scaled (1050 genomes of ~3 Mb, k=6, `max`
+min_size=100), C4's per-GPU share and its whole input on one GPU (k=7, n=100), the north-star
+shape at n=100, and C5 (1000 x 3 Mb mash sketches, k=12, s=3000, + the N x N distances).
+Synthetic uniform DNA generated on the device; sequences resident in HBM when the clock starts
+(the headline metric's rule); side numbers, not the bench.py metric."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from diverseseq_amd import _lib, distance, engine  # noqa: E402
+
+dev = torch.device("cuda:0")
+ctx = engine.Context(0)
+
+
+def synth(nseq, lo, hi, seed):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(lo, hi + 1, size=nseq, dtype=np.int64) if hi > lo else np.full(nseq, lo, np.int64)
+    offsets = np.zeros(nseq + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    total = int(offsets[-1])
+    seqs = torch.randint(0, 4, (total + 16,), dtype=torch.uint8, device=dev, generator=g)
+    torch.cuda.synchronize()
+    return seqs, offsets
+
+
+def timed(fn, reps):
+    fn()
+    ctx.sync()
+    t = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        ctx.sync()
+        t.append(time.perf_counter() - t0)
+    return min(t), out
+
+
+def select_case(name, nseq, lo, hi, k, mode, reps=3, **kw):
+    seqs, offsets = synth(nseq, lo, hi, 20260421 + len(name))
+
+    def run():
+        m = ctx.build_matrix_device(seqs.data_ptr(), offsets, k, 4)
+        sel = m.nmost(kw["n"]) if mode == "nmost" else m.max_divergent(kw["min_size"], nseq, "stdev")
+        s = sel.summary()
+        out = dict(size=s.size, accepts=s.n_accepts, rows_scored=s.rows_scored, engine=s.engine,
+                   arbitrations=s.n_arbitrated, total_jsd=s.total_jsd)
+        sel.close()
+        m.close()
+        return out
+
+    dt, out = timed(run, reps)
+    rec = dict(config=name, nseq=nseq, length=[lo, hi], k=k, mode=mode, **kw, ms=round(dt * 1e3, 3),
+               sequences_per_s=round(nseq / dt), gbases_per_s=round(float(offsets[-1]) / dt / 1e9, 2), **out)
+    print(json.dumps(rec), flush=True)
+    del seqs
+    torch.cuda.empty_cache()
+
+
+def mash_case(name, nseq, lo, hi, k, s, canonical, reps=2):
+    seqs, offsets = synth(nseq, lo, hi, 777)
+    sk = np.zeros((nseq, s), dtype=np.uint32)
+    lens = np.zeros(nseq, dtype=np.uint32)
+
+    def sketch():
+        ctx.check(ctx._L.dvs_mash_sketch(ctx._h, C.c_void_p(seqs.data_ptr()), 1, _lib.ptr(offsets, C.c_uint64),
+                                         nseq, k, s, 4, int(canonical), _lib.ptr(sk, C.c_uint32),
+                                         _lib.ptr(lens, C.c_uint32)))
+
+    dt_s, _ = timed(sketch, reps)
+    dt_p, d = timed(lambda: distance.distances_from_sketches(sk, lens, k, s, ctx=ctx), reps)
+    rec = dict(config=name, nseq=nseq, length=[lo, hi], k=k, sketch_size=s, canonical=canonical,
+               sketch_ms=round(dt_s * 1e3, 2), gbases_per_s=round(float(offsets[-1]) / dt_s / 1e9, 2),
+               pairs=nseq * (nseq - 1) // 2, pairs_ms=round(dt_p * 1e3, 2),
+               mean_distance=float(d[np.tril_indices(nseq, -1)].mean()))
+    print(json.dumps(rec), flush=True)
+    del seqs
+    torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    which = set(sys.argv[1:])
+    def want(n):
+        return not which or n in which
+    if want("C2"):
+        select_case("C2 n=10", 10_000, 2000, 2000, 6, "nmost", n=10)
+        select_case("C2 n=100", 10_000, 2000, 2000, 6, "nmost", n=100)
+    if want("NS"):
+        select_case("north-star n=10", 100_000, 5000, 5000, 6, "nmost", n=10)
+        select_case("north-star n=100", 100_000, 5000, 5000, 6, "nmost", n=100)
+    if want("C4"):
+        select_case("C4 per-GPU share (1/8)", 12_500, 5000, 5000, 7, "nmost", n=100)
+        select_case("C4 whole input, 1 GPU", 100_000, 5000, 5000, 7, "nmost", n=100)
+    if want("C3"):
+        select_case("C3 scaled (1050 genomes)", 1050, 2_500_000, 3_500_000, 6, "max", reps=2, min_size=100)
+    if want("C5"):
+        mash_case("C5 mash", 1000, 2_900_000, 3_100_000, 12, 3000, False)
+        mash_case("C5 mash canonical", 1000, 2_900_000, 3_100_000, 12, 3000, True)

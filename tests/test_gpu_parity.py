@@ -559,7 +559,23 @@ def test_config_c4_k7(ctx):
     seqs = synth_seqs(3000, 5000, 44, invalid_frac=0.0005)
     m = ctx.build_matrix(seqs, 7, 4)
     assert (m.counts(17, 2).astype(np.uint64) == _oracle_counts(seqs[17:19], 4, 7)).all()
-    _assert_selection(m.nmost(25), oracle.nmost(seqs, 25, 7, 4))
+    sel = m.nmost(25)
+    assert sel.summary().engine == 1  # 128 KB of set state in LDS: the persistent engine still fits
+    _assert_selection(sel, oracle.nmost(seqs, 25, 7, 4))
+    sel = m.nmost(70)  # more members than fit one wave's argmin, candidate row not register-cached
+    assert sel.summary().engine == 1
+    _assert_selection(sel, oracle.nmost(seqs, 70, 7, 4))
+
+
+def test_persistent_engine_odd_bin_counts(ctx):
+    """bins beyond the register cache and not a multiple of 256 (20 states, k=3: 8000 bins):
+    the persistent engine's scalar row path"""
+    rng = np.random.default_rng(4)
+    prot = [rng.integers(0, 21, size=int(rng.integers(900, 2500)), dtype=np.uint8) for _ in range(700)]
+    m = ctx.build_matrix(prot, 3, 20)
+    sel = m.nmost(9)
+    assert sel.summary().engine == 1
+    _assert_selection(sel, oracle.nmost(prot, 9, 3, 20))
 
 
 # ------------------------------------------------------ exact row-sharded mode (SURVEY 8e)
