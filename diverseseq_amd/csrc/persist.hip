@@ -55,6 +55,7 @@ constexpr uint32_t p_maxn(bool cached) { return cached ? P_MAXN : P_MAXN_BIG; }
 // leave-one-out jobs per event: (n + 1) * K <= max(G - 1, n + 1) <= maxn + 1 (G <= maxn + 2 is checked)
 constexpr uint32_t p_maxjobs(bool cached) { return p_maxn(cached) + 1; }
 constexpr uint32_t P_SPIN_LIMIT = 1u << 22;  // ~0.5 s of polling
+constexpr uint32_t P_SOFT = 64;              // uncertain candidates listed per window (more become plain events)
 
 struct PLine {  // a polled word on a cache line of its own (256 B apart)
     uint32_t v;
@@ -68,7 +69,10 @@ struct PSync {
     PLine ggen[8];    // completed barriers, one copy per group so 32 pollers share a line, not 256
     uint32_t timeout;
     uint32_t pad2[63];
-    unsigned long long ev[3][32];  // event words, slot = epoch % 3 (ev[s][0])
+    unsigned long long ev[3][32];  // event words, slot = epoch % 3 (ev[s][0]; ev[s][16] = the same position when sure)
+    // candidates whose fast score is within FAST_BAND of the threshold: count at [s][0], positions
+    // from [s][8]; the workgroups re-evaluate them in f64 after the rendezvous, in stream order
+    unsigned long long soft[3][8 + 64];
     unsigned long long dbg2[8];    // block 0 (owns a job): phase ticks
     unsigned long long dbg[8];     // mirror block: 100 MHz ticks per phase (scan, bar1, resolve, loo, bar2, finalize)
 };
@@ -133,12 +137,14 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                                             const uint32_t *__restrict__ totals,
                                             const double *__restrict__ rowH, const double *sl,
                                             uint64_t B, const PState &st, double he_base,
-                                            unsigned long long *evp, uint64_t first, uint64_t stride,
-                                            uint64_t nrows, uint32_t lane, uint32_t &nread,
+                                            unsigned long long *evp, unsigned long long *softp,
+                                            uint64_t first, uint64_t stride, uint64_t nrows,
+                                            uint32_t lane, uint32_t &nread,
                                             uint32_t &nprecise) {
     const double dn = double(st.n), rn = 1.0 / dn;
     const double thr_lo = st.thr - st.band;
     const double thr_fast = thr_lo - FAST_BAND, thr_sure = st.thr + st.band + FAST_BAND;
+    (void)thr_lo;
     const bool vec = (B & 255) == 0;
     for (uint64_t r = first; r < nrows; r += stride) {
         const uint64_t p = st.cursor + r;
@@ -199,18 +205,23 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
         const double hf = dvs_wave_sum((a0 + a1) + (a2 + a3));
         const double mn = dvs_wave_min(xmin);
         const double jf = hf - mean_entropy;
-        if (!(mn < 0.0) && jf > thr_fast) {
-            bool hit = jf > thr_sure;
-            if (!hit) {  // f64 tier for the +-FAST_BAND zone
-                nprecise++;
-                Ent e;
-                for (uint64_t i = lane; i < B; i += 64) e.add(fma(row_value(rp, i), rt, sl[i]) * rn);
-                hit = dvs_wave_sum(e.h) - mean_entropy > thr_lo;
-            }
-            if (hit && lane == 0) {
-                atomicMin(evp, (unsigned long long)p);
+        if (!(mn < 0.0) && jf > thr_fast && lane == 0) {
+            if (jf > thr_sure) {
                 // above the threshold by more than every error bound: no f64 re-evaluation needed
-                if (jf > thr_sure) atomicMin(evp + 16, (unsigned long long)p);
+                atomicMin(evp, (unsigned long long)p);
+                atomicMin(evp + 16, (unsigned long long)p);
+            } else {
+                // within FAST_BAND of the threshold: listed, not an event -- the scan goes on and
+                // the workgroups settle it in f64 after the rendezvous (a wave doing that alone
+                // would hold the whole grid at the barrier for 4^k f64 logarithms)
+                nprecise++;
+                const unsigned long long idx = atomicAdd(softp, 1ull);
+                if (idx < P_SOFT) {
+                    if (__hip_atomic_exchange(softp + 8 + idx, (unsigned long long)p, RLX_AGENT) == 1ull)
+                        softp[7] = 1;  // (never: position 1 is a seed; consumes the result)
+                } else {
+                    atomicMin(evp, (unsigned long long)p);  // list full: a plain (unsure) event
+                }
             }
         }
     }
@@ -271,7 +282,7 @@ __device__ __forceinline__ void p_argmin(const double *s_dl, const double *s_ds,
 }
 
 // LDS: [sl B f64][scratch 128 f64][s_mH maxn f64][s_slot maxn u32][s_dl, s_ds maxn f64]
-//      [s_ph, s_ps, s_pm maxjobs f64][s_pos maxn u64][flags]
+//      [s_ph, s_ps, s_pm maxjobs f64][s_pos maxn u64][s_soft P_SOFT u64][flags]
 // maxn / maxjobs = p_maxn(CACHED) / p_maxjobs(CACHED): compile-time offsets (runtime ones cost
 // registers the scan loop needs), smaller beyond 4096 bins so that 4^7 bins (128 KB of sl) still fit.
 // CACHED: B <= P_J * 512, so a thread's share of the candidate row stays in registers
@@ -291,7 +302,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     double *s_ps = s_ph + maxjobs;
     double *s_pm = s_ps + maxjobs;
     uint64_t *s_pos = reinterpret_cast<uint64_t *>(s_pm + maxjobs);  // matrix row of each member
-    int *s_flag = reinterpret_cast<int *>(s_pos + maxn);
+    uint64_t *s_soft = s_pos + maxn;  // this window's listed candidates
+    int *s_flag = reinterpret_cast<int *>(s_soft + P_SOFT);
     SelCtl *ctl = d.ctl;
     const int tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -351,8 +363,9 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // performed before this thread's arrival at the barrier below can be
         if (lead && tid == 0 &&
             (__hip_atomic_exchange(&sync->ev[(epoch + 1) % 3][0], SEL_NONE, RLX_AGENT) == 1ull) +
-                    (__hip_atomic_exchange(&sync->ev[(epoch + 1) % 3][16], SEL_NONE, RLX_AGENT) == 1ull) ==
-                2)
+                    (__hip_atomic_exchange(&sync->ev[(epoch + 1) % 3][16], SEL_NONE, RLX_AGENT) == 1ull) +
+                    (__hip_atomic_exchange(&sync->soft[(epoch + 1) % 3][0], 0ull, RLX_AGENT) == ~0ull) ==
+                3)
             sync->pad0[1] = 1;  // (consumes the results; position 1 is a seed, never an event)
         const uint64_t end = umin64(st.cursor + uint64_t(st.window), st.npos);
         const uint64_t nrows = end - st.cursor;
@@ -361,45 +374,28 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // previous event overlap the others' scan instead of delaying the rendezvous)
         if (!lead || G == 1)
             p_scan_rows<T>(mat, d.totals, d.rowH, sl, B, st, st.sumH - s_mH[st.li], evp,
-                           uint64_t(blockIdx.x) * wpb + wave, nwaves, nrows, lane, nread, nprecise);
+                           &sync->soft[epoch % 3][0], uint64_t(blockIdx.x) * wpb + wave, nwaves, nrows,
+                           lane, nread, nprecise);
         P_STAMP(0);
         if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
         P_STAMP(1);
-        const uint64_t p = __hip_atomic_load(evp, RLX_AGENT);
+        const uint64_t hard = __hip_atomic_load(evp, RLX_AGENT);
+        const uint64_t nlisted = __hip_atomic_load(&sync->soft[epoch % 3][0], RLX_AGENT);
         st.n_windows++;
-        if (p == SEL_NONE) {
-            st.cursor = end;
-            if (end >= st.npos) { exit_status = SEL_DONE; break; }
-            st.window = sel_next_window(st.cursor, st.n, st.wmin, st.wmax, st.wscale);
-            epoch++;
-            continue;
-        }
         // ================= resolve (every workgroup, identical arithmetic)
         // Scores only need to land inside the decision band (4 B eps H), so the f64
         // evaluations multiply by reciprocals; everything that feeds S / sl keeps the
         // reference's exact add / subtract / clamp order.
         const double dn = double(st.n), rn = 1.0 / dn;
-        const double tot = double(d.totals[p]);
-        const double cand_H = d.rowH[p];
-        const T *rp = mat + p * B;
+        uint64_t p = SEL_NONE;
+        double tot = 1.0, cand_H = 0.0;
+        const T *rp = mat;
         double fr[P_J];  // the candidate's frequencies of this thread's bins (B <= P_J * 512)
-        double jsd, sm;
-        // A sure event (fast score above thr + band + FAST_BAND, so the exact score is above
-        // thr + band) is accepted outright.  The sum-to-one guard needs no second look either:
-        // the candidate's mean vector sums to the previous whole-set sum up to ~B u, and that
-        // sum passed its guard at the last finalize.
-        const bool sure = __hip_atomic_load(evp + 16, RLX_AGENT) == p;
-        if (sure) {
-            if (CACHED) {
-#pragma unroll
-                for (int j = 0; j < P_J; j++) {
-                    const uint64_t i = uint64_t(j) * P_THREADS + tid;
-                    if (i < B) fr[j] = cand_freq(rp, i, tot);
-                }
-            }
-            jsd = INFINITY;
-            sm = 1.0;
-        } else {
+        double jsd = 0.0, sm = 1.0;
+        auto evaluate = [&](uint64_t q) {  // exact score of candidate q, by the whole workgroup
+            tot = double(d.totals[q]);
+            cand_H = d.rowH[q];
+            rp = mat + q * B;
             Ent e;
             for (uint64_t b0 = 0; b0 < B; b0 += uint64_t(P_J) * P_THREADS) {
 #pragma unroll
@@ -417,20 +413,85 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             block_red3(h, mn, sm, scratch);
             const double mean_entropy = (st.sumH - s_mH[st.li] + cand_H) / dn;
             jsd = (mn < 0.0) ? NAN : h - mean_entropy;
+        };
+        bool accepted = false, to_arbiter = false;
+        // listed candidates ahead of the first event, in stream order: the first one whose exact
+        // score beats the threshold is the event; a rejected one changes nothing, so the window's
+        // other scores stay valid and nothing is scanned again
+        if (nlisted) {
+            const uint32_t ns = nlisted < P_SOFT ? uint32_t(nlisted) : P_SOFT;
+            if (tid < ns) s_soft[tid] = __hip_atomic_load(&sync->soft[epoch % 3][8 + tid], RLX_AGENT);
+            __syncthreads();
+            uint64_t floor = st.cursor;
+            for (;;) {
+                uint64_t cand = SEL_NONE;
+                for (uint32_t i = 0; i < ns; i++) {
+                    const uint64_t v = s_soft[i];
+                    if (v >= floor && v < hard && v < cand) cand = v;
+                }
+                if (cand == SEL_NONE) break;
+                evaluate(cand);
+                p = cand;
+                if (sum_risky(sm, B) || fabs(jsd - st.thr) <= st.band) {
+                    to_arbiter = true;
+                    break;
+                }
+                st.n_events++;
+                if (jsd > st.thr) {
+                    accepted = true;
+                    break;
+                }
+                floor = cand + 1;
+            }
+            __syncthreads();  // s_soft is rewritten in the next window
         }
-        if (sum_risky(sm, B) || fabs(jsd - st.thr) <= st.band) {
+        if (!accepted && !to_arbiter) {
+            if (hard == SEL_NONE) {
+                st.cursor = end;
+                if (end >= st.npos) { exit_status = SEL_DONE; break; }
+                st.window = sel_next_window(st.cursor, st.n, st.wmin, st.wmax, st.wscale);
+                epoch++;
+                continue;
+            }
+            p = hard;
+            // A sure event (fast score above thr + band + FAST_BAND, so the exact score is above
+            // thr + band) is accepted outright.  The sum-to-one guard needs no second look either:
+            // the candidate's mean vector sums to the previous whole-set sum up to ~B u, and that
+            // sum passed its guard at the last finalize.
+            const bool sure = __hip_atomic_load(evp + 16, RLX_AGENT) == p;
+            if (sure) {
+                tot = double(d.totals[p]);
+                cand_H = d.rowH[p];
+                rp = mat + p * B;
+                if (CACHED) {
+#pragma unroll
+                    for (int j = 0; j < P_J; j++) {
+                        const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                        if (i < B) fr[j] = cand_freq(rp, i, tot);
+                    }
+                }
+                jsd = INFINITY;
+                sm = 1.0;
+            } else {
+                evaluate(p);
+            }
+            to_arbiter = sum_risky(sm, B) || fabs(jsd - st.thr) <= st.band;
+            if (!to_arbiter) {
+                st.n_events++;
+                if (!(jsd > st.thr)) {  // rejected (NaN included, records.rs:91)
+                    st.cursor = p + 1;
+                    if (st.cursor >= st.npos) { exit_status = SEL_DONE; break; }
+                    epoch++;
+                    continue;
+                }
+            }
+        }
+        if (to_arbiter) {
             st.n_windows--;  // the multi-launch resolve will count this window
             exit_status = SEL_ARBITER;
             arb_stage = ARB_RESOLVE;
             arb_pos = p;
             break;
-        }
-        st.n_events++;
-        if (!(jsd > st.thr)) {  // rejected (NaN included, records.rs:91)
-            st.cursor = p + 1;
-            if (st.cursor >= st.npos) { exit_status = SEL_DONE; break; }
-            epoch++;
-            continue;
         }
         P_STAMP(2);
         // ================= replace_lowest (records.rs:94-147) + leave-one-out
@@ -731,7 +792,7 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     s->persist_maxjobs = p_maxjobs(cached);
     if (s->cap > s->persist_maxn || s->persist_grid > s->persist_maxjobs + 1) return DVS_OK;
     const size_t lds = ((B + 1) & ~1ull) * 8 + 128 * 8 + size_t(s->persist_maxn) * 36 +
-                       size_t(s->persist_maxjobs) * 24 + 64;
+                       size_t(s->persist_maxjobs) * 24 + P_SOFT * 8 + 64;
     if (lds > ctx->lds_per_block) return DVS_OK;
     s->persist_lds = lds;
     const void *fn =

@@ -53,7 +53,7 @@ def select_case(name, nseq, lo, hi, k, mode, reps=3, **kw):
         m = ctx.build_matrix_device(seqs.data_ptr(), offsets, k, 4)
         sel = m.nmost(kw["n"]) if mode == "nmost" else m.max_divergent(kw["min_size"], nseq, "stdev")
         s = sel.summary()
-        out = dict(size=s.size, accepts=s.n_accepts, rows_scored=s.rows_scored, engine=s.engine,
+        out = dict(size=s.size, accepts=s.n_accepts, rows_scored=s.rows_scored, rechecked=s.rows_rechecked, windows=s.n_windows, engine=s.engine,
                    arbitrations=s.n_arbitrated, total_jsd=s.total_jsd)
         sel.close()
         m.close()
