@@ -601,6 +601,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             for (uint32_t i = tid; i < n; i += P_THREADS) d.ord[i] = s_slot[i];
         if (lead && tid == 0) {  // post-resolve mirror (what resolve_kernel leaves behind)
             ctl->sum_entropy = st.sumH;
+            ctl->s_is_resum = 0;
             if (old_lab < d.nlabels) d.inset[old_lab] = 0;
             if (uint32_t(p) < d.nlabels) d.inset[uint32_t(p)] = 1;
             d.mH[slot_low] = cand_H;

@@ -23,6 +23,7 @@ struct SelCtl {
     uint32_t ev_kind;   // 0 none, 1 set changed (replace / initial), 2 tentative push (MODE_MAX)
     uint32_t ev_n;      // members taking part in the pending leave-one-out pass
     uint32_t ev_risky;  // a sum-to-one check is too close to call on the device
+    uint32_t s_is_resum;  // S still equals the members' rows added up in member order (only pushes so far)
     uint32_t n_windows, n_events, n_accepts;
     uint32_t n_logged;  // entries of the event log (accepted set changes, for the arbiter)
     double total_jsd, sum_entropy;      // records.rs: total_jsd, summed_entropies

@@ -337,6 +337,7 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, uint32_t scan
         const uint32_t li = ctl->lowest, n = ctl->size;
         const uint32_t s = d.ord[li];
         double *mrow = d.M + uint64_t(s) * d.B;
+        if (tid == 0) ctl->s_is_resum = 0;
         for (uint64_t i = tid; i < d.B; i += WIDE) {
             double v = d.S[i] - mrow[i];
             if (v <= DVS_EPS) v = 0.0;
@@ -374,18 +375,34 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, uint32_t scan
     } else {
         // MODE_MAX with room: clone (= new over the members, records.rs:27-68,182-189)
         // then push the candidate; kept only if the stat rises (finalize decides)
+        // The clone's sums are the members' rows (entropies) added up in member order.  While the
+        // set has only grown by pushes -- the rule in this mode until max_size is reached, after
+        // which nothing is cloned any more -- the running S / sum_entropy ARE those sums, bit for
+        // bit: rebuild_kernel formed them in member order and every kept push appended its
+        // candidate at the end of both the order and the addition chain.
         const uint32_t n = ctl->size;
+        const bool resum = ctl->s_is_resum == 0;
         double *mrow = d.M + uint64_t(n) * d.B;  // slot n is free
         for (uint64_t i = tid; i < d.B; i += WIDE) {
-            double acc = 0.0;
-            for (uint32_t r = 0; r < n; r++) acc += d.M[uint64_t(d.ord[r]) * d.B + i];
+            double acc;
+            if (resum) {
+                acc = 0.0;
+                for (uint32_t r = 0; r < n; r++) acc += d.M[uint64_t(d.ord[r]) * d.B + i];
+            } else {
+                acc = d.S[i];
+            }
             const double f = d.cand[i];
             d.Stmp[i] = acc + f;
             mrow[i] = f;
         }
         if (tid == 0) {
-            double sh = 0.0;
-            for (uint32_t r = 0; r < n; r++) sh += d.mH[d.ord[r]];
+            double sh;
+            if (resum) {
+                sh = 0.0;
+                for (uint32_t r = 0; r < n; r++) sh += d.mH[d.ord[r]];
+            } else {
+                sh = ctl->sum_entropy;
+            }
             sh += cand_H;
             ctl->t_sum_entropy = sh;
             d.mH[n] = cand_H;
@@ -421,6 +438,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void rebuild_kernel(SelDev d) {
         double sh = 0.0;
         for (uint32_t r = 0; r < n; r++) sh += d.mH[d.ord[r]];
         ctl->sum_entropy = sh;
+        ctl->s_is_resum = 1;
     }
     __syncthreads();
     double sm;
