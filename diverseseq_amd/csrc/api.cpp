@@ -152,6 +152,7 @@ int dvs_ctx_create(int device, void *stream, dvs_ctx **out) {
 void dvs_ctx_destroy(dvs_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    dvs_dev_free(ctx, ctx->d_clog_tbl);
     dvs_dev_trim(ctx);
     for (void *p : ctx->pinned_pool) (void)hipHostFree(p);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);

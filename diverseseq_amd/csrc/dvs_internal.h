@@ -20,6 +20,7 @@ struct dvs_ctx {
     bool own_stream = false;
     int n_cu = 0;
     size_t lds_per_block = 0;  // max dynamic LDS a block may ask for
+    double *d_clog_tbl = nullptr;  // c log2 c, c < 256 (kmer_hist.hip)
     bool timing = false;
     std::string err;
     // device-memory cache: blocks released by dvs_dev_free are kept by size and
