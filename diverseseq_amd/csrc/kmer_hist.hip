@@ -392,7 +392,7 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
     }
     // 256 threads for whole sequences: with 16-18 KB of LDS each, 8 workgroups (32 waves) fill a CU;
     // measured on 100k x 5 kb: 0.67 ms at 256 threads, 0.78 at 320, 0.86 at 384 and 512
-    int nthreads = HIST_THREADS, tile_threads = HIST_MAX_THREADS;
+    int nthreads = HIST_THREADS, tile_threads = HIST_THREADS;  // (genome tiles: 256 and 512 measure the same)
     if (const char *e = getenv("DVS_HIST_THREADS")) nthreads = atoi(e);
     if (const char *e = getenv("DVS_HIST_TILE_THREADS")) tile_threads = atoi(e);
     const size_t lds = (lds_hist ? ((B * 4 + 15) & ~15ull) : 0) + (CLOG_TBL + 32) * sizeof(double);
