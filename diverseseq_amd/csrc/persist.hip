@@ -54,6 +54,8 @@ constexpr uint32_t P_MAXN_BIG = 256;        // ... and beyond (k = 7: 128 KB of 
 constexpr uint32_t p_maxn(bool cached) { return cached ? P_MAXN : P_MAXN_BIG; }
 // leave-one-out jobs per event: (n + 1) * K <= max(G - 1, n + 1) <= maxn + 1 (G <= maxn + 2 is checked)
 constexpr uint32_t p_maxjobs(bool cached) { return p_maxn(cached) + 1; }
+// leave-one-out accumulators: 3 slots (accept % 3) x (maxn + 1) members x one 64-byte line
+constexpr size_t p_acc_bytes(uint32_t maxn) { return size_t(3) * (maxn + 1) * 8 * sizeof(unsigned long long); }
 constexpr uint32_t P_SPIN_LIMIT = 1u << 22;  // ~0.5 s of polling
 constexpr uint32_t P_SOFT = 64;              // uncertain candidates listed per window (more become plain events)
 
@@ -73,8 +75,8 @@ struct PSync {
     // candidates whose fast score is within FAST_BAND of the threshold: count at [s][0], positions
     // from [s][8]; the workgroups re-evaluate them in f64 after the rendezvous, in stream order
     unsigned long long soft[3][8 + 64];
-    unsigned long long dbg2[8];    // block 0 (owns a job): phase ticks
-    unsigned long long dbg[8];     // mirror block: 100 MHz ticks per phase (scan, bar1, resolve, loo, bar2, finalize)
+    unsigned long long dbg2[16];   // block 0 (owns a job): phase ticks
+    unsigned long long dbg[16];    // mirror block: 100 MHz ticks per phase (scan, bar1, resolve, loo, bar2, finalize)
 };
 
 struct PState {  // replicated scalars (identical in every workgroup)
@@ -281,28 +283,27 @@ __device__ __forceinline__ void p_argmin(const double *s_dl, const double *s_ds,
     }
 }
 
-// LDS: [sl B f64][scratch 128 f64][s_mH maxn f64][s_slot maxn u32][s_dl, s_ds maxn f64]
-//      [s_ph, s_ps, s_pm maxjobs f64][s_pos maxn u64][s_soft P_SOFT u64][flags]
-// maxn / maxjobs = p_maxn(CACHED) / p_maxjobs(CACHED): compile-time offsets (runtime ones cost
-// registers the scan loop needs), smaller beyond 4096 bins so that 4^7 bins (128 KB of sl) still fit.
+// LDS: [sl B f64][scratch 128 f64][s_mH, s_tot, s_rt, s_dl, s_ds maxn f64][s_pos maxn u64]
+//      [s_slot maxn u32][s_soft P_SOFT u64][flags]
+// maxn = p_maxn(CACHED): compile-time offsets (runtime ones cost registers the scan loop needs),
+// smaller beyond 4096 bins so that 4^7 bins (128 KB of sl) still fit.
 // CACHED: B <= P_J * 512, so a thread's share of the candidate row stays in registers
 template <typename T, bool CACHED>
 __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, const T *__restrict__ mat,
                                                                     PSync *sync, unsigned long long *part, uint32_t G) {
-    constexpr uint32_t maxn = p_maxn(CACHED), maxjobs = p_maxjobs(CACHED);
+    constexpr uint32_t maxn = p_maxn(CACHED);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint64_t B = d.B;
     double *sl = reinterpret_cast<double *>(smem);
     double *scratch = sl + ((B + 1) & ~1ull);
     double *s_mH = scratch + 128;
-    uint32_t *s_slot = reinterpret_cast<uint32_t *>(s_mH + maxn);
-    double *s_dl = reinterpret_cast<double *>(s_slot + maxn);  // delta_jsd per member
-    double *s_ds = s_dl + maxn;                                 // sum of each member's mean vector
-    double *s_ph = s_ds + maxn;                                 // job partials: h, sum, min
-    double *s_ps = s_ph + maxjobs;
-    double *s_pm = s_ps + maxjobs;
-    uint64_t *s_pos = reinterpret_cast<uint64_t *>(s_pm + maxjobs);  // matrix row of each member
-    uint64_t *s_soft = s_pos + maxn;  // this window's listed candidates
+    double *s_tot = s_mH + maxn;  // member row totals and their correctly rounded reciprocals
+    double *s_rt = s_tot + maxn;
+    double *s_dl = s_rt + maxn;   // delta_jsd per member (sets of 64 members and more)
+    double *s_ds = s_dl + maxn;   // sum of each member's mean vector
+    uint64_t *s_pos = reinterpret_cast<uint64_t *>(s_ds + maxn);  // matrix row of each member
+    uint32_t *s_slot = reinterpret_cast<uint32_t *>(s_pos + maxn);
+    uint64_t *s_soft = reinterpret_cast<uint64_t *>(s_slot + maxn + (maxn & 1));  // this window's listed candidates
     int *s_flag = reinterpret_cast<int *>(s_soft + P_SOFT);
     SelCtl *ctl = d.ctl;
     const int tid = threadIdx.x;
@@ -328,9 +329,13 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     st.n_windows = st.n_events = st.n_accepts = 0;
     if (ctl->status != SEL_RUN || ctl->ev_kind != 0 || st.n > maxn || st.n < 2) return;
     for (uint32_t r = tid; r < st.n; r += P_THREADS) {
+        const uint64_t mp = d.mPos[d.ord[r]];
+        const double t = double(d.totals[mp]);
         s_slot[r] = d.ord[r];
         s_mH[r] = d.mH[d.ord[r]];
-        s_pos[r] = d.mPos[d.ord[r]];
+        s_pos[r] = mp;
+        s_tot[r] = t;
+        s_rt[r] = 1.0 / t;
     }
     __syncthreads();
     {
@@ -347,6 +352,19 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     uint32_t pend_kind = 0;  // ev_kind left pending for the multi-launch kernels (finalize tie)
     const uint64_t wpb = P_THREADS / 64;
     const uint64_t nwaves = uint64_t(G > 1 ? G - 1 : 1) * wpb;  // scanning waves
+    // Leave-one-out jobs (the set size is constant in this mode): job (r, part) covers the
+    // 512-bin chunks c = part, part + K, ... of member r's leave-one-out vector (r < n) or of the
+    // whole new set (r == n).  K is a power of two so that, with the candidate's frequencies in
+    // registers (fr[c], chunk c = bins c * 512 + tid), a thread's job bins are its own.
+    const uint32_t nchunk = uint32_t((B + P_THREADS - 1) / P_THREADS);
+    uint32_t K = 1;
+    {
+        const uint32_t kmax = (st.n + 1 < G) ? (G - 1) / (st.n + 1) : 1u;
+        while (K * 2 <= kmax && K * 2 <= nchunk && K * 2 <= 32u) K *= 2;
+    }
+    const uint32_t jobs = (st.n + 1) * K;
+    const bool one_job = jobs <= G - 1;  // at most one job per workgroup, none for the mirror block
+    const bool has_job = one_job ? (blockIdx.x < jobs) : true;
 
     unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
 #define P_STAMP(k)                                                         \
@@ -380,20 +398,40 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
         P_STAMP(1);
         const uint64_t hard = __hip_atomic_load(evp, RLX_AGENT);
+        const uint64_t hard_sure = __hip_atomic_load(evp + 16, RLX_AGENT);  // same round trip
         const uint64_t nlisted = __hip_atomic_load(&sync->soft[epoch % 3][0], RLX_AGENT);
         st.n_windows++;
+        // this workgroup's leave-one-out job, should the window end in an accept: the member's
+        // counts are requested now (its row does not depend on the event), in the same memory
+        // round trip as the candidate's row below.  Member r of the NEW order is member r of the
+        // old one before the lowest, r + 1 after it; the candidate becomes member n - 1.
+        const uint32_t job_r = one_job ? blockIdx.x / K : 0u, job_part = one_job ? blockIdx.x % K : 0u;
+        T mc[P_J];
+        double job_tot = 1.0, job_rt = 1.0;
+        if (CACHED && one_job && has_job && job_r + 1 < st.n) {
+            const uint32_t old = job_r < st.li ? job_r : job_r + 1;
+            const T *mrow = mat + s_pos[old] * B;
+            job_tot = s_tot[old];
+            job_rt = s_rt[old];
+#pragma unroll
+            for (int j = 0; j < P_J; j++) {
+                const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                if ((uint32_t(j) & (K - 1)) == job_part && i < B) mc[j] = mrow[i];
+            }
+        }
         // ================= resolve (every workgroup, identical arithmetic)
         // Scores only need to land inside the decision band (4 B eps H), so the f64
         // evaluations multiply by reciprocals; everything that feeds S / sl keeps the
         // reference's exact add / subtract / clamp order.
         const double dn = double(st.n), rn = 1.0 / dn;
         uint64_t p = SEL_NONE;
-        double tot = 1.0, cand_H = 0.0;
+        double tot = 1.0, rtot = 1.0, cand_H = 0.0;
         const T *rp = mat;
         double fr[P_J];  // the candidate's frequencies of this thread's bins (B <= P_J * 512)
         double jsd = 0.0, sm = 1.0;
         auto evaluate = [&](uint64_t q) {  // exact score of candidate q, by the whole workgroup
             tot = double(d.totals[q]);
+            rtot = 1.0 / tot;
             cand_H = d.rowH[q];
             rp = mat + q * B;
             Ent e;
@@ -402,7 +440,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 for (int j = 0; j < P_J; j++) {
                     const uint64_t i = b0 + uint64_t(j) * P_THREADS + tid;
                     if (i < B) {
-                        const double f = cand_freq(rp, i, tot);
+                        const double f = cand_freq_x(rp, i, tot, rtot);
                         if (CACHED) fr[j] = f;
                         e.add((sl[i] + f) * rn);
                     }
@@ -458,16 +496,17 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             // thr + band) is accepted outright.  The sum-to-one guard needs no second look either:
             // the candidate's mean vector sums to the previous whole-set sum up to ~B u, and that
             // sum passed its guard at the last finalize.
-            const bool sure = __hip_atomic_load(evp + 16, RLX_AGENT) == p;
+            const bool sure = hard_sure == p;
             if (sure) {
                 tot = double(d.totals[p]);
                 cand_H = d.rowH[p];
                 rp = mat + p * B;
+                rtot = 1.0 / tot;
                 if (CACHED) {
 #pragma unroll
                     for (int j = 0; j < P_J; j++) {
                         const uint64_t i = uint64_t(j) * P_THREADS + tid;
-                        if (i < B) fr[j] = cand_freq(rp, i, tot);
+                        if (i < B) fr[j] = cand_freq_x(rp, i, tot, rtot);
                     }
                 }
                 jsd = INFINITY;
@@ -495,44 +534,82 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         }
         P_STAMP(2);
         // ================= replace_lowest (records.rs:94-147) + leave-one-out
+        const uint32_t acc_slot = st.n_accepts % 3;
         st.n_accepts++;
         const uint32_t n = st.n, li = st.li;
         const uint32_t slot_low = s_slot[li];
         const uint32_t old_lab = lead ? d.mLabel[slot_low] : 0;
-        __syncthreads();
-        {   // Vec::remove(li) + push: every thread moves its members one place down
-            uint32_t mv_slot[(maxn + P_THREADS - 1) / P_THREADS];
-            double mv_H[(maxn + P_THREADS - 1) / P_THREADS];
-            uint64_t mv_pos[(maxn + P_THREADS - 1) / P_THREADS];
+        const double sh = (st.sumH - s_mH[li]) + cand_H;
+        __syncthreads();  // every thread has read the old member arrays
+        if (n <= 64) {
+            // Vec::remove(li) + push by one wave: a wave's LDS reads are all performed before its
+            // (data-dependent) writes, so the members move one place down without a barrier
+            if (wave == 0) {
+                const uint32_t i = li + lane;
+                const bool mv = i + 1 < n;
+                uint32_t a = 0;
+                uint64_t c = 0;
+                double b = 0.0, t = 1.0, rt = 1.0;
+                if (mv) {
+                    a = s_slot[i + 1];
+                    b = s_mH[i + 1];
+                    c = s_pos[i + 1];
+                    t = s_tot[i + 1];
+                    rt = s_rt[i + 1];
+                }
+                if (mv) {
+                    s_slot[i] = a;
+                    s_mH[i] = b;
+                    s_pos[i] = c;
+                    s_tot[i] = t;
+                    s_rt[i] = rt;
+                }
+                if (lane == 0) {
+                    s_slot[n - 1] = slot_low;
+                    s_mH[n - 1] = cand_H;
+                    s_pos[n - 1] = p;
+                    s_tot[n - 1] = tot;
+                    s_rt[n - 1] = rtot;
+                }
+            }
+        } else {  // every thread moves its members one place down
+            constexpr uint32_t Q = (maxn + P_THREADS - 1) / P_THREADS;
+            uint32_t mv_slot[Q];
+            double mv_H[Q], mv_t[Q], mv_rt[Q];
+            uint64_t mv_pos[Q];
 #pragma unroll
-            for (uint32_t q = 0; q < (maxn + P_THREADS - 1) / P_THREADS; q++) {
+            for (uint32_t q = 0; q < Q; q++) {
                 const uint32_t i = li + q * P_THREADS + tid;
                 if (i + 1 < n) {
                     mv_slot[q] = s_slot[i + 1];
                     mv_H[q] = s_mH[i + 1];
                     mv_pos[q] = s_pos[i + 1];
+                    mv_t[q] = s_tot[i + 1];
+                    mv_rt[q] = s_rt[i + 1];
                 }
             }
-            const double sh = (st.sumH - s_mH[li]) + cand_H;
             __syncthreads();
 #pragma unroll
-            for (uint32_t q = 0; q < (maxn + P_THREADS - 1) / P_THREADS; q++) {
+            for (uint32_t q = 0; q < Q; q++) {
                 const uint32_t i = li + q * P_THREADS + tid;
                 if (i + 1 < n) {
                     s_slot[i] = mv_slot[q];
                     s_mH[i] = mv_H[q];
                     s_pos[i] = mv_pos[q];
+                    s_tot[i] = mv_t[q];
+                    s_rt[i] = mv_rt[q];
                 }
             }
             if (tid == 0) {
-                scratch[127] = sh;
                 s_slot[n - 1] = slot_low;
                 s_mH[n - 1] = cand_H;
                 s_pos[n - 1] = p;
+                s_tot[n - 1] = tot;
+                s_rt[n - 1] = rtot;
             }
         }
         __syncthreads();
-        st.sumH = scratch[127];
+        st.sumH = sh;
         // S_new_i = clamp(S_i - low_i) + f_i.  The mirror block writes it, and the new member's
         // row, to global memory (it takes no job below, so this overlaps the others' arithmetic).
         if (lead) {
@@ -543,57 +620,96 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     if (i < B) {
                         double v = sl[i];
                         if (v <= DVS_EPS) v = 0.0;
-                        const double f = CACHED ? fr[j] : cand_freq(rp, i, tot);
+                        const double f = CACHED ? fr[j] : cand_freq_x(rp, i, tot, rtot);
                         d.S[i] = v + f;
                         d.M[uint64_t(slot_low) * B + i] = f;
                     }
                 }
             }
+            // the accumulators of the next accept are cleared now: every workgroup read them (two
+            // accepts ago) before it arrived at this window's first barrier
+            unsigned long long *nx = part + uint64_t((acc_slot + 1) % 3) * (maxn + 1) * 8;
+            for (uint32_t r = tid; r <= n; r += P_THREADS) {
+                const unsigned long long o0 = __hip_atomic_exchange(nx + uint64_t(r) * 8, 0ull, RLX_AGENT);
+                const unsigned long long o1 = __hip_atomic_exchange(nx + uint64_t(r) * 8 + 1, 0ull, RLX_AGENT);
+                if ((o0 & o1) == 0x7ff8dead0000beefull) sync->pad0[2] = 1;  // (never: consumes them)
+            }
         }
-        // ================= leave-one-out as (n + 1) * K jobs over the workgroups.
-        // Job (r, part): the entropy terms of bins [part * Bs, (part + 1) * Bs) of the mean
-        // vector without member r (r < n; updated_mean_freqs, records.rs:276-286) or of the
-        // whole new set (r == n; gives total_jsd).  K = (G - 1) / (n + 1) workgroups share one
-        // r, so the pass shrinks from 4^k bins per workgroup to 4^k / K; the K partial sums of
-        // each r are added in a fixed order after the barrier.
+        // ================= leave-one-out (get_lowest_record_index, records.rs:220-252, with
+        // updated_mean_freqs :276-286) as (n + 1) * K jobs over the workgroups.  A job's two sums
+        // (entropy terms, mean-vector total) are added to its member's accumulators as 2^-56
+        // fixed-point integers: integer addition is associative, so the totals do not depend on the
+        // order the K workgroups of a member arrive in, and partial sums of this magnitude
+        // (>= 2^-3) convert without rounding.  (Every term is >= 0: the clamps of the reference
+        // leave no negative bin here, so there is no NaN to carry.)
         const double rdiv = 1.0 / (dn - 1.0);
-        const uint32_t K = (n + 1 < G) ? min((G - 1) / (n + 1), 32u) : 1u;
-        const uint32_t jobs = (n + 1) * K;
-        const uint64_t Bs = (B + K - 1) / K;
-        for (uint32_t job = blockIdx.x; job < jobs; job += G) {
-            if (lead && jobs <= G - 1) break;
+        unsigned long long *acc = part + uint64_t(acc_slot) * (maxn + 1) * 8;
+        bool first_job = true;
+        for (uint32_t job = blockIdx.x; job < jobs && has_job; job += G) {
+            if (lead && one_job) break;
             const uint32_t r = job / K, part_i = job % K;
-            const uint64_t lo = uint64_t(part_i) * Bs, hi = umin64(B, lo + Bs);
             const bool is_new = r == n - 1;
-            // a member's frequency row = its (read-only) matrix row over its total, the very
-            // values d.M holds: no workgroup ever reads what another one stored during the launch
+            const bool pre = CACHED && one_job;  // member counts already requested above
             const uint64_t mp = r < n ? s_pos[r] : 0;
             const T *mrow = mat + mp * B;
-            const double mtot = double(d.totals[mp]);
-            double h = 0.0, sv = 0.0, mn = 0.0;
-            for (uint64_t i = lo + tid; i < hi; i += P_THREADS) {
+            const double mtot = pre ? job_tot : (r < n ? s_tot[r] : 1.0);
+            const double mrt = pre ? job_rt : (r < n ? s_rt[r] : 1.0);
+            double h = 0.0, sv = 0.0;
+            auto bin = [&](uint64_t i, double f, double fm) {
                 double v = sl[i];
                 if (v <= DVS_EPS) v = 0.0;
-                const double f = cand_freq(rp, i, tot);
                 const double sn = v + f;
                 double u;
                 if (r == n) {
                     u = sn * rn;
                 } else {
-                    u = (sn - (is_new ? f : cand_freq(mrow, i, mtot))) * rdiv;
+                    u = (sn - (is_new ? f : fm)) * rdiv;
                     if (u <= DVS_EPS) u = 0.0;
                 }
                 if (u > 0.0) h -= u * log2_acc(u);
                 sv += u;
-                mn = fmin(mn, u);
+            };
+            if (CACHED) {
+#pragma unroll
+                for (int j = 0; j < P_J; j++) {
+                    const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                    if ((uint32_t(j) & (K - 1)) == part_i && i < B) {
+                        const double fm = (r >= n || is_new) ? 0.0
+                                          : count_freq_x(pre ? mc[j] : mrow[i], mtot, mrt);
+                        bin(i, fr[j], fm);
+                    }
+                }
+            } else {
+                for (uint32_t c = part_i; c < nchunk; c += K) {
+                    const uint64_t i = uint64_t(c) * P_THREADS + tid;
+                    if (i < B) {
+                        const double f = cand_freq_x(rp, i, tot, rtot);
+                        const double fm = (r >= n || is_new) ? 0.0 : cand_freq_x(mrow, i, mtot, mrt);
+                        bin(i, f, fm);
+                    }
+                }
             }
-            block_red3(h, mn, sv, scratch);
-            if (tid == 0) {  // three exchanges in flight, results consumed before the arrival below
-                unsigned long long *pp = part + uint64_t(job) * 4;
-                const unsigned long long o0 = __hip_atomic_exchange(pp, (unsigned long long)__double_as_longlong(h), RLX_AGENT);
-                const unsigned long long o1 = __hip_atomic_exchange(pp + 1, (unsigned long long)__double_as_longlong(sv), RLX_AGENT);
-                const unsigned long long o2 = __hip_atomic_exchange(pp + 2, (unsigned long long)__double_as_longlong(mn), RLX_AGENT);
-                if ((o0 & o1 & o2) == 0x7ff8dead0000beefull) sync->pad0[2] = 1;  // (never: consumes them)
+            h = dvs_wave_sum(h);
+            sv = dvs_wave_sum(sv);
+            if (!first_job) __syncthreads();  // scratch[64..] still being read by thread 0
+            first_job = false;
+            if (lane == 0) {
+                scratch[64 + wave] = h;
+                scratch[80 + wave] = sv;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                double th = 0.0, ts = 0.0;
+                for (uint32_t w = 0; w < P_THREADS / 64; w++) {
+                    th += scratch[64 + w];
+                    ts += scratch[80 + w];
+                }
+                // two adds in flight, results consumed before the arrival below
+                const unsigned long long o0 = __hip_atomic_fetch_add(
+                        acc + uint64_t(r) * 8, (unsigned long long)__double2ll_rn(th * 0x1p56), RLX_AGENT);
+                const unsigned long long o1 = __hip_atomic_fetch_add(
+                        acc + uint64_t(r) * 8 + 1, (unsigned long long)__double2ll_rn(ts * 0x1p56), RLX_AGENT);
+                if ((o0 & o1) == 0x7ff8dead0000beefull) sync->pad0[2] = 1;  // (never: consumes them)
             }
         }
         st.cursor = p + 1;
@@ -618,63 +734,90 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         P_STAMP(3);
         if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
         P_STAMP(4);
-        // ================= combine: one load per job (a single memory round trip), then the K
-        // partials of each r are added in job order by one thread -> same bits in every workgroup
-        for (uint32_t j = tid; j < jobs; j += P_THREADS) {
-            const unsigned long long *pp = part + uint64_t(j) * 4;
-            s_ph[j] = __longlong_as_double((long long)__hip_atomic_load(pp, RLX_AGENT));
-            s_ps[j] = __longlong_as_double((long long)__hip_atomic_load(pp + 1, RLX_AGENT));
-            s_pm[j] = __longlong_as_double((long long)__hip_atomic_load(pp + 2, RLX_AGENT));
-        }
-        __syncthreads();
-        for (uint32_t r = tid; r <= n; r += P_THREADS) {
-            double h = 0.0, sv = 0.0, mn = 0.0;
-            for (uint32_t q = 0; q < K; q++) {
-                h += s_ph[r * K + q];
-                sv += s_ps[r * K + q];
-                mn = fmin(mn, s_pm[r * K + q]);
+        // ================= finalize (every workgroup): totals -> delta_jsd -> argmin (strict '<'
+        // from 1e6, first index), all from the accumulators: one memory round trip
+        uint32_t lowest;
+        double dmin, dsecond;
+        bool any_risky, ev_risky;
+        if (n < 64) {
+            // every wave on its own (lane r = member r, lane n = the whole set): no LDS, no barrier
+            const bool valid = lane <= n;
+            const long long ah = valid ? (long long)__hip_atomic_load(acc + uint64_t(lane) * 8, RLX_AGENT) : 0ll;
+            const long long as = valid ? (long long)__hip_atomic_load(acc + uint64_t(lane) * 8 + 1, RLX_AGENT) : 0ll;
+            const double h = double(ah) * 0x1p-56, sv = double(as) * 0x1p-56;
+            const double hm = __shfl(h, int(n), 64), svn = __shfl(sv, int(n), 64);
+            st.total_jsd = hm - st.sumH / dn;
+            ev_risky = sum_risky(svn, B) || !(hm == hm);
+            const bool mem = lane < n;
+            const double mH = mem ? s_mH[lane] : 0.0;
+            const double dl = mem ? st.total_jsd - (h - (st.sumH - mH) * rdiv) : 1e6;  // delta_jsd
+            P_STAMP(6);
+            dmin = dvs_wave_min(dl);
+            const unsigned long long at = __ballot(mem && dl == dmin && dmin < 1e6);
+            lowest = at ? uint32_t(__builtin_ctzll(at)) : 0u;
+            dsecond = dvs_wave_min((mem && lane != lowest) ? dl : 1e6);
+            any_risky = __ballot(mem && sum_risky(sv, B)) != 0ull;
+            P_STAMP(7);
+            if (lead && wave == 0) {
+                const double mu = dvs_wave_sum(mem ? dl : 0.0) / dn;
+                const double t = mem ? dl - mu : 0.0;
+                const double sd = sqrt(dvs_wave_sum(t * t) / (dn - 1.0));
+                if (mem) {
+                    d.dtmp[lane] = dl;
+                    d.dsum[lane] = sv;
+                    d.mDelta[lane] = dl;
+                }
+                if (lane == 0) {
+                    ctl->total_jsd = st.total_jsd;
+                    ctl->mean_delta = mu;
+                    ctl->std_delta = sd;
+                    ctl->cov_delta = sd / mu;
+                }
             }
-            if (r == n) {
-                scratch[110] = (mn < 0.0) ? NAN : h;
-                scratch[111] = sv;
-            } else {
-                s_dl[r] = h - (st.sumH - s_mH[r]) * rdiv;  // JSD of the set without member r
-                s_ds[r] = sv;
+        } else {
+            for (uint32_t r = tid; r <= n; r += P_THREADS) {
+                const double h = double((long long)__hip_atomic_load(acc + uint64_t(r) * 8, RLX_AGENT)) * 0x1p-56;
+                const double sv = double((long long)__hip_atomic_load(acc + uint64_t(r) * 8 + 1, RLX_AGENT)) * 0x1p-56;
+                if (r == n) {
+                    scratch[110] = h;
+                    scratch[111] = sv;
+                } else {
+                    s_dl[r] = h - (st.sumH - s_mH[r]) * rdiv;  // JSD of the set without member r
+                    s_ds[r] = sv;
+                }
             }
-        }
-        __syncthreads();
-        const double hm = scratch[110];
-        st.total_jsd = hm - st.sumH / dn;
-        const bool ev_risky = sum_risky(scratch[111], B) || !(hm == hm);
-        for (uint32_t r = tid; r < n; r += P_THREADS) s_dl[r] = st.total_jsd - s_dl[r];  // delta_jsd
-        __syncthreads();
-        if (lead) {
-            for (uint32_t r = tid; r < n; r += P_THREADS) {
-                d.dtmp[r] = s_dl[r];
-                d.dsum[r] = s_ds[r];
+            __syncthreads();
+            P_STAMP(6);
+            const double hm = scratch[110];
+            st.total_jsd = hm - st.sumH / dn;
+            ev_risky = sum_risky(scratch[111], B) || !(hm == hm);
+            for (uint32_t r = tid; r < n; r += P_THREADS) s_dl[r] = st.total_jsd - s_dl[r];  // delta_jsd
+            __syncthreads();
+            if (wave == 0) p_argmin<(maxn + 63) / 64>(s_dl, s_ds, n, B, lane, scratch);
+            __syncthreads();
+            dmin = scratch[100];
+            lowest = uint32_t(scratch[101]);
+            dsecond = scratch[102];
+            any_risky = scratch[105] != 0.0;
+            P_STAMP(7);
+            if (lead) {
+                for (uint32_t r = tid; r < n; r += P_THREADS) {
+                    d.dtmp[r] = s_dl[r];
+                    d.dsum[r] = s_ds[r];
+                    d.mDelta[r] = s_dl[r];
+                }
+                if (tid == 0) {
+                    ctl->total_jsd = st.total_jsd;
+                    ctl->mean_delta = scratch[103];
+                    ctl->std_delta = scratch[104];
+                    ctl->cov_delta = scratch[104] / scratch[103];
+                }
             }
-            if (tid == 0) {
-                ctl->total_jsd = st.total_jsd;
-                ctl->ev_risky = ev_risky ? 1 : 0;
-            }
+            __syncthreads();  // scratch[100..] is rewritten by the next accept
         }
-        // ================= finalize (every workgroup): argmin, strict '<' from 1e6
-        // one wave holds every score (lane l owns members l, l + 64, ...): shuffles only, one
-        // barrier to share the result
-        if (wave == 0) {
-            if (n <= 64) p_argmin<1>(s_dl, s_ds, n, B, lane, scratch);
-            else p_argmin<(maxn + 63) / 64>(s_dl, s_ds, n, B, lane, scratch);
-        }
-        __syncthreads();
-        const double dmin = scratch[100];
-        const uint32_t lowest = uint32_t(scratch[101]);
-        const double dsecond = scratch[102];
-        const double mean = scratch[103];
-        const double sd = scratch[104];
-        const int any_risky = scratch[105] != 0.0;
-        __syncthreads();
         const double band = sel_band(st.total_jsd + st.sumH / dn, B);
         if (any_risky || ev_risky || (n > 1 && dsecond - dmin <= band && dsecond < 1e6)) {
+            if (lead && tid == 0) ctl->ev_risky = ev_risky ? 1 : 0;
             exit_status = SEL_ARBITER;  // argmin too close to call: loo + finalize kernels resume
             arb_stage = ARB_FINALIZE;
             arb_pos = p;
@@ -686,9 +829,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         st.thr = st.total_jsd + DVS_EPS;
         {   // sl <- S_new - new lowest, in place (each thread owns its bins)
             const bool low_is_new = lowest == n - 1;
-            const uint64_t lp = s_pos[lowest];
-            const T *lrow = mat + lp * B;
-            const double ltot = double(d.totals[lp]);
+            const T *lrow = mat + s_pos[lowest] * B;
+            const double ltot = s_tot[lowest], lrt = s_rt[lowest];
             for (uint64_t b0 = 0; b0 < B; b0 += uint64_t(P_J) * P_THREADS) {
 #pragma unroll
                 for (int j = 0; j < P_J; j++) {
@@ -696,27 +838,21 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     if (i < B) {
                         double v = sl[i];
                         if (v <= DVS_EPS) v = 0.0;
-                        const double f = CACHED ? fr[j] : cand_freq(rp, i, tot);
+                        const double f = CACHED ? fr[j] : cand_freq_x(rp, i, tot, rtot);
                         const double sn = v + f;
-                        const double nv = sn - (low_is_new ? f : cand_freq(lrow, i, ltot));
+                        const double nv = sn - (low_is_new ? f : cand_freq_x(lrow, i, ltot, lrt));
                         sl[i] = nv;
                         if (lead) d.base[i] = nv / dn;
                     }
                 }
             }
         }
-        if (lead) {
-            for (uint32_t r = tid; r < n; r += P_THREADS) d.mDelta[r] = s_dl[r];
-            if (tid == 0) {
-                ctl->lowest = lowest;
-                ctl->mean_delta = mean;
-                ctl->std_delta = sd;
-                ctl->cov_delta = sd / mean;
-                ctl->band = band;
-                ctl->he_base = st.sumH - s_mH[lowest];
-                ctl->thr = st.thr;
-                ctl->ev_risky = 0;
-            }
+        if (lead && tid == 0) {
+            ctl->lowest = lowest;
+            ctl->band = band;
+            ctl->he_base = st.sumH - s_mH[lowest];
+            ctl->thr = st.thr;
+            ctl->ev_risky = 0;
         }
         __syncthreads();
         P_STAMP(5);
@@ -757,6 +893,7 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     memset(&init, 0, sizeof init);
     for (int i = 0; i < 3; i++) init.ev[i][0] = init.ev[i][16] = SEL_NONE;
     DVS_HIP(ctx, hipMemcpyAsync(s->psync, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    DVS_HIP(ctx, hipMemsetAsync(s->ppart, 0, p_acc_bytes(s->persist_maxn), ctx->stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->time_scan) {
         if (s->ev_used + 2 > s->ev_pool.size()) {
@@ -791,9 +928,8 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     const bool cached = B <= uint64_t(P_J) * P_THREADS;
     s->persist_maxn = p_maxn(cached);
     s->persist_maxjobs = p_maxjobs(cached);
-    if (s->cap > s->persist_maxn || s->persist_grid > s->persist_maxjobs + 1) return DVS_OK;
-    const size_t lds = ((B + 1) & ~1ull) * 8 + 128 * 8 + size_t(s->persist_maxn) * 36 +
-                       size_t(s->persist_maxjobs) * 24 + P_SOFT * 8 + 64;
+    if (s->cap > s->persist_maxn) return DVS_OK;
+    const size_t lds = ((B + 1) & ~1ull) * 8 + 128 * 8 + size_t(s->persist_maxn) * 52 + 8 + P_SOFT * 8 + 64;
     if (lds > ctx->lds_per_block) return DVS_OK;
     s->persist_lds = lds;
     const void *fn =
@@ -808,13 +944,13 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
         set_lds[fn] = lds;
     }
     int rc = dvs_dev_alloc(ctx, &s->psync, sizeof(PSync), "persistent sync block");
-    if (!rc) rc = dvs_dev_alloc(ctx, &s->ppart, size_t(s->persist_maxjobs) * 4 * sizeof(double), "leave-one-out partials");
+    if (!rc) rc = dvs_dev_alloc(ctx, &s->ppart, p_acc_bytes(s->persist_maxn), "leave-one-out accumulators");
     if (rc) return rc;
     s->persist = true;
     return DVS_OK;
 }
 
-size_t dvs_persist_dbg_offset(void) { return offsetof(PSync, dbg2); }  // dbg2[8] then dbg[8]
+size_t dvs_persist_dbg_offset(void) { return offsetof(PSync, dbg2); }  // dbg2[16] then dbg[16]
 
 int dvs_persist_launch(dvs_ctx *ctx, dvs_select *s) {
     return s->mat_kind == 0 ? persist_launch<uint32_t>(ctx, s, s->mat->d_counts)

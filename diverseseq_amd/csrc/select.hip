@@ -891,13 +891,14 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat) {
             s->ev_used = 0;
         }
         if (s->persist && s->psync && getenv("DVS_PERSIST_DEBUG")) {
-            unsigned long long dbg[16];
+            unsigned long long dbg[32];
             if (hipMemcpy(dbg, static_cast<char *>(s->psync) + dvs_persist_dbg_offset(), sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
                 for (int w = 0; w < 2; w++)
-                    fprintf(stderr, "[dvs persist %s] us: scan %.1f bar1 %.1f resolve %.1f loo %.1f bar2 %.1f finalize %.1f\n",
-                            w ? "mirror block" : "block 0", dbg[0 + 8 * w] / 100.0, dbg[1 + 8 * w] / 100.0,
-                            dbg[2 + 8 * w] / 100.0, dbg[3 + 8 * w] / 100.0, dbg[4 + 8 * w] / 100.0,
-                            dbg[5 + 8 * w] / 100.0);
+                    fprintf(stderr, "[dvs persist %s] us: scan %.1f bar1 %.1f resolve %.1f loo %.1f bar2 %.1f | partials %.1f combine %.1f argmin %.1f rebuild %.1f\n",
+                            w ? "mirror block" : "block 0", dbg[0 + 16 * w] / 100.0, dbg[1 + 16 * w] / 100.0,
+                            dbg[2 + 16 * w] / 100.0, dbg[3 + 16 * w] / 100.0, dbg[4 + 16 * w] / 100.0,
+                            dbg[6 + 16 * w] / 100.0, dbg[7 + 16 * w] / 100.0, dbg[8 + 16 * w] / 100.0,
+                            dbg[5 + 16 * w] / 100.0);
             }
         }
         if (c.status == SEL_DONE) return DVS_OK;
