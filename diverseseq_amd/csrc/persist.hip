@@ -70,7 +70,9 @@ struct PSync {
     PLine gcount[8];  // arrivals of group g = blockIdx % 8 (workgroups are dealt round-robin to the 8 XCDs)
     PLine ggen[8];    // completed barriers, one copy per group so 32 pollers share a line, not 256
     uint32_t timeout;
-    uint32_t pad2[63];
+    uint32_t wg_thresh;  // windows of up to wg_thresh rows per workgroup are scanned a row per WORKGROUP (0: never)
+    float wg_scale;      // ... and are cursor * wg_scale / size rows long (rounded up to whole rounds)
+    uint32_t pad2[61];
     unsigned long long ev[3][32];  // event words, slot = epoch % 3 (ev[s][0]; ev[s][16] = the same position when sure)
     // candidates whose fast score is within FAST_BAND of the threshold: count at [s][0], positions
     // from [s][8]; the workgroups re-evaluate them in f64 after the rendezvous, in stream order
@@ -229,6 +231,121 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
     }
 }
 
+// The same scores with one row per WORKGROUP (8 waves x 512 bins at k=6): a row takes an eighth of
+// the time a lone wave needs for it, so a short window -- early in the stream an accept comes every
+// few hundred rows and the scan is pure latency -- ends that much sooner, and the rows in flight
+// when an event is found are 255, not 2040.  One barrier per row: the waves' partial sums alternate
+// between two sets of LDS slots.  Lane l of wave w owns bins 4 (512 c + 64 w + l) .. + 3 of every
+// 2048-bin chunk c.  red: 2 x 24 doubles.
+template <typename T>
+__device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const uint32_t *__restrict__ totals,
+                                               const double *__restrict__ rowH, const double *sl, uint64_t B,
+                                               const PState &st, double he_base, unsigned long long *evp,
+                                               unsigned long long *softp, uint64_t first, uint64_t stride,
+                                               uint64_t nrows, double *red, uint32_t &nread,
+                                               uint32_t &nprecise) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double dn = double(st.n), rn = 1.0 / dn;
+    const double thr_fast = st.thr - st.band - FAST_BAND, thr_sure = st.thr + st.band + FAST_BAND;
+    const bool vec = (B & 2047) == 0;
+    uint32_t par = 0;
+    for (uint64_t r = first; r < nrows; r += stride, par ^= 1) {
+        const uint64_t p = st.cursor + r;
+        const T *rp = mat + p * B;
+        const unsigned long long ev = __hip_atomic_load(evp, RLX_AGENT);
+        const uint32_t tot = totals[p];
+        const double hrow = rowH[p];
+        const double rt = tot ? 1.0 / double(tot) : 0.0;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, xmin = 0.0;
+        if (vec) {
+            for (uint64_t i0 = 0; i0 < B; i0 += 4 * 2048) {  // up to four chunks requested at once
+                Raw4<T> raw[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (i0 + uint64_t(j) * 2048 < B) raw[j].load(rp + i0 + uint64_t(j) * 2048 + tid * 4);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint64_t i = i0 + uint64_t(j) * 2048 + tid * 4;
+                    if (i < B) {
+                        const double2 b01 = *reinterpret_cast<const double2 *>(sl + i);
+                        const double2 b23 = *reinterpret_cast<const double2 *>(sl + i + 2);
+                        double v0, v1, v2, v3;
+                        raw[j].get(v0, v1, v2, v3);
+                        const double x0 = fma(v0, rt, b01.x) * rn, x1 = fma(v1, rt, b01.y) * rn;
+                        const double x2 = fma(v2, rt, b23.x) * rn, x3 = fma(v3, rt, b23.y) * rn;
+                        a0 += fast_neg_xlog2x(x0);
+                        a1 += fast_neg_xlog2x(x1);
+                        a2 += fast_neg_xlog2x(x2);
+                        a3 += fast_neg_xlog2x(x3);
+                        xmin = fmin(fmin(xmin, fmin(x0, x1)), fmin(x2, x3));
+                    }
+                }
+            }
+        } else {
+            for (uint64_t i = tid; i < B; i += P_THREADS) {
+                const double x = fma(row_value(rp, i), rt, sl[i]) * rn;
+                a0 += fast_neg_xlog2x(x);
+                xmin = fmin(xmin, x);
+            }
+        }
+        const double hw = dvs_wave_sum((a0 + a1) + (a2 + a3));
+        const bool negw = __ballot(xmin < 0.0) != 0ull;
+        double *slot = red + par * 24;
+        if (lane == 0) {
+            slot[wave] = hw;
+            slot[8 + wave] = negw ? 1.0 : 0.0;
+            if (wave == 0) slot[16] = __longlong_as_double((long long)ev);
+        }
+        __syncthreads();
+        // every thread takes the same decisions from the same LDS words
+        if ((unsigned long long)__double_as_longlong(slot[16]) < p) break;
+        if (tot == 0) continue;
+        double hf = 0.0, neg = 0.0;
+#pragma unroll
+        for (int w = 0; w < P_THREADS / 64; w++) {
+            hf += slot[w];
+            neg += slot[8 + w];
+        }
+        const double jf = hf - (he_base + hrow) / dn;
+        if (tid == 0) {
+            nread++;
+            if (neg == 0.0 && jf > thr_fast) {
+                if (jf > thr_sure) {
+                    atomicMin(evp, (unsigned long long)p);
+                    atomicMin(evp + 16, (unsigned long long)p);
+                } else {
+                    nprecise++;
+                    const unsigned long long idx = atomicAdd(softp, 1ull);
+                    if (idx < P_SOFT) {
+                        if (__hip_atomic_exchange(softp + 8 + idx, (unsigned long long)p, RLX_AGENT) == 1ull)
+                            softp[7] = 1;  // (never: position 1 is a seed; consumes the result)
+                    } else {
+                        atomicMin(evp, (unsigned long long)p);  // list full: a plain (unsure) event
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Window policy of the persistent engine.  Short windows run a row per workgroup (p_scan_rows_wg) and
+// are whole rounds of the scanning workgroups long; the scale aims at ~3 in 4 windows ending in an
+// accept (the accept probability at stream position i is ~ size / i).
+__device__ __forceinline__ uint32_t p_next_window(const PState &st, uint32_t nwg, uint32_t wg_thresh,
+                                                  double wg_scale, bool &wgmode) {
+    if (wg_thresh) {
+        uint64_t w = uint64_t(double(st.cursor) * wg_scale / double(st.n ? st.n : 1u));
+        w = (w + nwg - 1) / nwg * nwg;
+        if (w < nwg) w = nwg;
+        if (w <= uint64_t(wg_thresh) * nwg) {
+            wgmode = true;
+            return uint32_t(w);
+        }
+    }
+    wgmode = false;
+    return sel_next_window(st.cursor, st.n, st.wmin, st.wmax, st.wscale);
+}
+
 // argmin (strict '<' from 1e6, first index), runner-up, mean and standard deviation of the
 // members' delta_jsd by ONE wave: lane l owns members l, l + 64, ... (Q per lane; re-read from LDS
 // in every pass when Q > 1 -- registers are the scan loop's).
@@ -351,7 +468,12 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     uint64_t arb_pos = 0;
     uint32_t pend_kind = 0;  // ev_kind left pending for the multi-launch kernels (finalize tie)
     const uint64_t wpb = P_THREADS / 64;
-    const uint64_t nwaves = uint64_t(G > 1 ? G - 1 : 1) * wpb;  // scanning waves
+    const uint32_t nwg = G > 1 ? G - 1 : 1;           // scanning workgroups
+    const uint64_t nwaves = uint64_t(nwg) * wpb;      // scanning waves
+    const uint32_t wg_thresh = sync->wg_thresh;       // (written by the host before the launch)
+    const double wg_scale = double(sync->wg_scale);
+    bool wgmode = false;
+    if (wg_thresh) st.window = p_next_window(st, nwg, wg_thresh, wg_scale, wgmode);
     // Leave-one-out jobs (the set size is constant in this mode): job (r, part) covers the
     // 512-bin chunks c = part, part + K, ... of member r's leave-one-out vector (r < n) or of the
     // whole new set (r == n).  K is a power of two so that, with the candidate's frequencies in
@@ -390,10 +512,16 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // ================= scan
         // (the mirror block scans nothing when there are other blocks: its global stores of the
         // previous event overlap the others' scan instead of delaying the rendezvous)
-        if (!lead || G == 1)
-            p_scan_rows<T>(mat, d.totals, d.rowH, sl, B, st, st.sumH - s_mH[st.li], evp,
-                           &sync->soft[epoch % 3][0], uint64_t(blockIdx.x) * wpb + wave, nwaves, nrows,
-                           lane, nread, nprecise);
+        if (!lead || G == 1) {
+            if (wgmode)
+                p_scan_rows_wg<T>(mat, d.totals, d.rowH, sl, B, st, st.sumH - s_mH[st.li], evp,
+                                  &sync->soft[epoch % 3][0], blockIdx.x, nwg, nrows, scratch + 64, nread,
+                                  nprecise);
+            else
+                p_scan_rows<T>(mat, d.totals, d.rowH, sl, B, st, st.sumH - s_mH[st.li], evp,
+                               &sync->soft[epoch % 3][0], uint64_t(blockIdx.x) * wpb + wave, nwaves, nrows,
+                               lane, nread, nprecise);
+        }
         P_STAMP(0);
         if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
         P_STAMP(1);
@@ -487,7 +615,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             if (hard == SEL_NONE) {
                 st.cursor = end;
                 if (end >= st.npos) { exit_status = SEL_DONE; break; }
-                st.window = sel_next_window(st.cursor, st.n, st.wmin, st.wmax, st.wscale);
+                st.window = p_next_window(st, nwg, wg_thresh, wg_scale, wgmode);
                 epoch++;
                 continue;
             }
@@ -857,7 +985,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         __syncthreads();
         P_STAMP(5);
         if (st.cursor >= st.npos) { exit_status = SEL_DONE; break; }
-        st.window = sel_next_window(st.cursor, st.n, st.wmin, st.wmax, st.wscale);
+        st.window = p_next_window(st, nwg, wg_thresh, wg_scale, wgmode);
         epoch++;
     }
 
@@ -892,6 +1020,11 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     PSync init;
     memset(&init, 0, sizeof init);
     for (int i = 0; i < 3; i++) init.ev[i][0] = init.ev[i][16] = SEL_NONE;
+    // a row per workgroup while a window is at most this many rounds of the grid (default policy only)
+    init.wg_thresh = s->params.window ? 0u : 4u;
+    init.wg_scale = 1.5f;
+    if (const char *e = getenv("DVS_PERSIST_WG_ROUNDS")) init.wg_thresh = uint32_t(atoi(e));
+    if (const char *e = getenv("DVS_PERSIST_WG_SCALE")) init.wg_scale = float(atof(e));
     DVS_HIP(ctx, hipMemcpyAsync(s->psync, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     DVS_HIP(ctx, hipMemsetAsync(s->ppart, 0, p_acc_bytes(s->persist_maxn), ctx->stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
