@@ -33,7 +33,7 @@ EXPORTS = (
     "dvs_select_destroy", "dvs_select_get_summary", "dvs_select_get_members",
     "dvs_select_gather_members",
     "dvs_select_delta_jsd", "dvs_select_step_scan", "dvs_select_step_fetch",
-    "dvs_select_step_apply", "dvs_select_step_poll", "dvs_select_bench_scan", "dvs_selftest_fast_log2", "dvs_selftest_log2_acc", "dvs_mash_sketch", "dvs_mash_distances", "dvs_euclidean_distances",
+    "dvs_select_step_apply", "dvs_select_step_poll", "dvs_select_bench_scan", "dvs_selftest_fast_log2", "dvs_selftest_log2_acc", "dvs_selftest_log2_f32", "dvs_selftest_exact_div", "dvs_mash_sketch", "dvs_mash_distances", "dvs_euclidean_distances",
 )
 
 
@@ -147,6 +147,8 @@ def load() -> C.CDLL:
         L.dvs_select_bench_scan.argtypes = [vp, vp, C.c_int, f64p, u64p]
         L.dvs_selftest_fast_log2.argtypes = [vp, f64p]
         L.dvs_selftest_log2_acc.argtypes = [vp, f64p]
+        L.dvs_selftest_log2_f32.argtypes = [vp, f64p]
+        L.dvs_selftest_exact_div.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.dvs_mash_sketch.argtypes = [vp, vp, C.c_int, u64p, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.c_uint32, C.c_int, u32p, u32p]
         L.dvs_mash_distances.argtypes = [vp, u32p, C.c_uint32, u32p, C.c_uint32, C.c_uint32,

@@ -72,7 +72,8 @@ struct PSync {
     uint32_t timeout;
     uint32_t wg_thresh;  // windows of up to wg_thresh rows per workgroup are scanned a row per WORKGROUP (0: never)
     float wg_scale;      // ... and are cursor * wg_scale / size rows long (rounded up to whole rounds)
-    uint32_t pad2[61];
+    uint32_t no_coarse;  // measurement aid: skip the COARSE tier
+    uint32_t pad2[60];
     unsigned long long ev[3][32];  // event words, slot = epoch % 3 (ev[s][0]; ev[s][16] = the same position when sure)
     // candidates whose fast score is within FAST_BAND of the threshold: count at [s][0], positions
     // from [s][8]; the workgroups re-evaluate them in f64 after the rendezvous, in stream order
@@ -136,20 +137,22 @@ __device__ bool grid_barrier(PSync *sync, uint32_t G, uint32_t &gen, int *s_ok) 
 
 // One wave's share of the window, as scan_rows_hot but against the unscaled vector sl:
 // x = (sl_i + c_i / T) / n  computed as  fma(c, 1/T, sl) * (1/n).
-template <typename T>
+template <typename T, bool COARSE>
 __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                                             const uint32_t *__restrict__ totals,
                                             const double *__restrict__ rowH, const double *sl,
-                                            uint64_t B, const PState &st, double he_base,
+                                            const float *slf, uint64_t B, const PState &st, double he_base,
                                             unsigned long long *evp, unsigned long long *softp,
                                             uint64_t first, uint64_t stride, uint64_t nrows,
                                             uint32_t lane, uint32_t &nread,
-                                            uint32_t &nprecise) {
+                                            uint32_t &nprecise, uint32_t &nmid, bool coarse_on) {
     const double dn = double(st.n), rn = 1.0 / dn;
     const double thr_lo = st.thr - st.band;
     const double thr_fast = thr_lo - FAST_BAND, thr_sure = st.thr + st.band + FAST_BAND;
     (void)thr_lo;
     const bool vec = (B & 255) == 0;
+    const double cband = coarse_band(B);
+    const double thr_c_lo = st.thr - st.band - cband, thr_c_hi = st.thr + st.band + cband;
     for (uint64_t r = first; r < nrows; r += stride) {
         const uint64_t p = st.cursor + r;
         const T *rp = mat + p * B;
@@ -161,6 +164,47 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
         const double rt = 1.0 / double(tot);
         const double mean_entropy = (he_base + hrow) / dn;
         nread++;
+        if constexpr (COARSE) {
+            if (vec && coarse_on) {  // COARSE tier: decides every row farther than cband from the threshold
+                const float rtn = float(rt * rn);
+                const dvs_f2 r2 = {rtn, rtn};
+                double c0 = 0.0, c1 = 0.0;
+                const uint64_t full = B - B % (256 * P_CH);
+                uint64_t i0 = 0;
+                for (; i0 < full; i0 += 256 * P_CH) {
+                    Raw4<T> raw[P_CH];
+#pragma unroll
+                    for (int j = 0; j < P_CH; j++) raw[j].load(rp + i0 + uint64_t(j) * 256 + lane * 4);
+                    // (the scheduler would otherwise sink each load to its use: one 1 KiB request in
+                    // flight per wave instead of sixteen)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < P_CH; j += 2) {
+                        const uint64_t i = i0 + uint64_t(j) * 256 + lane * 4;
+                        raw[j].pin();  // nothing of chunk j is consumed (converted) above this point
+                        raw[j + 1].pin();
+                        c0 += double(coarse4(raw[j].c, *reinterpret_cast<const float4 *>(slf + i), r2));
+                        c1 += double(coarse4(raw[j + 1].c, *reinterpret_cast<const float4 *>(slf + i + 256), r2));
+                    }
+                }
+                for (; i0 < B; i0 += 256) {
+                    const uint64_t i = i0 + lane * 4;
+                    Raw4<T> raw;
+                    raw.load(rp + i);
+                    c0 += double(coarse4(raw.c, *reinterpret_cast<const float4 *>(slf + i), r2));
+                }
+                const double jf0 = -dvs_wave_sum(c0 + c1) - mean_entropy;
+                if (!(jf0 > thr_c_lo)) continue;  // (NaN: a negative bin, rejected as the reference does)
+                if (jf0 > thr_c_hi) {
+                    if (lane == 0) {
+                        atomicMin(evp, (unsigned long long)p);
+                        atomicMin(evp + 16, (unsigned long long)p);
+                    }
+                    continue;
+                }
+                nmid++;
+            }
+        }
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, xmin = 0.0;
         if (vec) {
             const uint64_t full = B - B % (256 * P_CH);
@@ -237,17 +281,20 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
 // when an event is found are 255, not 2040.  One barrier per row: the waves' partial sums alternate
 // between two sets of LDS slots.  Lane l of wave w owns bins 4 (512 c + 64 w + l) .. + 3 of every
 // 2048-bin chunk c.  red: 2 x 24 doubles.
-template <typename T>
+template <typename T, bool COARSE>
 __device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const uint32_t *__restrict__ totals,
-                                               const double *__restrict__ rowH, const double *sl, uint64_t B,
+                                               const double *__restrict__ rowH, const double *sl,
+                                               const float *slf, uint64_t B,
                                                const PState &st, double he_base, unsigned long long *evp,
                                                unsigned long long *softp, uint64_t first, uint64_t stride,
                                                uint64_t nrows, double *red, uint32_t &nread,
-                                               uint32_t &nprecise) {
+                                               uint32_t &nprecise, uint32_t &nmid, bool coarse_on) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double dn = double(st.n), rn = 1.0 / dn;
     const double thr_fast = st.thr - st.band - FAST_BAND, thr_sure = st.thr + st.band + FAST_BAND;
     const bool vec = (B & 2047) == 0;
+    const double cband = coarse_band(B);
+    const double thr_c_lo = st.thr - st.band - cband, thr_c_hi = st.thr + st.band + cband;
     uint32_t par = 0;
     for (uint64_t r = first; r < nrows; r += stride, par ^= 1) {
         const uint64_t p = st.cursor + r;
@@ -256,6 +303,48 @@ __device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const 
         const uint32_t tot = totals[p];
         const double hrow = rowH[p];
         const double rt = tot ? 1.0 / double(tot) : 0.0;
+        if constexpr (COARSE) {
+            if (vec && B <= 4 * 2048 && coarse_on) {  // COARSE tier first (select_dev.h); its sums use red[48..]
+                const float rtn = float(rt * rn);
+                const dvs_f2 r2 = {rtn, rtn};
+                double c0 = 0.0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint64_t i = uint64_t(j) * 2048 + tid * 4;
+                    if (i < B) {
+                        Raw4<T> raw;
+                        raw.load(rp + i);
+                        c0 += double(coarse4(raw.c, *reinterpret_cast<const float4 *>(slf + i), r2));
+                    }
+                }
+                c0 = dvs_wave_sum(c0);
+                double *cslot = red + 48 + par * 16;
+                if (lane == 0) {
+                    cslot[wave] = c0;
+                    if (wave == 0) cslot[8] = __longlong_as_double((long long)ev);
+                }
+                __syncthreads();
+                if ((unsigned long long)__double_as_longlong(cslot[8]) < p) break;
+                if (tot == 0) continue;
+                double hc = 0.0;
+#pragma unroll
+                for (int w = 0; w < P_THREADS / 64; w++) hc += cslot[w];
+                const double jf0 = -hc - (he_base + hrow) / dn;
+                if (tid == 0) nread++;
+                if (!(jf0 > thr_c_lo)) continue;
+                if (jf0 > thr_c_hi) {
+                    if (tid == 0) {
+                        atomicMin(evp, (unsigned long long)p);
+                        atomicMin(evp + 16, (unsigned long long)p);
+                    }
+                    continue;
+                }
+                if (tid == 0) {
+                    nmid++;
+                    nread--;  // counted again below
+                }
+            }
+        }
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, xmin = 0.0;
         if (vec) {
             for (uint64_t i0 = 0; i0 < B; i0 += 4 * 2048) {  // up to four chunks requested at once
@@ -412,7 +501,10 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint64_t B = d.B;
     double *sl = reinterpret_cast<double *>(smem);
-    double *scratch = sl + ((B + 1) & ~1ull);
+    // f32 copy of sl / n for the COARSE tier (count matrices whose state fits the register cache)
+    constexpr bool COARSE = CACHED && sizeof(T) == 4;
+    float *slf = reinterpret_cast<float *>(sl + ((B + 1) & ~1ull));
+    double *scratch = sl + ((B + 1) & ~1ull) + (COARSE ? ((B + 3) & ~3ull) / 2 : 0);
     double *s_mH = scratch + 128;
     double *s_tot = s_mH + maxn;  // member row totals and their correctly rounded reciprocals
     double *s_rt = s_tot + maxn;
@@ -457,12 +549,17 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     __syncthreads();
     {
         const double *low = d.M + uint64_t(s_slot[st.li]) * B;
-        for (uint64_t i = tid; i < B; i += P_THREADS) sl[i] = d.S[i] - low[i];
+        const double rn0 = 1.0 / double(st.n);
+        for (uint64_t i = tid; i < B; i += P_THREADS) {
+            const double v = d.S[i] - low[i];
+            sl[i] = v;
+            if (COARSE) slf[i] = coarse_sl(v, rn0);
+        }
     }
     __syncthreads();
 
     uint32_t gen = 0, epoch = 0;
-    uint32_t nread = 0, nprecise = 0;
+    uint32_t nread = 0, nprecise = 0, nmid = 0;
     uint32_t exit_status = SEL_RUN;  // what the lead block writes to ctl->status on exit
     uint32_t arb_stage = 0;
     uint64_t arb_pos = 0;
@@ -472,6 +569,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     const uint64_t nwaves = uint64_t(nwg) * wpb;      // scanning waves
     const uint32_t wg_thresh = sync->wg_thresh;       // (written by the host before the launch)
     const double wg_scale = double(sync->wg_scale);
+    const bool coarse_on = (sync->no_coarse & 1u) == 0;
+    if (sync->no_coarse & 2u) st.thr = 1e300;  // measurement aid: no row is ever an event (pure streaming)
     bool wgmode = false;
     if (wg_thresh) st.window = p_next_window(st, nwg, wg_thresh, wg_scale, wgmode);
     // Leave-one-out jobs (the set size is constant in this mode): job (r, part) covers the
@@ -514,13 +613,13 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // previous event overlap the others' scan instead of delaying the rendezvous)
         if (!lead || G == 1) {
             if (wgmode)
-                p_scan_rows_wg<T>(mat, d.totals, d.rowH, sl, B, st, st.sumH - s_mH[st.li], evp,
-                                  &sync->soft[epoch % 3][0], blockIdx.x, nwg, nrows, scratch + 64, nread,
-                                  nprecise);
+                p_scan_rows_wg<T, COARSE>(mat, d.totals, d.rowH, sl, slf, B, st, st.sumH - s_mH[st.li], evp,
+                                          &sync->soft[epoch % 3][0], blockIdx.x, nwg, nrows, scratch + 32,
+                                          nread, nprecise, nmid, coarse_on);
             else
-                p_scan_rows<T>(mat, d.totals, d.rowH, sl, B, st, st.sumH - s_mH[st.li], evp,
-                               &sync->soft[epoch % 3][0], uint64_t(blockIdx.x) * wpb + wave, nwaves, nrows,
-                               lane, nread, nprecise);
+                p_scan_rows<T, COARSE>(mat, d.totals, d.rowH, sl, slf, B, st, st.sumH - s_mH[st.li], evp,
+                                       &sync->soft[epoch % 3][0], uint64_t(blockIdx.x) * wpb + wave, nwaves,
+                                       nrows, lane, nread, nprecise, nmid, coarse_on);
         }
         P_STAMP(0);
         if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
@@ -970,6 +1069,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                         const double sn = v + f;
                         const double nv = sn - (low_is_new ? f : cand_freq_x(lrow, i, ltot, lrt));
                         sl[i] = nv;
+                        if (COARSE) slf[i] = coarse_sl(nv, rn);
                         if (lead) d.base[i] = nv / dn;
                     }
                 }
@@ -993,6 +1093,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     if (lane == 0 && nread) {
         atomicAdd(&ctl->rows_scored, (unsigned long long)nread);
         if (nprecise) atomicAdd(&ctl->rows_rechecked, (unsigned long long)nprecise);
+        if (nmid) atomicAdd(&sync->dbg[15], (unsigned long long)nmid);  // rows the COARSE tier passed on
     }
     if (lead && tid == 0) {
         ctl->cursor = st.cursor;
@@ -1025,6 +1126,7 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     init.wg_scale = 1.5f;
     if (const char *e = getenv("DVS_PERSIST_WG_ROUNDS")) init.wg_thresh = uint32_t(atoi(e));
     if (const char *e = getenv("DVS_PERSIST_WG_SCALE")) init.wg_scale = float(atof(e));
+    init.no_coarse = (getenv("DVS_PERSIST_NO_COARSE") ? 1u : 0u) | (getenv("DVS_PERSIST_NO_EVENTS") ? 2u : 0u);
     DVS_HIP(ctx, hipMemcpyAsync(s->psync, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     DVS_HIP(ctx, hipMemsetAsync(s->ppart, 0, p_acc_bytes(s->persist_maxn), ctx->stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1062,7 +1164,8 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     s->persist_maxn = p_maxn(cached);
     s->persist_maxjobs = p_maxjobs(cached);
     if (s->cap > s->persist_maxn) return DVS_OK;
-    const size_t lds = ((B + 1) & ~1ull) * 8 + 128 * 8 + size_t(s->persist_maxn) * 52 + 8 + P_SOFT * 8 + 64;
+    const size_t lds = ((B + 1) & ~1ull) * 8 + (cached && s->mat_kind == 0 ? ((B + 3) & ~3ull) * 4 : 0) + 128 * 8 +
+                       size_t(s->persist_maxn) * 52 + 8 + P_SOFT * 8 + 64;
     if (lds > ctx->lds_per_block) return DVS_OK;
     s->persist_lds = lds;
     const void *fn =

@@ -899,6 +899,7 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat) {
                             dbg[2 + 16 * w] / 100.0, dbg[3 + 16 * w] / 100.0, dbg[4 + 16 * w] / 100.0,
                             dbg[6 + 16 * w] / 100.0, dbg[7 + 16 * w] / 100.0, dbg[8 + 16 * w] / 100.0,
                             dbg[5 + 16 * w] / 100.0);
+                fprintf(stderr, "[dvs persist] rows passed on by the coarse tier: %llu\n", dbg[16 + 15]);
             }
         }
         if (c.status == SEL_DONE) return DVS_OK;
@@ -1253,6 +1254,76 @@ __global__ void log2_acc_selftest_kernel(double *out) {
     for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o, 64));
     if ((threadIdx.x & 63) == 0)
         atomicMax(reinterpret_cast<unsigned long long *>(out), (unsigned long long)__double_as_longlong(worst));
+}
+
+// COARSE tier (select_dev.h): max over EVERY f32 y in [2^-101, 2) of
+// |v_log_f32(y) - log2 y| / (2^-23 max(1, |log2 y|)), the k of its error bound; and the exact
+// quotient by fma against the division, over 2^26 (count, total) pairs per launch
+__global__ void log2_f32_selftest_kernel(double *out) {
+    double worst = 0.0;
+    const uint64_t first = uint64_t(26) << 23, last = uint64_t(128) << 23;  // biased exponents 26 .. 127
+    for (uint64_t b = first + uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; b < last;
+         b += uint64_t(gridDim.x) * blockDim.x) {
+        const float y = __uint_as_float(uint32_t(b));
+        const double ref = log2(double(y));
+        const double err = fabs(double(__builtin_amdgcn_logf(y)) - ref) / (0x1p-23 * fmax(1.0, fabs(ref)));
+        worst = fmax(worst, err);
+    }
+    for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o, 64));
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(reinterpret_cast<unsigned long long *>(out), (unsigned long long)__double_as_longlong(worst));
+}
+
+__global__ void exact_div_selftest_kernel(unsigned long long *bad) {
+    const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    unsigned long long nbad = 0;
+    uint64_t x = (t + 1) * 0x9E3779B97F4A7C15ull;
+    for (int it = 0; it < 64; it++) {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        uint32_t tot = uint32_t(x >> 32), c = uint32_t(x);
+        if (it & 1) tot >>= (x >> 27) & 31;  // short totals too
+        if (!tot) tot = 1;
+        if (it & 2) c %= tot;  // frequencies proper (c <= tot), and any pair
+        const double dt = double(tot);
+        if (exact_div_u32(double(c), dt, 1.0 / dt) != double(c) / dt) nbad++;
+    }
+    // every count up to a small total, exhaustively
+    const uint32_t tot = uint32_t(t % 8192) + 1, c0 = uint32_t(t / 8192);
+    if (c0 <= tot) {
+        const double dt = double(tot);
+        if (exact_div_u32(double(c0), dt, 1.0 / dt) != double(c0) / dt) nbad++;
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
+extern "C" int dvs_selftest_log2_f32(dvs_ctx *ctx, double *max_ulps) {
+    if (!ctx || !max_ulps) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    double *d = nullptr;
+    DVS_HIP(ctx, hipMalloc(&d, 8));
+    DVS_HIP(ctx, hipMemsetAsync(d, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(log2_f32_selftest_kernel, dim3(4096), dim3(256), 0, ctx->stream, d);
+    DVS_HIP(ctx, hipGetLastError());
+    DVS_HIP(ctx, hipMemcpyAsync(max_ulps, d, 8, hipMemcpyDeviceToHost, ctx->stream));
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d);
+    return DVS_OK;
+}
+
+extern "C" int dvs_selftest_exact_div(dvs_ctx *ctx, uint64_t *mismatches) {
+    if (!ctx || !mismatches) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long *d = nullptr;
+    DVS_HIP(ctx, hipMalloc(&d, 8));
+    DVS_HIP(ctx, hipMemsetAsync(d, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(exact_div_selftest_kernel, dim3(8192 * 8192 / 256), dim3(256), 0, ctx->stream, d);
+    DVS_HIP(ctx, hipGetLastError());
+    DVS_HIP(ctx, hipMemcpyAsync(mismatches, d, 8, hipMemcpyDeviceToHost, ctx->stream));
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d);
+    return DVS_OK;
 }
 
 extern "C" int dvs_selftest_log2_acc(dvs_ctx *ctx, double *max_rel_err) {

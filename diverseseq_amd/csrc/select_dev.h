@@ -86,12 +86,45 @@ __device__ __forceinline__ double fast_neg_xlog2x(double x) {
     return -xm * (double(e) + double(l));
 }
 
+// COARSE tier (count matrices, persistent engine): everything in f32 -- y = c * (1 / (T n)) + sl / n
+// by packed fma, v_log_f32 on the whole value, the four products of a chunk added in f32 -- and one
+// f64 add per four bins: ~22 issue cycles per bin where the FAST tier needs ~127.  With e = 2^-24
+// and H = the entropy of the mean vector (<= log2 B), its score is off by at most
+//   3 e (H + 1.45)   y: rounding of sl / n, of 1 / (T n) (or of a count >= 2^24) and of the fma;
+//                    d(-y log2 y)/dy = -(log2 y + 1 / ln 2), and sum y = 1
+// + 2 k e (H + 1)    v_log_f32: k ulp of a result of magnitude max(1, |log2 y|); k <= 1.5 is asserted
+//                    over EVERY f32 in [2^-101, 2) by dvs_selftest_log2_f32
+// + e H              the f32 product y * log2 y
+// + 2 e H            the two f32 additions that fold four products
+// = e ((6 + 2k) H + 4.35 + 2k) <= e (9 log2 B + 7.4); COARSE_BAND adds a quarter on top.
+// A row scoring beyond thr +- (band + COARSE_BAND) is decided here; anything closer is scored again
+// by the FAST tier.  A bin of sl that is exactly zero is stored as 1e-30 (contributes ~1e-28), so
+// log2 never sees a zero; a negative bin makes v_log_f32 return NaN, the score NaN, and the row is
+// rejected as the reference rejects it (record.rs:95: log2 of a negative is NaN, NaN > x is false).
+typedef float dvs_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double coarse_band(uint64_t B) {
+    return 1.25 * 0x1p-24 * (9.0 * log2(double(B)) + 7.4);
+}
+__device__ __forceinline__ float coarse_sl(double v, double rn) { return v == 0.0 ? 1e-30f : float(v * rn); }
+// sum of y log2 y over 4 consecutive bins (<= 0)
+__device__ __forceinline__ float coarse4(const uint4 c, const float4 b, const dvs_f2 r2) {
+    const dvs_f2 c01 = {float(c.x), float(c.y)}, c23 = {float(c.z), float(c.w)};
+    const dvs_f2 y01 = __builtin_elementwise_fma(c01, r2, (dvs_f2){b.x, b.y});
+    const dvs_f2 y23 = __builtin_elementwise_fma(c23, r2, (dvs_f2){b.z, b.w});
+    const dvs_f2 l01 = {__builtin_amdgcn_logf(y01.x), __builtin_amdgcn_logf(y01.y)};
+    const dvs_f2 l23 = {__builtin_amdgcn_logf(y23.x), __builtin_amdgcn_logf(y23.y)};
+    const dvs_f2 s = y01 * l01 + y23 * l23;
+    return s.x + s.y;
+}
+
 // 4 consecutive bins as they sit in memory (converted to f64 only when consumed, so a
 // batch of in-flight chunks costs 4 VGPRs each for a count matrix)
 template <typename T> struct Raw4;
 template <> struct Raw4<uint32_t> {
     uint4 c;
     __device__ __forceinline__ void load(const uint32_t *p) { c = *reinterpret_cast<const uint4 *>(p); }
+    // keeps the four registers as loaded up to this point (see the burst loops)
+    __device__ __forceinline__ void pin() { asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w)); }
     __device__ __forceinline__ void get(double &v0, double &v1, double &v2, double &v3) const {
         v0 = double(c.x); v1 = double(c.y); v2 = double(c.z); v3 = double(c.w);
     }
@@ -102,6 +135,7 @@ template <> struct Raw4<double> {
         a = *reinterpret_cast<const double2 *>(p);
         b = *reinterpret_cast<const double2 *>(p + 2);
     }
+    __device__ __forceinline__ void pin() {}
     __device__ __forceinline__ void get(double &v0, double &v1, double &v2, double &v3) const {
         v0 = a.x; v1 = a.y; v2 = b.x; v3 = b.y;
     }

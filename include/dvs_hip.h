@@ -198,6 +198,13 @@ int dvs_selftest_fast_log2(dvs_ctx *ctx, double *max_abs_err);
 /* diagnostic: max |log2_acc(x) - log2(x)| / max(1, |log2 x|) of the f64 log2 the precise
  * evaluations use (select_dev.h), over 2^17 mantissas x 80 binades */
 int dvs_selftest_log2_acc(dvs_ctx *ctx, double *max_rel_err);
+/* diagnostic: the hardware term of the persistent engine's coarse (f32) tier: max over every
+ * f32 y in [2^-101, 2) of |v_log_f32(y) - log2 y| in units of 2^-23 max(1, |log2 y|) */
+int dvs_selftest_log2_f32(dvs_ctx *ctx, double *max_ulps);
+/* diagnostic: count / total by the fma sequence the selection kernels use in place of the f64
+ * division (select_dev.h exact_div_u32) against the division itself: every count <= total <=
+ * 8192 and 2^32 random pairs; reports the number of mismatches (must be 0) */
+int dvs_selftest_exact_div(dvs_ctx *ctx, uint64_t *mismatches);
 
 /* ---- mash ----------------------------------------------------------------- *
  * dvs_mash_sketch replaces _dvs.mash_sketch (src/distance.rs:136-182) for a

@@ -531,6 +531,26 @@ def test_log2_acc_error_bound(ctx):
     assert 0.0 <= err.value < 1e-15, err.value
 
 
+def test_coarse_tier_log2_error_bound(ctx):
+    """the hardware term of the persistent engine's f32 tier: v_log_f32 over EVERY f32 in
+    [2^-101, 2) stays within the 1.5 ulp (of max(1, |log2 y|)) that COARSE_BAND budgets"""
+    import ctypes as C
+
+    k = C.c_double()
+    ctx.check(ctx._L.dvs_selftest_log2_f32(ctx._h, C.byref(k)))
+    print("max |v_log_f32 - log2| in ulps of the result:", k.value)
+    assert 0.0 < k.value <= 1.5, k.value
+
+
+def test_exact_quotient_by_fma(ctx):
+    """count / total by fma (no f64 division) is the correctly rounded quotient, bit for bit"""
+    import ctypes as C
+
+    bad = C.c_uint64(1)
+    ctx.check(ctx._L.dvs_selftest_exact_div(ctx._h, C.byref(bad)))
+    assert bad.value == 0
+
+
 # ------------------------------------------------ genome-scale rows (configs C3 / C5, scaled down)
 def test_genome_length_sequences_max_and_sketch(ctx):
     """C3 / C5 shapes at reduced N: ~3 Mb sequences (92 tiles each), `max` min_size 5 and
