@@ -74,7 +74,10 @@ struct PSync {
     float wg_scale;      // ... and are cursor * wg_scale / size rows long (rounded up to whole rounds)
     uint32_t no_coarse;  // measurement aid: skip the COARSE tier
     uint32_t pad2[60];
-    unsigned long long ev[3][32];  // event words, slot = epoch % 3 (ev[s][0]; ev[s][16] = the same position when sure)
+    // event words, slot = epoch % 3, one copy per group g = blockIdx % 8 (a wave polls before every
+    // row: one word for the whole grid serialises those loads at the memory side): ev[s][32 g] = first
+    // event position, ev[s][32 g + 16] = the same position when the event is sure
+    unsigned long long ev[3][8 * 32];
     // candidates whose fast score is within FAST_BAND of the threshold: count at [s][0], positions
     // from [s][8]; the workgroups re-evaluate them in f64 after the rendezvous, in stream order
     unsigned long long soft[3][8 + 64];
@@ -135,6 +138,20 @@ __device__ bool grid_barrier(PSync *sync, uint32_t G, uint32_t &gen, int *s_ok) 
     return *s_ok != 0;
 }
 
+// publishing an event: every group copy of the slot (evs = its base)
+__device__ __forceinline__ void p_post_event_wave(unsigned long long *evs, uint64_t p, bool sure, uint32_t lane) {
+    if (lane < 8) {
+        atomicMin(evs + lane * 32, (unsigned long long)p);
+        if (sure) atomicMin(evs + lane * 32 + 16, (unsigned long long)p);
+    }
+}
+__device__ __forceinline__ void p_post_event_thread(unsigned long long *evs, uint64_t p, bool sure) {
+    for (uint32_t g = 0; g < 8; g++) {
+        atomicMin(evs + g * 32, (unsigned long long)p);
+        if (sure) atomicMin(evs + g * 32 + 16, (unsigned long long)p);
+    }
+}
+
 // One wave's share of the window, as scan_rows_hot but against the unscaled vector sl:
 // x = (sl_i + c_i / T) / n  computed as  fma(c, 1/T, sl) * (1/n).
 template <typename T, bool COARSE>
@@ -142,7 +159,8 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                                             const uint32_t *__restrict__ totals,
                                             const double *__restrict__ rowH, const double *sl,
                                             const float *slf, uint64_t B, const PState &st, double he_base,
-                                            unsigned long long *evp, unsigned long long *softp,
+                                            unsigned long long *evp, unsigned long long *evs,
+                                            unsigned long long *softp,
                                             uint64_t first, uint64_t stride, uint64_t nrows,
                                             uint32_t lane, uint32_t &nread,
                                             uint32_t &nprecise, uint32_t &nmid, bool coarse_on) {
@@ -196,10 +214,7 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                 const double jf0 = -dvs_wave_sum(c0 + c1) - mean_entropy;
                 if (!(jf0 > thr_c_lo)) continue;  // (NaN: a negative bin, rejected as the reference does)
                 if (jf0 > thr_c_hi) {
-                    if (lane == 0) {
-                        atomicMin(evp, (unsigned long long)p);
-                        atomicMin(evp + 16, (unsigned long long)p);
-                    }
+                    p_post_event_wave(evs, p, true, lane);
                     continue;
                 }
                 nmid++;
@@ -253,12 +268,11 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
         const double hf = dvs_wave_sum((a0 + a1) + (a2 + a3));
         const double mn = dvs_wave_min(xmin);
         const double jf = hf - mean_entropy;
-        if (!(mn < 0.0) && jf > thr_fast && lane == 0) {
-            if (jf > thr_sure) {
-                // above the threshold by more than every error bound: no f64 re-evaluation needed
-                atomicMin(evp, (unsigned long long)p);
-                atomicMin(evp + 16, (unsigned long long)p);
-            } else {
+        if (!(mn < 0.0) && jf > thr_sure) {
+            // above the threshold by more than every error bound: no f64 re-evaluation needed
+            p_post_event_wave(evs, p, true, lane);
+        } else if (!(mn < 0.0) && jf > thr_fast && lane == 0) {
+            {
                 // within FAST_BAND of the threshold: listed, not an event -- the scan goes on and
                 // the workgroups settle it in f64 after the rendezvous (a wave doing that alone
                 // would hold the whole grid at the barrier for 4^k f64 logarithms)
@@ -268,7 +282,7 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                     if (__hip_atomic_exchange(softp + 8 + idx, (unsigned long long)p, RLX_AGENT) == 1ull)
                         softp[7] = 1;  // (never: position 1 is a seed; consumes the result)
                 } else {
-                    atomicMin(evp, (unsigned long long)p);  // list full: a plain (unsure) event
+                    p_post_event_thread(evs, p, false);  // list full: a plain (unsure) event
                 }
             }
         }
@@ -286,7 +300,8 @@ __device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const 
                                                const double *__restrict__ rowH, const double *sl,
                                                const float *slf, uint64_t B,
                                                const PState &st, double he_base, unsigned long long *evp,
-                                               unsigned long long *softp, uint64_t first, uint64_t stride,
+                                               unsigned long long *evs, unsigned long long *softp,
+                                               uint64_t first, uint64_t stride,
                                                uint64_t nrows, double *red, uint32_t &nread,
                                                uint32_t &nprecise, uint32_t &nmid, bool coarse_on) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -299,7 +314,7 @@ __device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const 
     for (uint64_t r = first; r < nrows; r += stride, par ^= 1) {
         const uint64_t p = st.cursor + r;
         const T *rp = mat + p * B;
-        const unsigned long long ev = __hip_atomic_load(evp, RLX_AGENT);
+        const unsigned long long ev = wave == 0 ? __hip_atomic_load(evp, RLX_AGENT) : 0ull;
         const uint32_t tot = totals[p];
         const double hrow = rowH[p];
         const double rt = tot ? 1.0 / double(tot) : 0.0;
@@ -333,10 +348,7 @@ __device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const 
                 if (tid == 0) nread++;
                 if (!(jf0 > thr_c_lo)) continue;
                 if (jf0 > thr_c_hi) {
-                    if (tid == 0) {
-                        atomicMin(evp, (unsigned long long)p);
-                        atomicMin(evp + 16, (unsigned long long)p);
-                    }
+                    if (tid == 0) p_post_event_thread(evs, p, true);
                     continue;
                 }
                 if (tid == 0) {
@@ -400,8 +412,7 @@ __device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const 
             nread++;
             if (neg == 0.0 && jf > thr_fast) {
                 if (jf > thr_sure) {
-                    atomicMin(evp, (unsigned long long)p);
-                    atomicMin(evp + 16, (unsigned long long)p);
+                    p_post_event_thread(evs, p, true);
                 } else {
                     nprecise++;
                     const unsigned long long idx = atomicAdd(softp, 1ull);
@@ -409,7 +420,7 @@ __device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const 
                         if (__hip_atomic_exchange(softp + 8 + idx, (unsigned long long)p, RLX_AGENT) == 1ull)
                             softp[7] = 1;  // (never: position 1 is a seed; consumes the result)
                     } else {
-                        atomicMin(evp, (unsigned long long)p);  // list full: a plain (unsure) event
+                        p_post_event_thread(evs, p, false);  // list full: a plain (unsure) event
                     }
                 }
             }
@@ -597,15 +608,14 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         }                                                                  \
     } while (0)
     for (;;) {
-        unsigned long long *evp = &sync->ev[epoch % 3][0];
+        unsigned long long *evs = &sync->ev[epoch % 3][0];            // the slot: eight group copies
+        unsigned long long *evp = evs + (blockIdx.x & 7u) * 32;       // this workgroup's copy
         // the slot of the NEXT epoch is cleared now; an exchange (its result is consumed) has been
         // performed before this thread's arrival at the barrier below can be
-        if (lead && tid == 0 &&
-            (__hip_atomic_exchange(&sync->ev[(epoch + 1) % 3][0], SEL_NONE, RLX_AGENT) == 1ull) +
-                    (__hip_atomic_exchange(&sync->ev[(epoch + 1) % 3][16], SEL_NONE, RLX_AGENT) == 1ull) +
-                    (__hip_atomic_exchange(&sync->soft[(epoch + 1) % 3][0], 0ull, RLX_AGENT) == ~0ull) ==
-                3)
-            sync->pad0[1] = 1;  // (consumes the results; position 1 is a seed, never an event)
+        if (lead && tid < 17 &&
+            __hip_atomic_exchange(tid < 16 ? &sync->ev[(epoch + 1) % 3][tid * 16] : &sync->soft[(epoch + 1) % 3][0],
+                                  tid < 16 ? SEL_NONE : 0ull, RLX_AGENT) == 1ull)
+            sync->pad0[1] = 1;  // (consumes the results; position 1 is a seed, never an event or a count)
         const uint64_t end = umin64(st.cursor + uint64_t(st.window), st.npos);
         const uint64_t nrows = end - st.cursor;
         // ================= scan
@@ -613,11 +623,11 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // previous event overlap the others' scan instead of delaying the rendezvous)
         if (!lead || G == 1) {
             if (wgmode)
-                p_scan_rows_wg<T, COARSE>(mat, d.totals, d.rowH, sl, slf, B, st, st.sumH - s_mH[st.li], evp,
+                p_scan_rows_wg<T, COARSE>(mat, d.totals, d.rowH, sl, slf, B, st, st.sumH - s_mH[st.li], evp, evs,
                                           &sync->soft[epoch % 3][0], blockIdx.x, nwg, nrows, scratch + 32,
                                           nread, nprecise, nmid, coarse_on);
             else
-                p_scan_rows<T, COARSE>(mat, d.totals, d.rowH, sl, slf, B, st, st.sumH - s_mH[st.li], evp,
+                p_scan_rows<T, COARSE>(mat, d.totals, d.rowH, sl, slf, B, st, st.sumH - s_mH[st.li], evp, evs,
                                        &sync->soft[epoch % 3][0], uint64_t(blockIdx.x) * wpb + wave, nwaves,
                                        nrows, lane, nread, nprecise, nmid, coarse_on);
         }
@@ -1120,7 +1130,8 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     const SelDev &d = s->dev;
     PSync init;
     memset(&init, 0, sizeof init);
-    for (int i = 0; i < 3; i++) init.ev[i][0] = init.ev[i][16] = SEL_NONE;
+    for (int i = 0; i < 3; i++)
+        for (int w = 0; w < 16; w++) init.ev[i][w * 16] = SEL_NONE;
     // a row per workgroup while a window is at most this many rounds of the grid (default policy only)
     init.wg_thresh = s->params.window ? 0u : 4u;
     init.wg_scale = 1.5f;
