@@ -72,6 +72,29 @@ __device__ __forceinline__ double dvs_wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// the same sum by DPP (register cross-lane moves, no LDS crossbar): ~23 instructions where the
+// shuffle form needs 12 ds_bpermute round trips; every lane gets the total
+template <int CTRL>
+__device__ __forceinline__ double dvs_dpp_mov(double v) {
+    const long long b = __double_as_longlong(v);
+    int lo = int(b), hi = int(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ double dvs_wave_sum_dpp(double v) {
+    v += dvs_dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dvs_dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dvs_dpp_mov<0x141>(v);  // row_half_mirror
+    v += dvs_dpp_mov<0x140>(v);  // row_mirror: every lane holds the sum of its row of 16
+    const long long b = __double_as_longlong(v);
+    const int lo = int(b), hi = int(b >> 32);
+    auto row = [&](int l) {
+        return __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, l) << 32) |
+                                                (unsigned)__builtin_amdgcn_readlane(lo, l)));
+    };
+    return (row(0) + row(16)) + (row(32) + row(48));
+}
 __device__ __forceinline__ double dvs_wave_min(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));

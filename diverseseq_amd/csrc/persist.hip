@@ -211,7 +211,7 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                     raw.load(rp + i);
                     c0 += double(coarse4(raw.c, *reinterpret_cast<const float4 *>(slf + i), r2));
                 }
-                const double jf0 = -dvs_wave_sum(c0 + c1) - mean_entropy;
+                const double jf0 = -dvs_wave_sum_dpp(c0 + c1) - mean_entropy;
                 if (!(jf0 > thr_c_lo)) continue;  // (NaN: a negative bin, rejected as the reference does)
                 if (jf0 > thr_c_hi) {
                     p_post_event_wave(evs, p, true, lane);
@@ -332,7 +332,7 @@ __device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const 
                         c0 += double(coarse4(raw.c, *reinterpret_cast<const float4 *>(slf + i), r2));
                     }
                 }
-                c0 = dvs_wave_sum(c0);
+                c0 = dvs_wave_sum_dpp(c0);
                 double *cslot = red + 48 + par * 16;
                 if (lane == 0) {
                     cslot[wave] = c0;
@@ -424,6 +424,99 @@ __device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const 
                     }
                 }
             }
+        }
+    }
+}
+
+// The row-per-workgroup scan as a stream (4^k = 4096 bins, COARSE tier): every thread keeps the
+// two 16-byte requests of each of the next D rows of its workgroup in flight, so the grid streams
+// rows at memory speed while an event still leaves only ~one row per workgroup to drain.  A row the
+// COARSE tier cannot decide is scored again by p_scan_rows_wg (FAST tier) as a one-row window.
+// red: the 128-double scratch area minus its first 32 (slots [48..80) are this function's).
+template <typename T>
+__device__ __forceinline__ void p_scan_rows_wg_stream(const T *__restrict__ mat,
+                                                      const uint32_t *__restrict__ totals,
+                                                      const double *__restrict__ rowH, const double *sl,
+                                                      const float *slf, const PState &st, double he_base,
+                                                      unsigned long long *evp, unsigned long long *evs,
+                                                      unsigned long long *softp, uint64_t first,
+                                                      uint64_t stride, uint64_t nrows, double *red,
+                                                      uint32_t &nread, uint32_t &nprecise, uint32_t &nmid) {
+    constexpr uint64_t B = 4096;
+    constexpr int D = 4;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double dn = double(st.n), rn = 1.0 / dn;
+    const double cband = coarse_band(B);
+    const double thr_c_lo = st.thr - st.band - cband, thr_c_hi = st.thr + st.band + cband;
+    struct Row {
+        Raw4<T> r0, r1;
+        uint32_t tot;
+        double hrow;
+        unsigned long long ev;
+    };
+    auto issue = [&](Row &w, uint64_t r) {
+        const uint64_t p = st.cursor + r;
+        const T *rp = mat + p * B;
+        w.r0.load(rp + tid * 4);
+        w.r1.load(rp + 2048 + tid * 4);
+        w.tot = totals[p];
+        if (wave == 0) {  // the row's entropy and the event word travel through LDS with the partial sums
+            w.hrow = rowH[p];
+            w.ev = __hip_atomic_load(evp, RLX_AGENT);
+        }
+    };
+    uint32_t par = 0;
+    auto process = [&](Row &w, uint64_t r) -> bool {  // false: an earlier event exists, the workgroup is done
+        const uint64_t p = st.cursor + r;
+        const float rtn = w.tot ? float(rn / double(w.tot)) : 0.0f;
+        const dvs_f2 r2 = {rtn, rtn};
+        w.r0.pin();
+        w.r1.pin();
+        const double c = double(coarse4(w.r0.c, *reinterpret_cast<const float4 *>(slf + tid * 4), r2)) +
+                         double(coarse4(w.r1.c, *reinterpret_cast<const float4 *>(slf + 2048 + tid * 4), r2));
+        const double cs = dvs_wave_sum_dpp(c);
+        double *slot = red + 48 + par * 16;
+        par ^= 1;
+        if (lane == 0) {
+            slot[wave] = cs;
+            if (wave == 0) {
+                slot[8] = __longlong_as_double((long long)w.ev);
+                slot[9] = w.hrow;
+            }
+        }
+        __syncthreads();
+        if ((unsigned long long)__double_as_longlong(slot[8]) < p) return false;
+        if (w.tot == 0) return true;
+        double hc = 0.0;
+#pragma unroll
+        for (int q = 0; q < P_THREADS / 64; q++) hc += slot[q];
+        const double jf0 = -hc - (he_base + slot[9]) / dn;
+        if (tid == 0) nread++;
+        if (!(jf0 > thr_c_lo)) return true;  // (NaN: a negative bin, rejected as the reference does)
+        if (jf0 > thr_c_hi) {
+            if (tid == 0) p_post_event_thread(evs, p, true);
+            return true;
+        }
+        if (tid == 0) {
+            nmid++;
+            nread--;  // counted again by the FAST pass
+        }
+        uint32_t nm = 0;
+        p_scan_rows_wg<T, false>(mat, totals, rowH, sl, slf, B, st, he_base, evp, evs, softp, r, nrows, nrows, red,
+                                 nread, nprecise, nm, false);
+        return true;
+    };
+    Row w[D];
+#pragma unroll
+    for (int d = 0; d < D; d++)
+        if (first + uint64_t(d) * stride < nrows) issue(w[d], first + uint64_t(d) * stride);
+    for (uint64_t base = first; base < nrows; base += uint64_t(D) * stride) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const uint64_t r = base + uint64_t(d) * stride;
+            if (r >= nrows) return;
+            if (!process(w[d], r)) return;
+            if (r + uint64_t(D) * stride < nrows) issue(w[d], r + uint64_t(D) * stride);
         }
     }
 }
@@ -622,7 +715,12 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // (the mirror block scans nothing when there are other blocks: its global stores of the
         // previous event overlap the others' scan instead of delaying the rendezvous)
         if (!lead || G == 1) {
-            if (wgmode)
+            if (wgmode && COARSE && B == 4096 && coarse_on) {
+                if constexpr (COARSE)
+                    p_scan_rows_wg_stream<T>(mat, d.totals, d.rowH, sl, slf, st, st.sumH - s_mH[st.li], evp, evs,
+                                             &sync->soft[epoch % 3][0], blockIdx.x, nwg, nrows, scratch + 32,
+                                             nread, nprecise, nmid);
+            } else if (wgmode)
                 p_scan_rows_wg<T, COARSE>(mat, d.totals, d.rowH, sl, slf, B, st, st.sumH - s_mH[st.li], evp, evs,
                                           &sync->soft[epoch % 3][0], blockIdx.x, nwg, nrows, scratch + 32,
                                           nread, nprecise, nmid, coarse_on);
