@@ -42,19 +42,6 @@ def parse():
     return ap.parse_args()
 
 
-_CPU_JOB = {}  # what the forked CPU-baseline workers inherit
-
-
-def _cpu_chunk(bounds):
-    import oracle
-
-    lo, hi = bounds
-    off = _CPU_JOB["off"]
-    local = (off[lo: hi + 1] - off[lo]).astype(np.uint64)
-    res, _ = oracle.nmost_concat(_CPU_JOB["host"][off[lo]: off[hi]], local, _CPU_JOB["n"], _CPU_JOB["k"], 4)
-    return res.members(with_freqs=True)[3]
-
-
 def main():
     a = parse()
     # RCCL prints a version banner on stdout when the process exits; the contract is ONE JSON
@@ -246,24 +233,18 @@ def main():
                            "Rust path (oracle/dvs_oracle.c), data in RAM"),
             }
             # the reference's own parallel scheme on every host core (records.py:225-245): contiguous
-            # chunks, an independent selection per worker PROCESS (forked: they inherit the sample
-            # and only run the C restatement -- nothing in them touches the GPU), final_nmost over
-            # the winners
-            import multiprocessing as mp
-
+            # chunks, an independent selection per worker, final_nmost over the winners -- the workers
+            # are threads inside the C restatement (oracle/dvs_oracle.c orc_nmost_chunks_mt), so no
+            # process is forked from one that holds the GPU
             from diverseseq_amd.parallel import chunk_bounds
 
-            ncores = max(1, min(os.cpu_count() or 1, ns // max(4 * a.n, 1)))
-            _CPU_JOB.update(host=host, off=offsets.astype(np.int64), n=a.n, k=a.k)
+            ncores = max(1, min(len(os.sched_getaffinity(0)), ns // max(4 * a.n, 1)))
             t0 = time.perf_counter()
-            with mp.get_context("fork").Pool(ncores) as pool:
-                rows = pool.map(_cpu_chunk, chunk_bounds(ns, ncores))
-            oracle.final_nmost(np.vstack(rows), a.n)
+            oracle.nmost_chunks_threads(host, offsets[: ns + 1], chunk_bounds(ns, ncores), a.n, a.k, 4)
             dt_all = time.perf_counter() - t0
-            _CPU_JOB.clear()
             out["cpu_baseline"].update({"value_all_cores": ns / dt_all, "cores_all": ncores,
                                         "sample_all_cores": "same sample, the reference's chunk + merge "
-                                        "(-np cores), one worker process per host core"})
+                                        "(-np cores), one worker thread per usable host core"})
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or force_dist:
         dist.destroy_process_group()

@@ -75,6 +75,7 @@ def lib() -> C.CDLL:
         L.orc_max.argtypes = [u8p, u64p, u32p, sz, sz, sz, C.c_int, C.c_uint, C.c_uint,
                               C.POINTER(vp)]
         L.orc_final_nmost.argtypes = [f64p, u32p, sz, sz, sz, C.POINTER(vp)]
+        L.orc_nmost_chunks_mt.argtypes = [u8p, u64p, u64p, sz, sz, C.c_uint, C.c_uint, f64p, u32p, u64p]
         L.orc_final_max.argtypes = [f64p, u32p, sz, sz, sz, sz, C.c_int, C.POINTER(vp)]
         L.orc_make_summed_records.argtypes = [u8p, u64p, u32p, sz, C.c_uint, C.c_uint,
                                               C.POINTER(vp)]
@@ -302,6 +303,24 @@ def max_divergent(seqs, min_size: int, max_size: int, k: int, num_states: int = 
                          min_size, max_size, int(stat == "stdev"), k, num_states,
                          C.byref(out)))
     return SummedRecords(out.value)
+
+
+def nmost_chunks_threads(data, offsets, bounds, n: int, k: int, num_states: int = 4):
+    """the reference's `-np len(bounds)` scheme (diverse_seq/records.py:225-245) with one THREAD per
+    chunk: an independent select_nmost per contiguous chunk, then final_nmost over the winners in
+    chunk order.  bounds: [(start, end)] per chunk.  Returns the merged SummedRecords."""
+    nch = len(bounds)
+    B = num_states ** k
+    edges = np.ascontiguousarray([b[0] for b in bounds] + [bounds[-1][1]], dtype=np.uint64)
+    rows = np.zeros((nch * n, B), dtype=np.float64)
+    labels = np.zeros(nch * n, dtype=np.uint32)
+    sizes = np.zeros(nch, dtype=np.uint64)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    _check(lib().orc_nmost_chunks_mt(_p(data, C.c_uint8), _p(offsets, C.c_uint64), _p(edges, C.c_uint64), nch,
+                                     n, k, num_states, _p(rows, C.c_double), _p(labels, C.c_uint32),
+                                     _p(sizes, C.c_uint64)))
+    keep = np.concatenate([np.arange(c * n, c * n + int(sizes[c])) for c in range(nch)])
+    return final_nmost(rows[keep], n, labels=labels[keep])
 
 
 def final_nmost(freq_rows, n: int, labels=None) -> SummedRecords:

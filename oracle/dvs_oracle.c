@@ -589,6 +589,89 @@ int orc_nmost(const uint8_t *seqs, const uint64_t *offsets, const uint32_t *labe
     return rc;
 }
 
+/* The reference's own parallel scheme for `nmost` (diverse_seq/records.py:225-245 apply_app:
+ * contiguous chunks of the id list, diverse_seq/util.py:82-102, one select_nmost per worker,
+ * then select_final_nmost over the winners in chunk order, src/records.rs:363-382), with the
+ * workers as threads of this process instead of worker processes: what bench.py times as the
+ * all-cores CPU baseline.  bounds: nchunks + 1 sequence indices.  winners_out: nchunks * n rows of
+ * B doubles (chunk c's members, in member order, from row c * n), sizes_out: members per chunk. */
+#include <pthread.h>
+typedef struct {
+    const uint8_t *seqs;
+    const uint64_t *offsets;
+    size_t lo, hi, n, B;
+    unsigned k, ns;
+    double *rows;
+    uint32_t *labels;
+    size_t size;
+    int rc;
+} orc_chunk_job;
+
+static void *orc_chunk_worker(void *arg) {
+    orc_chunk_job *j = (orc_chunk_job *)arg;
+    const size_t m = j->hi - j->lo;
+    uint64_t *local = (uint64_t *)malloc((m + 1) * sizeof(uint64_t));
+    uint32_t *lab = (uint32_t *)malloc((m ? m : 1) * sizeof(uint32_t));
+    orc_set *set = NULL;
+    uint64_t acc = 0;
+    j->size = 0;
+    if (!local || !lab) {
+        j->rc = ORC_ERR_ALLOC;
+    } else {
+        for (size_t i = 0; i <= m; i++) local[i] = j->offsets[j->lo + i] - j->offsets[j->lo];
+        for (size_t i = 0; i < m; i++) lab[i] = (uint32_t)(j->lo + i);
+        j->rc = orc_nmost(j->seqs + j->offsets[j->lo], local, lab, m, j->n, j->k, j->ns, &set, &acc);
+        if (!j->rc) {
+            j->size = orc_set_size(set);
+            orc_set_members(set, j->labels, NULL, NULL, j->rows);
+        }
+    }
+    if (set) orc_set_free(set);
+    free(local);
+    free(lab);
+    return NULL;
+}
+
+int orc_nmost_chunks_mt(const uint8_t *seqs, const uint64_t *offsets, const uint64_t *bounds,
+                        size_t nchunks, size_t n, unsigned k, unsigned ns, double *winners_out,
+                        uint32_t *labels_out, uint64_t *sizes_out) {
+    size_t B = 1;
+    for (unsigned i = 0; i < k; i++) B *= ns;
+    orc_chunk_job *jobs = (orc_chunk_job *)calloc(nchunks, sizeof(orc_chunk_job));
+    pthread_t *th = (pthread_t *)calloc(nchunks, sizeof(pthread_t));
+    if (!jobs || !th) {
+        free(jobs);
+        free(th);
+        return orc_fail(ORC_ERR_ALLOC, "out of memory", 0, 0);
+    }
+    int rc = 0;
+    for (size_t c = 0; c < nchunks; c++) {
+        orc_chunk_job *j = &jobs[c];
+        j->seqs = seqs;
+        j->offsets = offsets;
+        j->lo = bounds[c];
+        j->hi = bounds[c + 1];
+        j->n = n;
+        j->B = B;
+        j->k = k;
+        j->ns = ns;
+        j->rows = winners_out + c * n * B;
+        j->labels = labels_out + c * n;
+        if (pthread_create(&th[c], NULL, orc_chunk_worker, j)) {
+            orc_chunk_worker(j); /* no thread to be had: run it here */
+            th[c] = 0;
+        }
+    }
+    for (size_t c = 0; c < nchunks; c++) {
+        if (th[c]) pthread_join(th[c], NULL);
+        sizes_out[c] = jobs[c].size;
+        if (jobs[c].rc && !rc) rc = jobs[c].rc;
+    }
+    free(jobs);
+    free(th);
+    return rc;
+}
+
 int orc_max(const uint8_t *seqs, const uint64_t *offsets, const uint32_t *labels,
             size_t nseq, size_t min_size, size_t max_size, int stat_is_std, unsigned k,
             unsigned ns, orc_set **out) {

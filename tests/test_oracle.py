@@ -268,3 +268,27 @@ def test_brca1_demo_c1(brca1):
     sr = oracle.nmost([brca1[n] for n in names], 10, 4, 4)
     assert sr.size == 10
     assert sr.total_jsd > 0
+
+
+def test_chunk_and_merge_on_threads_equals_the_sequential_scheme():
+    """orc_nmost_chunks_mt (bench.py's all-cores CPU baseline): the reference's -np scheme
+    (diverse_seq/records.py:225-245) with threads as workers gives what the same chunks give
+    one after the other"""
+    from diverseseq_amd.parallel import chunk_bounds
+
+    rng = np.random.default_rng(5)
+    nseq, length, k, n = 600, 400, 4, 6
+    data = rng.integers(0, 4, size=nseq * length, dtype=np.uint8)
+    off = (np.arange(nseq + 1) * length).astype(np.uint64)
+    bounds = chunk_bounds(nseq, 5)
+    got = oracle.nmost_chunks_threads(data, off, bounds, n, k)
+    rows, labs = [], []
+    for lo, hi in bounds:
+        res, _ = oracle.nmost_concat(data[off[lo]:off[hi]], (off[lo:hi + 1] - off[lo]).astype(np.uint64), n, k, 4,
+                                     labels=np.arange(lo, hi, dtype=np.uint32))
+        lab, _, _, f = res.members(with_freqs=True)
+        rows.append(f)
+        labs.append(lab)
+    exp = oracle.final_nmost(np.vstack(rows), n, labels=np.concatenate(labs))
+    assert got.members()[0].tolist() == exp.members()[0].tolist()
+    assert got.total_jsd == exp.total_jsd
