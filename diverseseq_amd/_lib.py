@@ -34,6 +34,9 @@ EXPORTS = (
     "dvs_select_gather_members",
     "dvs_select_delta_jsd", "dvs_select_step_scan", "dvs_select_step_fetch",
     "dvs_select_step_apply", "dvs_select_step_poll", "dvs_select_bench_scan", "dvs_selftest_fast_log2", "dvs_selftest_log2_acc", "dvs_selftest_log2_f32", "dvs_selftest_exact_div", "dvs_mash_sketch", "dvs_mash_distances", "dvs_euclidean_distances",
+    "dvs_default_alphabet_lut", "dvs_seqbatch_from_fasta", "dvs_seqbatch_destroy", "dvs_seqbatch_info",
+    "dvs_seqbatch_offsets", "dvs_seqbatch_header_positions", "dvs_seqbatch_dev_codes", "dvs_seqbatch_get_codes",
+    "dvs_matrix_build_from_seqbatch",
 )
 
 
@@ -154,6 +157,18 @@ def load() -> C.CDLL:
         L.dvs_mash_distances.argtypes = [vp, u32p, C.c_uint32, u32p, C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, f64p]
         L.dvs_euclidean_distances.argtypes = [vp, vp, f64p]
+        L.dvs_default_alphabet_lut.argtypes = [C.c_int, u8p]
+        L.dvs_default_alphabet_lut.restype = None
+        L.dvs_seqbatch_from_fasta.argtypes = [vp, vp, C.c_int, C.c_uint64, u8p, C.c_int, C.POINTER(vp)]
+        L.dvs_seqbatch_destroy.argtypes = [vp]
+        L.dvs_seqbatch_destroy.restype = None
+        L.dvs_seqbatch_info.argtypes = [vp, u32p, u64p, u32p]
+        L.dvs_seqbatch_offsets.argtypes = [vp, u64p]
+        L.dvs_seqbatch_header_positions.argtypes = [vp, u64p]
+        L.dvs_seqbatch_dev_codes.argtypes = [vp]
+        L.dvs_seqbatch_dev_codes.restype = vp
+        L.dvs_seqbatch_get_codes.argtypes = [vp, vp, u8p]
+        L.dvs_matrix_build_from_seqbatch.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
         if L.dvs_abi_version() != 1:
             raise RuntimeError("libdvs_hip.so ABI version mismatch")
         _lib = L

@@ -1,0 +1,388 @@
+// Device-side FASTA ingest: raw file bytes in HBM -> one byte per base holding the cogent3
+// alphabet index, plus record offsets -- the input format of the histogram kernel -- without a
+// host pass over the bases.
+//
+// Replaces, for the hot path's input, what the reference does on the host per file
+// (diverse_seq/io.py:75-104 dvs_load_seqs.main: parse the records, join their sequences with "-",
+// diverse_seq/util.py:32-45 str2arr: alphabet.to_indices) before the bytes reach
+// ZarrStoreWrapper.write / nmost_divergent.  SURVEY.md 8(f) rank 2.
+//
+// A byte i of the file is a base of record r when it is not inside a header line (a line that
+// starts with '>') and is not white space.  With
+//   lastnl(i) = the last '\n' at or before i,  lastgt(i) = the last line-initial '>' at or before i
+// a byte is in a header iff lastgt(i) > lastnl(i); r = (number of line-initial '>' up to i) - 1.
+// Both are prefix scans (max, max, sum) over the file, and the position of a base in the output
+// is a fourth (sum of keep flags).  Each scan is three passes: per-block aggregates (4 KiB of file
+// per 256-thread block, 16 bytes per thread), one block scanning the aggregates, and a pass that
+// redoes the block locally on top of its carry.  The file is read three times at HBM speed; the
+// bases are written once.
+//
+// join_records != 0 restates io.py:100: the records of the file become ONE sequence, a gap symbol
+// ('-' = index 4 for DNA, an invalid state, so no k-mer spans two records) between adjacent records.
+#include "dvs_internal.h"
+
+#include <cstring>
+
+namespace {
+
+constexpr int ING_THREADS = 256;
+constexpr int ING_CHUNK = 16;                        // bytes per thread
+constexpr int ING_BLOCK = ING_THREADS * ING_CHUNK;   // bytes per block
+
+struct Agg {       // aggregate of a run of bytes
+    long long nl;  // position of the last '\n' (-1: none)
+    long long gt;  // position of the last line-initial '>' (-1: none)
+    long long ng;  // number of line-initial '>'
+};
+__device__ __forceinline__ Agg agg_join(const Agg a, const Agg b) {  // a then b
+    return Agg{b.nl > a.nl ? b.nl : a.nl, b.gt > a.gt ? b.gt : a.gt, a.ng + b.ng};
+}
+
+__device__ __forceinline__ bool is_space(uint8_t c) { return c == '\n' || c == '\r' || c == ' ' || c == '\t' || c == 0; }
+
+// the 16 bytes of this thread (0 beyond the end) and the byte in front of them ('\n' at the file start)
+__device__ __forceinline__ void load_chunk(const uint8_t *raw, uint64_t n, uint64_t base, uint8_t (&c)[ING_CHUNK],
+                                           uint8_t &prev) {
+    if (base + ING_CHUNK <= n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(raw + base);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < ING_CHUNK; i++) c[i] = uint8_t(w[i >> 2] >> (8 * (i & 3)));
+    } else {
+#pragma unroll
+        for (int i = 0; i < ING_CHUNK; i++) c[i] = base + i < n ? raw[base + i] : 0;
+    }
+    prev = base == 0 ? uint8_t('\n') : (base - 1 < n ? raw[base - 1] : 0);
+}
+
+__device__ __forceinline__ Agg chunk_agg(const uint8_t (&c)[ING_CHUNK], uint8_t prev, uint64_t base, uint64_t n) {
+    Agg a{-1, -1, 0};
+#pragma unroll
+    for (int i = 0; i < ING_CHUNK; i++) {
+        if (base + i >= n) break;
+        const uint8_t p = i ? c[i - 1] : prev;
+        if (c[i] == '\n') a.nl = (long long)(base + i);
+        if (c[i] == '>' && p == '\n') {
+            a.gt = (long long)(base + i);
+            a.ng++;
+        }
+    }
+    return a;
+}
+
+// inclusive scan of one Agg per thread over the block (Hillis-Steele in LDS); returns the
+// EXCLUSIVE prefix of this thread and the block total in `total`
+__device__ __forceinline__ Agg block_scan_agg(Agg mine, Agg *lds, Agg &total) {
+    const int t = threadIdx.x;
+    lds[t] = mine;
+    __syncthreads();
+    for (int o = 1; o < ING_THREADS; o <<= 1) {
+        Agg v = lds[t];
+        if (t >= o) v = agg_join(lds[t - o], v);
+        __syncthreads();
+        lds[t] = v;
+        __syncthreads();
+    }
+    total = lds[ING_THREADS - 1];
+    const Agg ex = t ? lds[t - 1] : Agg{-1, -1, 0};
+    __syncthreads();
+    return ex;
+}
+
+__device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long mine, unsigned long long *lds,
+                                                             unsigned long long &total) {
+    const int t = threadIdx.x;
+    lds[t] = mine;
+    __syncthreads();
+    for (int o = 1; o < ING_THREADS; o <<= 1) {
+        unsigned long long v = lds[t];
+        if (t >= o) v += lds[t - o];
+        __syncthreads();
+        lds[t] = v;
+        __syncthreads();
+    }
+    total = lds[ING_THREADS - 1];
+    const unsigned long long ex = t ? lds[t - 1] : 0ull;
+    __syncthreads();
+    return ex;
+}
+
+// pass 1: aggregate of every block
+__global__ __launch_bounds__(ING_THREADS) void ing_agg_kernel(const uint8_t *__restrict__ raw, uint64_t n,
+                                                              Agg *__restrict__ blocks) {
+    __shared__ Agg lds[ING_THREADS];
+    const uint64_t base = uint64_t(blockIdx.x) * ING_BLOCK + uint64_t(threadIdx.x) * ING_CHUNK;
+    uint8_t c[ING_CHUNK], prev;
+    load_chunk(raw, n, base, c, prev);
+    Agg total;
+    (void)block_scan_agg(chunk_agg(c, prev, base, n), lds, total);
+    if (threadIdx.x == 0) blocks[blockIdx.x] = total;
+}
+
+// pass 2: one block turns the block aggregates into exclusive prefixes (carry of every block);
+// blocks[nb] receives the grand total
+__global__ __launch_bounds__(ING_THREADS) void ing_scan_agg_kernel(Agg *__restrict__ blocks, uint64_t nb) {
+    __shared__ Agg lds[ING_THREADS];
+    Agg carry{-1, -1, 0};
+    for (uint64_t b0 = 0; b0 < nb; b0 += ING_THREADS) {
+        const uint64_t b = b0 + threadIdx.x;
+        const Agg mine = b < nb ? blocks[b] : Agg{-1, -1, 0};
+        Agg total;
+        const Agg ex = block_scan_agg(mine, lds, total);
+        if (b < nb) blocks[b] = agg_join(carry, ex);
+        carry = agg_join(carry, total);
+    }
+    if (threadIdx.x == 0) blocks[nb] = carry;
+}
+
+__global__ __launch_bounds__(ING_THREADS) void ing_scan_u64_kernel(unsigned long long *__restrict__ blocks, uint64_t nb) {
+    __shared__ unsigned long long lds[ING_THREADS];
+    unsigned long long carry = 0;
+    for (uint64_t b0 = 0; b0 < nb; b0 += ING_THREADS) {
+        const uint64_t b = b0 + threadIdx.x;
+        const unsigned long long mine = b < nb ? blocks[b] : 0ull;
+        unsigned long long total;
+        const unsigned long long ex = block_scan_u64(mine, lds, total);
+        if (b < nb) blocks[b] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) blocks[nb] = carry;
+}
+
+// what a byte becomes: 0 dropped, 1 a base, 2 the gap symbol that joins two records
+__device__ __forceinline__ int classify(uint8_t ch, uint8_t prevch, uint64_t pos, Agg &run, int join) {
+    if (ch == '\n') run.nl = (long long)pos;
+    const bool header_start = ch == '>' && prevch == '\n';
+    if (header_start) {
+        run.gt = (long long)pos;
+        run.ng++;
+        return (join && run.ng >= 2) ? 2 : 0;
+    }
+    if (run.gt > run.nl || run.ng == 0 || is_space(ch)) return 0;
+    return 1;
+}
+
+// passes 3 and 5: WRITE == false counts what each block keeps; WRITE == true writes the codes,
+// the start of every record in the output and the file position of its header
+template <bool WRITE>
+__global__ __launch_bounds__(ING_THREADS) void ing_emit_kernel(const uint8_t *__restrict__ raw, uint64_t n,
+                                                               const Agg *__restrict__ carry_agg,
+                                                               unsigned long long *__restrict__ keep_blocks,
+                                                               const uint8_t *__restrict__ lut, int join,
+                                                               uint8_t gap_code, uint8_t *__restrict__ codes,
+                                                               unsigned long long *__restrict__ rec_start,
+                                                               unsigned long long *__restrict__ hdr_pos) {
+    __shared__ Agg lds[ING_THREADS];
+    __shared__ unsigned long long ldk[ING_THREADS];
+    __shared__ uint8_t s_lut[256];
+    if (WRITE) s_lut[threadIdx.x] = lut[threadIdx.x];
+    const uint64_t base = uint64_t(blockIdx.x) * ING_BLOCK + uint64_t(threadIdx.x) * ING_CHUNK;
+    uint8_t c[ING_CHUNK], prev;
+    load_chunk(raw, n, base, c, prev);
+    Agg total;
+    const Agg ex = block_scan_agg(chunk_agg(c, prev, base, n), lds, total);
+    const Agg start = agg_join(carry_agg[blockIdx.x], ex);  // state in front of this thread's bytes
+    Agg run = start;
+    unsigned long long kept = 0;
+    uint32_t cls = 0;  // 2 bits per byte
+#pragma unroll
+    for (int i = 0; i < ING_CHUNK; i++) {
+        if (base + i >= n) break;
+        const int k = classify(c[i], i ? c[i - 1] : prev, base + i, run, join);
+        cls |= uint32_t(k) << (2 * i);
+        kept += k != 0;
+    }
+    unsigned long long btotal;
+    const unsigned long long kex = block_scan_u64(kept, ldk, btotal);
+    if (!WRITE) {
+        if (threadIdx.x == 0) keep_blocks[blockIdx.x] = btotal;
+        return;
+    }
+    unsigned long long out = keep_blocks[blockIdx.x] + kex;
+    long long ng = start.ng;
+#pragma unroll
+    for (int i = 0; i < ING_CHUNK; i++) {
+        if (base + i >= n) break;
+        const uint8_t p = i ? c[i - 1] : prev;
+        if (c[i] == '>' && p == '\n') {  // record ng starts here; its bases follow the joining gap, if any
+            const uint32_t k = (cls >> (2 * i)) & 3u;
+            rec_start[ng] = out + (k == 2 ? 1 : 0);
+            hdr_pos[ng] = base + i;
+            ng++;
+        }
+        const uint32_t k = (cls >> (2 * i)) & 3u;
+        if (k == 1) codes[out++] = s_lut[c[i]];
+        else if (k == 2) codes[out++] = gap_code;
+    }
+}
+
+}  // namespace
+
+struct dvs_seqbatch {
+    dvs_ctx *ctx = nullptr;
+    uint8_t *d_codes = nullptr;  // total + 16 bytes (the histogram kernel reads 16-byte chunks)
+    uint64_t total = 0;
+    uint32_t nseq = 0;
+    std::vector<uint64_t> offsets;     // nseq + 1
+    std::vector<uint64_t> header_pos;  // file offset of the '>' of every record of the file
+};
+
+extern "C" void dvs_seqbatch_destroy(dvs_seqbatch *b) {
+    if (!b) return;
+    if (b->d_codes) dvs_dev_free(b->ctx, b->d_codes);
+    delete b;
+}
+
+// cogent3 moltype "dna" / "rna": most_degen_alphabet() = "TCAG-NRYWSKMBDHV?" (U for T in RNA);
+// lower case is folded; any other byte maps to 255 (cogent3 would refuse it)
+extern "C" void dvs_default_alphabet_lut(int rna, uint8_t lut[256]) {
+    memset(lut, 255, 256);
+    const char *order = rna ? "UCAG-NRYWSKMBDHV?" : "TCAG-NRYWSKMBDHV?";
+    for (int i = 0; order[i]; i++) {
+        const unsigned char ch = (unsigned char)order[i];
+        lut[ch] = uint8_t(i);
+        if (ch >= 'A' && ch <= 'Z') lut[ch + 32] = uint8_t(i);
+    }
+    lut[(unsigned char)(rna ? 'T' : 'U')] = 0;  // T and U are the same base, index 0
+    lut[(unsigned char)(rna ? 't' : 'u')] = 0;
+}
+
+extern "C" int dvs_seqbatch_from_fasta(dvs_ctx *ctx, const uint8_t *raw, int raw_on_device, uint64_t nbytes,
+                                       const uint8_t *lut256, int join_records, dvs_seqbatch **out) {
+    if (!ctx || !out || (!raw && nbytes)) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    *out = nullptr;
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    uint8_t lut[256];
+    if (lut256) memcpy(lut, lut256, 256);
+    else dvs_default_alphabet_lut(0, lut);
+    const uint8_t gap = lut[(unsigned char)'-'];
+    dvs_seqbatch *b = new dvs_seqbatch;
+    b->ctx = ctx;
+    const uint64_t nb = (nbytes + ING_BLOCK - 1) / ING_BLOCK;
+    uint8_t *d_raw = nullptr, *d_lut = nullptr;
+    Agg *d_agg = nullptr;
+    unsigned long long *d_keep = nullptr, *d_rec = nullptr, *d_hdr = nullptr;
+    bool own_raw = false;
+    int rc = DVS_OK;
+    auto cleanup = [&]() {
+        if (own_raw && d_raw) dvs_dev_free(ctx, d_raw);
+        if (d_lut) dvs_dev_free(ctx, d_lut);
+        if (d_agg) dvs_dev_free(ctx, d_agg);
+        if (d_keep) dvs_dev_free(ctx, d_keep);
+        if (d_rec) dvs_dev_free(ctx, d_rec);
+        if (d_hdr) dvs_dev_free(ctx, d_hdr);
+    };
+#define ING_TRY(expr)                                              \
+    do {                                                           \
+        hipError_t e__ = (expr);                                   \
+        if (e__ != hipSuccess) {                                   \
+            rc = dvs_hip_fail(ctx, e__, #expr);                    \
+            cleanup();                                             \
+            dvs_seqbatch_destroy(b);                               \
+            return rc;                                             \
+        }                                                          \
+    } while (0)
+#define ING_RC(expr)                      \
+    do {                                  \
+        rc = (expr);                      \
+        if (rc) {                         \
+            cleanup();                    \
+            dvs_seqbatch_destroy(b);      \
+            return rc;                    \
+        }                                 \
+    } while (0)
+    if (raw_on_device) {
+        d_raw = const_cast<uint8_t *>(raw);
+    } else {
+        own_raw = true;
+        ING_RC(dvs_dev_alloc(ctx, (void **)&d_raw, nbytes + 16, "raw FASTA bytes"));
+        ING_TRY(hipMemcpyAsync(d_raw, raw, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ING_RC(dvs_dev_alloc(ctx, (void **)&d_lut, 256, "alphabet table"));
+    ING_TRY(hipMemcpyAsync(d_lut, lut, 256, hipMemcpyHostToDevice, ctx->stream));
+    ING_RC(dvs_dev_alloc(ctx, (void **)&d_agg, (nb + 1) * sizeof(Agg), "ingest block aggregates"));
+    ING_RC(dvs_dev_alloc(ctx, (void **)&d_keep, (nb + 1) * sizeof(unsigned long long), "ingest block counts"));
+    Agg tot_agg{-1, -1, 0};
+    unsigned long long total = 0;
+    if (nb) {
+        hipLaunchKernelGGL(ing_agg_kernel, dim3(uint32_t(nb)), dim3(ING_THREADS), 0, ctx->stream, d_raw, nbytes, d_agg);
+        hipLaunchKernelGGL(ing_scan_agg_kernel, dim3(1), dim3(ING_THREADS), 0, ctx->stream, d_agg, nb);
+        hipLaunchKernelGGL((ing_emit_kernel<false>), dim3(uint32_t(nb)), dim3(ING_THREADS), 0, ctx->stream, d_raw,
+                           nbytes, d_agg, d_keep, d_lut, join_records, gap, (uint8_t *)nullptr,
+                           (unsigned long long *)nullptr, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL(ing_scan_u64_kernel, dim3(1), dim3(ING_THREADS), 0, ctx->stream, d_keep, nb);
+        ING_TRY(hipGetLastError());
+        ING_TRY(hipMemcpyAsync(&tot_agg, d_agg + nb, sizeof(Agg), hipMemcpyDeviceToHost, ctx->stream));
+        ING_TRY(hipMemcpyAsync(&total, d_keep + nb, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+        ING_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    const uint64_t nrec = uint64_t(tot_agg.ng);
+    if (nrec > 0xFFFFFFFFull) {
+        cleanup();
+        dvs_seqbatch_destroy(b);
+        return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "more than 2^32 - 1 records in one file");
+    }
+    b->total = total;
+    ING_RC(dvs_dev_alloc(ctx, (void **)&b->d_codes, total + 16, "encoded sequences"));
+    ING_TRY(hipMemsetAsync(b->d_codes + total, 0xFF, 16, ctx->stream));  // invalid filler behind the last base
+    std::vector<uint64_t> starts(nrec);
+    b->header_pos.resize(nrec);
+    if (nb && nrec) {
+        ING_RC(dvs_dev_alloc(ctx, (void **)&d_rec, nrec * 8, "record starts"));
+        ING_RC(dvs_dev_alloc(ctx, (void **)&d_hdr, nrec * 8, "header positions"));
+    }
+    if (nb) {
+        hipLaunchKernelGGL((ing_emit_kernel<true>), dim3(uint32_t(nb)), dim3(ING_THREADS), 0, ctx->stream, d_raw,
+                           nbytes, d_agg, d_keep, d_lut, join_records, gap, b->d_codes, d_rec, d_hdr);
+        ING_TRY(hipGetLastError());
+        if (nrec) {
+            ING_TRY(hipMemcpyAsync(starts.data(), d_rec, nrec * 8, hipMemcpyDeviceToHost, ctx->stream));
+            ING_TRY(hipMemcpyAsync(b->header_pos.data(), d_hdr, nrec * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        ING_TRY(hipStreamSynchronize(ctx->stream));
+    }
+#undef ING_TRY
+#undef ING_RC
+    if (join_records) {
+        b->nseq = nrec ? 1u : 0u;
+        if (nrec) b->offsets = {0, total};
+        else b->offsets = {0};
+    } else {
+        b->nseq = uint32_t(nrec);
+        b->offsets.assign(starts.begin(), starts.end());
+        b->offsets.push_back(total);
+    }
+    cleanup();
+    *out = b;
+    return DVS_OK;
+}
+
+extern "C" int dvs_seqbatch_info(const dvs_seqbatch *b, uint32_t *nseq, uint64_t *total_bases, uint32_t *nrecords) {
+    if (!b) return DVS_ERR_VALUE;
+    if (nseq) *nseq = b->nseq;
+    if (total_bases) *total_bases = b->total;
+    if (nrecords) *nrecords = uint32_t(b->header_pos.size());
+    return DVS_OK;
+}
+extern "C" int dvs_seqbatch_offsets(const dvs_seqbatch *b, uint64_t *offsets_out) {
+    if (!b || !offsets_out) return DVS_ERR_VALUE;
+    memcpy(offsets_out, b->offsets.data(), b->offsets.size() * 8);
+    return DVS_OK;
+}
+extern "C" int dvs_seqbatch_header_positions(const dvs_seqbatch *b, uint64_t *pos_out) {
+    if (!b || !pos_out) return DVS_ERR_VALUE;
+    memcpy(pos_out, b->header_pos.data(), b->header_pos.size() * 8);
+    return DVS_OK;
+}
+extern "C" const void *dvs_seqbatch_dev_codes(const dvs_seqbatch *b) { return b ? b->d_codes : nullptr; }
+extern "C" int dvs_seqbatch_get_codes(dvs_ctx *ctx, const dvs_seqbatch *b, uint8_t *codes_out) {
+    if (!ctx || !b || (!codes_out && b->total)) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    DVS_HIP(ctx, hipMemcpyAsync(codes_out, b->d_codes, b->total, hipMemcpyDeviceToHost, ctx->stream));
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DVS_OK;
+}
+extern "C" int dvs_matrix_build_from_seqbatch(dvs_ctx *ctx, const dvs_seqbatch *b, uint32_t k, uint32_t num_states,
+                                              dvs_matrix **out) {
+    if (!ctx || !b || !out) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    return dvs_matrix_build(ctx, b->d_codes, 1, b->offsets.data(), b->nseq, k, num_states, out);
+}

@@ -91,6 +91,28 @@ class Context:
                                             num_states, C.byref(h)))
         return CountMatrix(self, h, k, num_states)
 
+    # ---- ingest ---------------------------------------------------------------
+    def encode_fasta(self, raw, join_records: bool = False, moltype: str = "dna",
+                     dev_ptr: int | None = None, nbytes: int | None = None) -> "SeqBatch":
+        """FASTA file bytes -> index-coded sequences in HBM (csrc/ingest.hip), replacing the host
+        parse + str2arr of diverse_seq/io.py:75-104 / util.py:32-45.  `raw`: bytes / uint8 array of
+        the file (or None with dev_ptr + nbytes for bytes already on the device, in which case
+        record names are not extracted).  join_records: one sequence per file, records joined by
+        a gap symbol (io.py:100); else one sequence per record."""
+        lut = np.zeros(256, dtype=np.uint8)
+        self._L.dvs_default_alphabet_lut(int(moltype.lower() == "rna"), _lib.ptr(lut, C.c_uint8))
+        h = C.c_void_p()
+        if dev_ptr is not None:
+            self.check(self._L.dvs_seqbatch_from_fasta(self._h, C.c_void_p(dev_ptr), 1, int(nbytes),
+                                                       _lib.ptr(lut, C.c_uint8), int(join_records), C.byref(h)))
+            host = None
+        else:
+            host = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else np.ascontiguousarray(raw, dtype=np.uint8)
+            self.check(self._L.dvs_seqbatch_from_fasta(self._h, C.c_void_p(host.ctypes.data) if host.size else None, 0,
+                                                       host.size, _lib.ptr(lut, C.c_uint8), int(join_records),
+                                                       C.byref(h)))
+        return SeqBatch(self, h, host)
+
     def matrix_from_freqs(self, freqs: np.ndarray) -> "CountMatrix":
         f = np.ascontiguousarray(freqs, dtype=np.float64)
         if f.ndim != 2:
@@ -117,6 +139,60 @@ class Context:
             return m.counts(), m.totals(), m.entropy()
         finally:
             m.close()
+
+
+class SeqBatch:
+    """index-coded sequences resident in HBM, as produced by Context.encode_fasta"""
+
+    def __init__(self, ctx: Context, handle, raw_host):
+        self.ctx, self._h = ctx, handle
+        nseq, total, nrec = C.c_uint32(), C.c_uint64(), C.c_uint32()
+        ctx._L.dvs_seqbatch_info(handle, C.byref(nseq), C.byref(total), C.byref(nrec))
+        self.nseq, self.total, self.nrecords = nseq.value, total.value, nrec.value
+        self.offsets = np.zeros(self.nseq + 1, dtype=np.uint64)
+        ctx._L.dvs_seqbatch_offsets(handle, _lib.ptr(self.offsets, C.c_uint64))
+        self.header_positions = np.zeros(self.nrecords, dtype=np.uint64)
+        if self.nrecords:
+            ctx._L.dvs_seqbatch_header_positions(handle, _lib.ptr(self.header_positions, C.c_uint64))
+        # record labels: the header line without '>' (host slices of the file, no pass over the bases)
+        self.labels = None
+        if raw_host is not None:
+            self.labels = []
+            buf = raw_host.tobytes() if self.nrecords else b""
+            for p in self.header_positions:
+                e = buf.find(b"\n", int(p))
+                self.labels.append(buf[int(p) + 1: e if e >= 0 else len(buf)].decode("utf8", "replace").strip())
+
+    @property
+    def dev_ptr(self) -> int:
+        return int(self.ctx._L.dvs_seqbatch_dev_codes(self._h) or 0)
+
+    def codes(self) -> np.ndarray:
+        """the encoded symbols, copied to the host (tests, store writers)"""
+        out = np.zeros(self.total, dtype=np.uint8)
+        self.ctx.check(self.ctx._L.dvs_seqbatch_get_codes(self.ctx._h, self._h, _lib.ptr(out, C.c_uint8)))
+        return out
+
+    def sequences(self) -> list:
+        c = self.codes()
+        return [c[int(a): int(b)] for a, b in zip(self.offsets[:-1], self.offsets[1:])]
+
+    def build_matrix(self, k: int, num_states: int = 4) -> "CountMatrix":
+        """k-mer count matrix straight from the encoded bases in HBM (no host round trip)"""
+        h = C.c_void_p()
+        self.ctx.check(self.ctx._L.dvs_matrix_build_from_seqbatch(self.ctx._h, self._h, k, num_states, C.byref(h)))
+        return CountMatrix(self.ctx, h, k, num_states)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._L.dvs_seqbatch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class CountMatrix:

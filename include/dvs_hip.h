@@ -97,6 +97,29 @@ int dvs_kmer_counts(dvs_ctx *ctx, const uint8_t *seqs, const uint64_t *offsets,
                     uint32_t nseq, uint32_t k, uint32_t num_states,
                     uint32_t *counts_out, uint32_t *totals_out, double *entropy_out);
 
+/* ---- ingest -------------------------------------- *
+ * FASTA file bytes -> the data convention above, on the device: replaces, for the hot path's
+ * input, the host-side parse + encode of diverse_seq/io.py:75-104 (dvs_load_seqs.main: records
+ * parsed, their sequences joined with "-") and diverse_seq/util.py:32-45 (str2arr:
+ * alphabet.to_indices).  `raw` is the file as it is (host pointer, or device pointer when
+ * raw_on_device != 0); lut256 maps a file byte to its alphabet index (NULL: the cogent3 "dna"
+ * table, dvs_default_alphabet_lut).  join_records != 0: one sequence per file, a gap symbol
+ * between adjacent records (io.py:100); 0: one sequence per record.  The encoded bases stay in HBM
+ * and feed dvs_matrix_build_from_seqbatch directly. */
+typedef struct dvs_seqbatch dvs_seqbatch;
+void dvs_default_alphabet_lut(int rna, uint8_t lut[256]);
+int dvs_seqbatch_from_fasta(dvs_ctx *ctx, const uint8_t *raw, int raw_on_device, uint64_t nbytes,
+                            const uint8_t *lut256, int join_records, dvs_seqbatch **out);
+void dvs_seqbatch_destroy(dvs_seqbatch *b);
+/* nseq sequences (1 when joined), total encoded symbols, records ('>' lines) in the file */
+int dvs_seqbatch_info(const dvs_seqbatch *b, uint32_t *nseq, uint64_t *total_bases, uint32_t *nrecords);
+int dvs_seqbatch_offsets(const dvs_seqbatch *b, uint64_t *offsets_out);        /* nseq + 1 */
+int dvs_seqbatch_header_positions(const dvs_seqbatch *b, uint64_t *pos_out);   /* nrecords: offset of each '>' */
+const void *dvs_seqbatch_dev_codes(const dvs_seqbatch *b);                     /* uint8 [total] in HBM */
+int dvs_seqbatch_get_codes(dvs_ctx *ctx, const dvs_seqbatch *b, uint8_t *codes_out);
+int dvs_matrix_build_from_seqbatch(dvs_ctx *ctx, const dvs_seqbatch *b, uint32_t k, uint32_t num_states,
+                                   dvs_matrix **out);
+
 /* ---- greedy delta-JSD selection ------------------------------------------ *
  * replaces SummedRecords (src/records.rs:10-216), get_lowest_record_index
  * (:220-252) and the selectors select_nmost_divergent (:311-342),

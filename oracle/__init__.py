@@ -408,3 +408,44 @@ def euclidean_distance(a, b) -> float:
     x = np.ascontiguousarray(a, dtype=np.float64)
     y = np.ascontiguousarray(b, dtype=np.float64)
     return lib().orc_euclidean_distance(_p(x, C.c_double), _p(y, C.c_double), x.size)
+
+
+# ----------------------------------------------------------------------- ingest
+DNA_ORDER = "TCAG-NRYWSKMBDHV?"  # cogent3 get_moltype("dna").most_degen_alphabet()
+
+
+def str2arr(text: str, moltype: str = "dna") -> np.ndarray:
+    """diverse_seq/util.py:32-45 str2arr: alphabet.to_indices over the most degenerate alphabet
+    (canonical states first: T0 C1 A2 G3, then '-', the ambiguity codes, '?'); lower case folded,
+    any other character 255.  Pinned by tests/test_util.py:9-16 of the reference (ACGTT ->
+    the canonical indices, N > 3)."""
+    order = DNA_ORDER.replace("T", "U") if moltype.lower() == "rna" else DNA_ORDER
+    lut = {c: i for i, c in enumerate(order)}
+    lut.update({c.lower(): i for c, i in list(lut.items()) if c.isalpha()})
+    lut["U" if moltype.lower() != "rna" else "T"] = 0
+    lut["u" if moltype.lower() != "rna" else "t"] = 0
+    return np.array([lut.get(c, 255) for c in text], dtype=np.uint8)
+
+
+def parse_fasta(raw: bytes):
+    """records of a FASTA file as (label, sequence text): a line starting with '>' opens a record,
+    every other line's characters minus white space belong to the open record (what cogent3's
+    MinimalFastaParser yields for diverse_seq/io.py:95-96); text in front of the first header is
+    dropped"""
+    records, cur = [], None
+    for line in raw.split(b"\n"):
+        if line.startswith(b">"):
+            cur = [line[1:].decode("utf8", "replace").strip(), []]
+            records.append(cur)
+        elif cur is not None:
+            cur[1].append(bytes(ch for ch in line if ch not in b" \t\r\x00").decode("latin1"))
+    return [(lab, "".join(parts)) for lab, parts in records]
+
+
+def load_fasta(raw: bytes, join_records: bool = False, moltype: str = "dna"):
+    """diverse_seq/io.py:92-104 dvs_load_seqs.main (join_records: the file's sequences joined by
+    "-" into one) or one coded sequence per record; returns (labels, [uint8 arrays])"""
+    recs = parse_fasta(raw)
+    if join_records:
+        return [lab for lab, _ in recs], ([str2arr("-".join(s for _, s in recs), moltype)] if recs else [])
+    return [lab for lab, _ in recs], [str2arr(s, moltype) for _, s in recs]
