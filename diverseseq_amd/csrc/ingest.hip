@@ -27,7 +27,10 @@ namespace {
 
 constexpr int ING_THREADS = 256;
 constexpr int ING_CHUNK = 16;                        // bytes per thread
-constexpr int ING_BLOCK = ING_THREADS * ING_CHUNK;   // bytes per block
+constexpr int ING_TILE = ING_THREADS * ING_CHUNK;    // bytes per block-wide step (4 KiB)
+constexpr int ING_TILES = 32;                        // steps per block: the single-block scans of the
+                                                     // block aggregates stay short (128 KiB of file per block)
+constexpr uint64_t ING_BLOCK = uint64_t(ING_TILE) * ING_TILES;  // bytes per block
 
 struct Agg {       // aggregate of a run of bytes
     long long nl;  // position of the last '\n' (-1: none)
@@ -111,12 +114,18 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
 __global__ __launch_bounds__(ING_THREADS) void ing_agg_kernel(const uint8_t *__restrict__ raw, uint64_t n,
                                                               Agg *__restrict__ blocks) {
     __shared__ Agg lds[ING_THREADS];
-    const uint64_t base = uint64_t(blockIdx.x) * ING_BLOCK + uint64_t(threadIdx.x) * ING_CHUNK;
-    uint8_t c[ING_CHUNK], prev;
-    load_chunk(raw, n, base, c, prev);
-    Agg total;
-    (void)block_scan_agg(chunk_agg(c, prev, base, n), lds, total);
-    if (threadIdx.x == 0) blocks[blockIdx.x] = total;
+    Agg run{-1, -1, 0};
+    for (int tile = 0; tile < ING_TILES; tile++) {
+        const uint64_t base = uint64_t(blockIdx.x) * ING_BLOCK + uint64_t(tile) * ING_TILE +
+                              uint64_t(threadIdx.x) * ING_CHUNK;
+        if (uint64_t(blockIdx.x) * ING_BLOCK + uint64_t(tile) * ING_TILE >= n) break;  // (block-uniform)
+        uint8_t c[ING_CHUNK], prev;
+        load_chunk(raw, n, base, c, prev);
+        Agg total;
+        (void)block_scan_agg(chunk_agg(c, prev, base, n), lds, total);
+        run = agg_join(run, total);
+    }
+    if (threadIdx.x == 0) blocks[blockIdx.x] = run;
 }
 
 // pass 2: one block turns the block aggregates into exclusive prefixes (carry of every block);
@@ -176,44 +185,50 @@ __global__ __launch_bounds__(ING_THREADS) void ing_emit_kernel(const uint8_t *__
     __shared__ unsigned long long ldk[ING_THREADS];
     __shared__ uint8_t s_lut[256];
     if (WRITE) s_lut[threadIdx.x] = lut[threadIdx.x];
-    const uint64_t base = uint64_t(blockIdx.x) * ING_BLOCK + uint64_t(threadIdx.x) * ING_CHUNK;
-    uint8_t c[ING_CHUNK], prev;
-    load_chunk(raw, n, base, c, prev);
-    Agg total;
-    const Agg ex = block_scan_agg(chunk_agg(c, prev, base, n), lds, total);
-    const Agg start = agg_join(carry_agg[blockIdx.x], ex);  // state in front of this thread's bytes
-    Agg run = start;
-    unsigned long long kept = 0;
-    uint32_t cls = 0;  // 2 bits per byte
+    Agg run_block = carry_agg[blockIdx.x];  // state in front of the tile being processed
+    unsigned long long kept_block = WRITE ? keep_blocks[blockIdx.x] : 0ull;
+    for (int tile = 0; tile < ING_TILES; tile++) {
+        const uint64_t tile_base = uint64_t(blockIdx.x) * ING_BLOCK + uint64_t(tile) * ING_TILE;
+        if (tile_base >= n) break;  // (block-uniform)
+        const uint64_t base = tile_base + uint64_t(threadIdx.x) * ING_CHUNK;
+        uint8_t c[ING_CHUNK], prev;
+        load_chunk(raw, n, base, c, prev);
+        Agg total;
+        const Agg ex = block_scan_agg(chunk_agg(c, prev, base, n), lds, total);
+        const Agg start = agg_join(run_block, ex);  // state in front of this thread's bytes
+        Agg run = start;
+        unsigned long long kept = 0;
+        uint32_t cls = 0;  // 2 bits per byte
 #pragma unroll
-    for (int i = 0; i < ING_CHUNK; i++) {
-        if (base + i >= n) break;
-        const int k = classify(c[i], i ? c[i - 1] : prev, base + i, run, join);
-        cls |= uint32_t(k) << (2 * i);
-        kept += k != 0;
-    }
-    unsigned long long btotal;
-    const unsigned long long kex = block_scan_u64(kept, ldk, btotal);
-    if (!WRITE) {
-        if (threadIdx.x == 0) keep_blocks[blockIdx.x] = btotal;
-        return;
-    }
-    unsigned long long out = keep_blocks[blockIdx.x] + kex;
-    long long ng = start.ng;
-#pragma unroll
-    for (int i = 0; i < ING_CHUNK; i++) {
-        if (base + i >= n) break;
-        const uint8_t p = i ? c[i - 1] : prev;
-        if (c[i] == '>' && p == '\n') {  // record ng starts here; its bases follow the joining gap, if any
-            const uint32_t k = (cls >> (2 * i)) & 3u;
-            rec_start[ng] = out + (k == 2 ? 1 : 0);
-            hdr_pos[ng] = base + i;
-            ng++;
+        for (int i = 0; i < ING_CHUNK; i++) {
+            if (base + i >= n) break;
+            const int k = classify(c[i], i ? c[i - 1] : prev, base + i, run, join);
+            cls |= uint32_t(k) << (2 * i);
+            kept += k != 0;
         }
-        const uint32_t k = (cls >> (2 * i)) & 3u;
-        if (k == 1) codes[out++] = s_lut[c[i]];
-        else if (k == 2) codes[out++] = gap_code;
+        unsigned long long btotal;
+        const unsigned long long kex = block_scan_u64(kept, ldk, btotal);
+        if (WRITE) {
+            unsigned long long out = kept_block + kex;
+            long long ng = start.ng;
+#pragma unroll
+            for (int i = 0; i < ING_CHUNK; i++) {
+                if (base + i >= n) break;
+                const uint8_t p = i ? c[i - 1] : prev;
+                const uint32_t k = (cls >> (2 * i)) & 3u;
+                if (c[i] == '>' && p == '\n') {  // record ng starts here; its bases follow the joining gap, if any
+                    rec_start[ng] = out + (k == 2 ? 1 : 0);
+                    hdr_pos[ng] = base + i;
+                    ng++;
+                }
+                if (k == 1) codes[out++] = s_lut[c[i]];
+                else if (k == 2) codes[out++] = gap_code;
+            }
+        }
+        run_block = agg_join(run_block, total);
+        kept_block += btotal;
     }
+    if (!WRITE && threadIdx.x == 0) keep_blocks[blockIdx.x] = kept_block;
 }
 
 }  // namespace

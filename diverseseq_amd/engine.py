@@ -154,14 +154,28 @@ class SeqBatch:
         self.header_positions = np.zeros(self.nrecords, dtype=np.uint64)
         if self.nrecords:
             ctx._L.dvs_seqbatch_header_positions(handle, _lib.ptr(self.header_positions, C.c_uint64))
-        # record labels: the header line without '>' (host slices of the file, no pass over the bases)
-        self.labels = None
-        if raw_host is not None:
-            self.labels = []
-            buf = raw_host.tobytes() if self.nrecords else b""
-            for p in self.header_positions:
-                e = buf.find(b"\n", int(p))
-                self.labels.append(buf[int(p) + 1: e if e >= 0 else len(buf)].decode("utf8", "replace").strip())
+        self._raw_host = raw_host
+        self._labels = None
+
+    @property
+    def labels(self):
+        """record labels: the header line without '>' (host slices of the file on first use; no
+        pass over the bases); None when the file was handed over as a device pointer"""
+        raw_host = self._raw_host
+        if self._labels is None and raw_host is not None:
+            self.labels_ = []
+            for p in self.header_positions:  # a window per header: the file itself is never copied
+                p, width = int(p), 256
+                while True:
+                    line = raw_host[p + 1: p + 1 + width]
+                    nl = np.flatnonzero(line == 10)
+                    if nl.size or p + 1 + width >= raw_host.size:
+                        break
+                    width *= 16
+                end = int(nl[0]) if nl.size else line.size
+                self.labels_.append(line[:end].tobytes().decode("utf8", "replace").strip())
+            self._labels = self.labels_
+        return self._labels
 
     @property
     def dev_ptr(self) -> int:

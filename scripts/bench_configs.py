@@ -107,6 +107,41 @@ def mash_case(name, nseq, lo, hi, k, s, canonical, reps=2, composition=False):
     torch.cuda.empty_cache()
 
 
+def ingest_case(name, nrec, length, reps=3):
+    """FASTA bytes (80-column lines) -> index codes in HBM (csrc/ingest.hip): device-resident file
+    (the kernels alone) and host file (upload included)"""
+    rng = np.random.default_rng(99)
+    width = 80
+    rows = length // width
+    recs = []
+    for r in range(nrec):
+        body = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(rows, width), dtype=np.uint8)]
+        body = np.concatenate([body, np.full((rows, 1), 10, dtype=np.uint8)], axis=1).ravel()
+        recs.append(np.frombuffer(b">genome%05d synthetic\n" % r, dtype=np.uint8))
+        recs.append(body)
+    raw = np.concatenate(recs)
+    t_raw = torch.from_numpy(raw).to(dev)
+    torch.cuda.synchronize()
+
+    def on_device():
+        b = ctx.encode_fasta(None, dev_ptr=t_raw.data_ptr(), nbytes=raw.size)
+        n = (b.nseq, b.total)
+        b.close()
+        return n
+
+    def from_host():
+        b = ctx.encode_fasta(raw)
+        n = (b.nseq, b.total)
+        b.close()
+        return n
+
+    dt_d, n = timed(on_device, reps)
+    dt_h, _ = timed(from_host, reps)
+    print(json.dumps(dict(config=name, records=n[0], bases=n[1], file_bytes=int(raw.size),
+                          device_ms=round(dt_d * 1e3, 3), device_gbytes_per_s=round(raw.size / dt_d / 1e9, 1),
+                          host_ms=round(dt_h * 1e3, 3), host_gbytes_per_s=round(raw.size / dt_h / 1e9, 1))), flush=True)
+
+
 if __name__ == "__main__":
     which = set(sys.argv[1:])
     def want(n):
@@ -125,6 +160,9 @@ if __name__ == "__main__":
                     reps=2, composition=True, min_size=100)
         select_case("C3 scaled (1050 genomes, i.i.d. uniform: degenerate)", 1050, 2_500_000, 3_500_000, 6, "max",
                     reps=2, min_size=100)
+    if want("ING"):
+        ingest_case("FASTA ingest, 100 x 3 Mb genomes", 100, 3_000_000)
+        ingest_case("FASTA ingest, 100k x 5 kb records", 100_000, 5_040)
     if want("C5"):
         mash_case("C5 mash", 1000, 2_900_000, 3_100_000, 12, 3000, False)
         mash_case("C5 mash canonical", 1000, 2_900_000, 3_100_000, 12, 3000, True)

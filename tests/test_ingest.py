@@ -103,6 +103,15 @@ def test_device_ingest_matches_oracle_on_ragged_files(ctx, seed):
 
 
 @pytest.mark.gpu
+def test_device_ingest_across_many_scan_blocks(ctx):
+    """~1 MB of ragged records: the carries of the three-pass scans cross several 128 KiB blocks"""
+    raw = _random_fasta(np.random.default_rng(77), nrec=2500, crlf=True)
+    assert len(raw) > 5 * 131072
+    _check(ctx, raw, False)
+    _check(ctx, raw, True)
+
+
+@pytest.mark.gpu
 def test_matrix_from_device_ingest_equals_matrix_from_host_sequences(ctx):
     """the encoded bases feed the histogram kernel without leaving HBM: same counts as the
     host-encoded sequences give (and as the oracle counts)"""
