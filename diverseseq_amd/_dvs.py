@@ -66,7 +66,8 @@ class SummedRecordsResult:
 
 
 class ZarrStoreWrapper:
-    """In-memory sequence store with the python face of src/zarr_py.rs:9-247.
+    """The python face of src/zarr_py.rs:9-247 over an in-memory store (path None) or an on-disk
+    ``.dvseqsz`` directory (diverseseq_amd/zarr_store.py: the reference's Zarr v3 + zstd layout).
 
     Sequences are deduplicated by content: ``unique_seqids`` holds one id per
     distinct sequence, the last one written (src/zarr_io.rs:376-384;
@@ -75,36 +76,67 @@ class ZarrStoreWrapper:
     "same ordered seqids in -> same ids out", SURVEY.md hard part 6).
     """
 
-
     def __init__(self, path: str | None = None, mode: str = "r"):
-        if path is not None:
-            raise NotImplementedError(
-                "on-disk .dvseqsz (Zarr v3 + zstd) stores are not part of this build "
-                "(SURVEY.md 8f rank 1); use make_zarr_store() for an in-memory store")
         self._seqs: dict[str, bytes] = {}
         self._meta: dict[str, dict] = {}
+        self._disk = None
         self.source = ""
+        if path is not None:
+            from .zarr_store import DvseqszDir
+
+            self._disk = DvseqszDir(str(path), mode)  # FileNotFoundError / RuntimeError as zarr_py.rs:41-57
+            self.source = str(path)
 
     def __repr__(self):
-        return f"ZarrStoreWrapper(source='in memory', num members={len(self)})"
+        src = self.source if self.source else "'in memory'"
+        return f"ZarrStoreWrapper(source={src}, num members={len(self)})"
 
     def __contains__(self, key: str) -> bool:
-        return key in self._seqs
+        return key in (self._disk.seqid_to_hash if self._disk else self._seqs)
 
     def __len__(self) -> int:
-        return len(self._seqs)
+        return len(self._disk.seqid_to_hash if self._disk else self._seqs)
 
+    # pickling by path (src/zarr_py.rs:90-133); an in-memory store refuses
     def __getstate__(self):
-        raise TypeError("Cannot pickle in-memory store")  # src/zarr_py.rs:91-95
+        if self._disk is None:
+            raise TypeError("Cannot pickle in-memory store")
+        if self._disk.mode != "r":
+            self._disk.save_metadata()
+        return {"path": self.source}
+
+    def __setstate__(self, state):
+        self.__init__(state["path"], "r")
+
+    def __getnewargs__(self):
+        return (self.source,)
+
+    def close(self):
+        """what Drop does (src/zarr_io.rs:404-422): persist the id map of a writable store"""
+        if self._disk is not None and self._disk.mode != "r":
+            self._disk.save_metadata()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def write(self, seqid: str, seq, metadata: dict | None = None) -> None:
         data = bytes(seq)
+        meta = {str(k): str(v) for k, v in metadata.items()} if metadata else {"source": "unknown"}
         if len(data) == 0:
             raise ValueError(f"Failed to create add {seqid}")
+        if self._disk is not None:
+            try:
+                self._disk.add(seqid, data, meta)
+            except (OSError, ValueError, RuntimeError) as e:
+                raise ValueError(f"Failed to create add {seqid}") from e
+            return
         if seqid in self._seqs:
             return  # idempotent per seqid (src/zarr_io.rs:217-219)
         self._seqs[seqid] = data
-        self._meta[seqid] = dict(metadata) if metadata else {"source": "unknown"}
+        self._meta[seqid] = meta
 
     def write_log(self, unique_id: str, data: str) -> None:
         pass
@@ -114,34 +146,38 @@ class ZarrStoreWrapper:
 
     def read(self, seqid: str) -> bytes:
         try:
-            return self._seqs[seqid]
-        except KeyError:
+            return self._disk.read(seqid) if self._disk else self._seqs[seqid]
+        except (KeyError, OSError, RuntimeError, ValueError):
             raise RuntimeError(f"Failed to create add {seqid}") from None
 
     def read_metadata(self, seqid: str) -> dict:
         try:
-            return dict(self._meta[seqid])
-        except KeyError:
-            raise RuntimeError(f"Failed to read metadata for {seqid}") from None
+            return self._disk.read_metadata(seqid) if self._disk else dict(self._meta[seqid])
+        except (KeyError, OSError, ValueError) as e:
+            raise RuntimeError(f"Failed to read metadata for {seqid}: {e}") from None
+
+    def _content_keys(self):
+        """(seqid, content key) in insertion order: the content hash on disk, the bytes in memory"""
+        return (self._disk.seqid_to_hash if self._disk else self._seqs).items()
 
     def num_unique(self) -> int:
-        return len(set(self._seqs.values()))
+        return len({key for _, key in self._content_keys()})
 
     @property
     def unique_seqids(self) -> list[str]:
-        last: dict[bytes, str] = {}
-        for sid, data in self._seqs.items():
-            last[data] = sid
+        last: dict = {}
+        for sid, key in self._content_keys():
+            last[key] = sid
         return list(last.values())
 
     def get_seqids(self) -> list[str]:
-        return list(self._seqs)
+        return [sid for sid, _ in self._content_keys()]
 
     def get_lazyseq(self, seqid: str, num_states: int) -> "LazySeq":
         return LazySeq(seqid, self, num_states)
 
     def get_lazyseqs(self, num_states: int) -> list["LazySeq"]:
-        return [self.get_lazyseq(s, num_states) for s in self._seqs]
+        return [self.get_lazyseq(s, num_states) for s in self.get_seqids()]
 
 
 class LazySeq:
@@ -174,7 +210,8 @@ def make_zarr_store(path: str | None = None, mode: str = "r") -> ZarrStoreWrappe
 
 
 def get_seqids_from_store(path: str) -> list[str]:
-    raise NotImplementedError("on-disk .dvseqsz stores are not part of this build (SURVEY.md 8f)")
+    """src/lib.rs:29-34: every seqid of the store at `path` (opened read-only)"""
+    return ZarrStoreWrapper(path, "r").get_seqids()
 
 
 def _gather(store: ZarrStoreWrapper, seqids):
@@ -182,10 +219,9 @@ def _gather(store: ZarrStoreWrapper, seqids):
     ids = list(store.unique_seqids) if seqids is None else list(seqids)
     seqs, labels, label_of = [], [], {}
     for sid in ids:
-        try:
-            seqs.append(store._seqs[sid])
-        except KeyError:  # read_uint8_array(..).unwrap() panics (src/record.rs:206)
-            raise ValueError(f"sequence {sid!r} not in store") from None
+        if sid not in store:  # read_uint8_array(..).unwrap() panics (src/record.rs:206)
+            raise ValueError(f"sequence {sid!r} not in store")
+        seqs.append(store.read(sid))
         labels.append(label_of.setdefault(sid, len(label_of)))
     return ids, seqs, np.asarray(labels, dtype=np.uint32)
 

@@ -428,6 +428,32 @@ def test_euclidean(brca1):
 
 
 # ------------------------------------------------------------ _dvs drop-in level
+def test_selection_through_an_on_disk_store(brca1, tmp_path):
+    """`dvs nmost` / `dvs max` over a .dvseqsz directory (diverseseq_amd/zarr_store.py): the store a
+    `prep` step wrote is reopened read-only and gives what the in-memory store and the oracle give"""
+    from diverseseq_amd import _dvs as dvs
+
+    path = str(tmp_path / "brca1.dvseqsz")
+    disk = dvs.make_zarr_store(path, mode="w")
+    mem = dvs.make_zarr_store()
+    for name, arr in brca1.items():
+        disk.write(name, arr.tobytes(), {"source": f"brca1:{name}"})
+        mem.write(name, arr.tobytes())
+    disk.close()
+    ro = dvs.make_zarr_store(path, mode="r")
+    ids = dvs.get_seqids_from_store(path)
+    assert ids == list(brca1)
+    a = dvs.nmost_divergent(ro, n=10, k=4, seqids=ids)
+    b = dvs.nmost_divergent(mem, n=10, k=4, seqids=ids)
+    exp = oracle.nmost([brca1[i] for i in ids], 10, 4, 4)
+    assert a.record_names == b.record_names == [ids[i] for i in exp.members()[0]]
+    assert a.total_jsd == b.total_jsd
+    np.testing.assert_allclose(a.total_jsd, exp.total_jsd, rtol=1e-12)
+    c = dvs.max_divergent(ro, min_size=5, max_size=12, k=3, seqids=ids)
+    d = dvs.max_divergent(mem, min_size=5, max_size=12, k=3, seqids=ids)
+    assert c.record_names == d.record_names and 5 <= c.size <= 12
+
+
 def test_dvs_module_like_reference_tests(brca1):
     """reference tests/test_records.py through the drop-in module"""
     from diverseseq_amd import _dvs as dvs
