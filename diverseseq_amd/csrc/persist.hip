@@ -603,7 +603,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                                                                     PSync *sync, unsigned long long *part, uint32_t G) {
     constexpr uint32_t maxn = p_maxn(CACHED);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint64_t B = d.B;
+    const uint64_t B0 = d.B;
+    const uint64_t B = B0;  // (the event loop below takes its own, laundered copy)
     double *sl = reinterpret_cast<double *>(smem);
     // f32 copy of sl / n for the COARSE tier (count matrices whose state fits the register cache)
     constexpr bool COARSE = CACHED && sizeof(T) == 4;
@@ -619,8 +620,9 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     uint64_t *s_soft = reinterpret_cast<uint64_t *>(s_slot + maxn + (maxn & 1));  // this window's listed candidates
     int *s_flag = reinterpret_cast<int *>(s_soft + P_SOFT);
     SelCtl *ctl = d.ctl;
-    const int tid = threadIdx.x;
-    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const int tid0 = threadIdx.x;
+    const int tid = tid0;
+    [[maybe_unused]] const uint32_t lane = tid & 63, wave = tid >> 6;
     // the LAST block mirrors the state into global memory: with n < G it owns no member in
     // the leave-one-out pass, so its extra stores overlap the other blocks' arithmetic
     const bool lead = blockIdx.x == G - 1;
@@ -691,6 +693,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     const bool one_job = jobs <= G - 1;  // at most one job per workgroup, none for the mirror block
     const bool has_job = one_job ? (blockIdx.x < jobs) : true;
 
+#ifdef DVS_PERSIST_STAMPS  // per-phase in-kernel timing (DVS_PERSIST_DEBUG prints it): costs registers
     unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
 #define P_STAMP(k)                                                         \
     do {                                                                   \
@@ -700,7 +703,19 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             t_prev = t_now;                                                \
         }                                                                  \
     } while (0)
+#else
+#define P_STAMP(k) do { } while (0)
+#endif
     for (;;) {
+        // The loop body's view of the bin count and the thread index goes through an empty asm:
+        // otherwise every loop-invariant mask and address derived from them (dozens) is hoisted in
+        // front of the loop and kept alive across the scan, which the 256-VGPR budget pays for in
+        // scratch spills on every window.
+        uint64_t B = B0;
+        int tid = tid0;
+        asm volatile("" : "+s"(B));
+        asm volatile("" : "+v"(tid));
+        const uint32_t lane = uint32_t(tid) & 63u, wave = uint32_t(tid) >> 6;
         unsigned long long *evs = &sync->ev[epoch % 3][0];            // the slot: eight group copies
         unsigned long long *evp = evs + (blockIdx.x & 7u) * 32;       // this workgroup's copy
         // the slot of the NEXT epoch is cleared now; an exchange (its result is consumed) has been
