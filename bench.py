@@ -42,6 +42,25 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores() -> int:
+    """host cores this process may really use: the affinity mask, capped by the cgroup CPU quota
+    (a GPU box hands out a share of its cores, not all of them)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def main():
     a = parse()
     # RCCL prints a version banner on stdout when the process exits; the contract is ONE JSON
@@ -238,7 +257,7 @@ def main():
             # process is forked from one that holds the GPU
             from diverseseq_amd.parallel import chunk_bounds
 
-            ncores = max(1, min(len(os.sched_getaffinity(0)), ns // max(4 * a.n, 1)))
+            ncores = max(1, min(usable_cores(), ns // max(4 * a.n, 1)))
             t0 = time.perf_counter()
             oracle.nmost_chunks_threads(host, offsets[: ns + 1], chunk_bounds(ns, ncores), a.n, a.k, 4)
             dt_all = time.perf_counter() - t0
