@@ -724,6 +724,9 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             __hip_atomic_exchange(tid < 16 ? &sync->ev[(epoch + 1) % 3][tid * 16] : &sync->soft[(epoch + 1) % 3][0],
                                   tid < 16 ? SEL_NONE : 0ull, RLX_AGENT) == 1ull)
             sync->pad0[1] = 1;  // (consumes the results; position 1 is a seed, never an event or a count)
+#ifdef DVS_PERSIST_STAMPS
+        const unsigned long long t_window = __builtin_amdgcn_s_memrealtime();
+#endif
         const uint64_t end = umin64(st.cursor + uint64_t(st.window), st.npos);
         const uint64_t nrows = end - st.cursor;
         // ================= scan
@@ -747,6 +750,14 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         P_STAMP(0);
         if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
         P_STAMP(1);
+#ifdef DVS_PERSIST_STAMPS
+        if (lead && tid == 0) {  // scan + rendezvous time and window count by scan mode, rows per mode
+            const unsigned long long t_w = __builtin_amdgcn_s_memrealtime();
+            sync->dbg[wgmode ? 9 : 11] += t_w - t_window;
+            sync->dbg[wgmode ? 10 : 12] += 1;
+            sync->dbg[wgmode ? 13 : 14] += nrows;
+        }
+#endif
         const uint64_t hard = __hip_atomic_load(evp, RLX_AGENT);
         const uint64_t hard_sure = __hip_atomic_load(evp + 16, RLX_AGENT);  // same round trip
         const uint64_t nlisted = __hip_atomic_load(&sync->soft[epoch % 3][0], RLX_AGENT);

@@ -900,6 +900,10 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat) {
                             dbg[6 + 16 * w] / 100.0, dbg[7 + 16 * w] / 100.0, dbg[8 + 16 * w] / 100.0,
                             dbg[5 + 16 * w] / 100.0);
                 fprintf(stderr, "[dvs persist] rows passed on by the coarse tier: %llu\n", dbg[16 + 15]);
+                if (dbg[16 + 10] + dbg[16 + 12])
+                    fprintf(stderr, "[dvs persist] scan + rendezvous: row-per-workgroup windows %llu (%.1f us, %llu rows), "
+                            "row-per-wave windows %llu (%.1f us, %llu rows)\n", dbg[16 + 10], dbg[16 + 9] / 100.0,
+                            dbg[16 + 13], dbg[16 + 12], dbg[16 + 11] / 100.0, dbg[16 + 14]);
             }
         }
         if (c.status == SEL_DONE) return DVS_OK;
