@@ -54,8 +54,17 @@ constexpr uint32_t P_MAXN_BIG = 256;        // ... and beyond (k = 7: 128 KB of 
 constexpr uint32_t p_maxn(bool cached) { return cached ? P_MAXN : P_MAXN_BIG; }
 // leave-one-out jobs per event: (n + 1) * K <= max(G - 1, n + 1) <= maxn + 1 (G <= maxn + 2 is checked)
 constexpr uint32_t p_maxjobs(bool cached) { return p_maxn(cached) + 1; }
-// leave-one-out accumulators: 3 slots (accept % 3) x (maxn + 1) members x one 64-byte line
-constexpr size_t p_acc_bytes(uint32_t maxn) { return size_t(3) * (maxn + 1) * 8 * sizeof(unsigned long long); }
+// leave-one-out accumulators: 3 slots (accept % 3) x 8 group replicas x (maxn + 1) members x 2 words
+constexpr size_t p_acc_bytes(uint32_t maxn) { return size_t(3) * 8 * (maxn + 1) * 2 * sizeof(unsigned long long); }
+// A leave-one-out accumulator word = (2^-50 fixed-point sum << 6) + number of contributions: a
+// reader that finds the count at K knows the sum is complete -- no barrier between the jobs and
+// the workgroups that need their totals.  Sums of such words add sums and counts independently
+// (two's complement, counts <= 32 < 64); |sum| < 64 keeps the word inside 63 bits.
+__device__ __forceinline__ unsigned long long p_acc_word(double v) {
+    return ((unsigned long long)__double2ll_rn(v * 0x1p50) << 6) + 1ull;
+}
+__device__ __forceinline__ double p_acc_value(unsigned long long w) { return double((long long)w >> 6) * 0x1p-50; }
+__device__ __forceinline__ uint32_t p_acc_count(unsigned long long w) { return uint32_t(w & 63ull); }
 constexpr uint32_t P_SPIN_LIMIT = 1u << 22;  // ~0.5 s of polling
 constexpr uint32_t P_SOFT = 64;              // uncertain candidates listed per window (more become plain events)
 
@@ -989,11 +998,12 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             }
             // the accumulators of the next accept are cleared now: every workgroup read them (two
             // accepts ago) before it arrived at this window's first barrier
-            unsigned long long *nx = part + uint64_t((acc_slot + 1) % 3) * (maxn + 1) * 8;
-            for (uint32_t r = tid; r <= n; r += P_THREADS) {
-                const unsigned long long o0 = __hip_atomic_exchange(nx + uint64_t(r) * 8, 0ull, RLX_AGENT);
-                const unsigned long long o1 = __hip_atomic_exchange(nx + uint64_t(r) * 8 + 1, 0ull, RLX_AGENT);
-                if ((o0 & o1) == 0x7ff8dead0000beefull) sync->pad0[2] = 1;  // (never: consumes them)
+            // (all eight group replicas; the stores are acknowledged before this block's next
+            // barrier arrival, and nobody adds to that slot before that barrier has completed)
+            unsigned long long *nx = part + uint64_t((acc_slot + 1) % 3) * 8 * (maxn + 1) * 2;
+            for (uint32_t i = tid; i < 8u * (n + 1) * 2u; i += P_THREADS) {
+                const uint32_t g = i / ((n + 1) * 2u), w = i % ((n + 1) * 2u);
+                __hip_atomic_store(nx + (uint64_t(g) * (maxn + 1)) * 2 + w, 0ull, RLX_AGENT);
             }
         }
         // ================= leave-one-out (get_lowest_record_index, records.rs:220-252, with
@@ -1004,7 +1014,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // (>= 2^-3) convert without rounding.  (Every term is >= 0: the clamps of the reference
         // leave no negative bin here, so there is no NaN to carry.)
         const double rdiv = 1.0 / (dn - 1.0);
-        unsigned long long *acc = part + uint64_t(acc_slot) * (maxn + 1) * 8;
+        unsigned long long *acc_all = part + uint64_t(acc_slot) * 8 * (maxn + 1) * 2;          // the slot's replicas
+        const unsigned long long *acc = acc_all + uint64_t(blockIdx.x & 7u) * (maxn + 1) * 2;  // this group's
         bool first_job = true;
         for (uint32_t job = blockIdx.x; job < jobs && has_job; job += G) {
             if (lead && one_job) break;
@@ -1059,18 +1070,15 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 scratch[80 + wave] = sv;
             }
             __syncthreads();
-            if (tid == 0) {
+            if (tid < 8) {  // lane g adds the job's words to group g's replica
                 double th = 0.0, ts = 0.0;
                 for (uint32_t w = 0; w < P_THREADS / 64; w++) {
                     th += scratch[64 + w];
                     ts += scratch[80 + w];
                 }
-                // two adds in flight, results consumed before the arrival below
-                const unsigned long long o0 = __hip_atomic_fetch_add(
-                        acc + uint64_t(r) * 8, (unsigned long long)__double2ll_rn(th * 0x1p56), RLX_AGENT);
-                const unsigned long long o1 = __hip_atomic_fetch_add(
-                        acc + uint64_t(r) * 8 + 1, (unsigned long long)__double2ll_rn(ts * 0x1p56), RLX_AGENT);
-                if ((o0 & o1) == 0x7ff8dead0000beefull) sync->pad0[2] = 1;  // (never: consumes them)
+                unsigned long long *dst = acc_all + (uint64_t(tid) * (maxn + 1) + r) * 2;
+                atomicAdd(dst, p_acc_word(th));
+                atomicAdd(dst + 1, p_acc_word(ts));
             }
         }
         st.cursor = p + 1;
@@ -1093,52 +1101,91 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             ctl->ev_n = n;
         }
         P_STAMP(3);
-        if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
-        P_STAMP(4);
         // ================= finalize (every workgroup): totals -> delta_jsd -> argmin (strict '<'
-        // from 1e6, first index), all from the accumulators: one memory round trip
+        // from 1e6, first index), all from the accumulators
         uint32_t lowest;
         double dmin, dsecond;
         bool any_risky, ev_risky;
         if (n < 64) {
-            // every wave on its own (lane r = member r, lane n = the whole set): no LDS, no barrier
-            const bool valid = lane <= n;
-            const long long ah = valid ? (long long)__hip_atomic_load(acc + uint64_t(lane) * 8, RLX_AGENT) : 0ll;
-            const long long as = valid ? (long long)__hip_atomic_load(acc + uint64_t(lane) * 8 + 1, RLX_AGENT) : 0ll;
-            const double h = double(ah) * 0x1p-56, sv = double(as) * 0x1p-56;
-            const double hm = __shfl(h, int(n), 64), svn = __shfl(sv, int(n), 64);
-            st.total_jsd = hm - st.sumH / dn;
-            ev_risky = sum_risky(svn, B) || !(hm == hm);
-            const bool mem = lane < n;
-            const double mH = mem ? s_mH[lane] : 0.0;
-            const double dl = mem ? st.total_jsd - (h - (st.sumH - mH) * rdiv) : 1e6;  // delta_jsd
-            P_STAMP(6);
-            dmin = dvs_wave_min(dl);
-            const unsigned long long at = __ballot(mem && dl == dmin && dmin < 1e6);
-            lowest = at ? uint32_t(__builtin_ctzll(at)) : 0u;
-            dsecond = dvs_wave_min((mem && lane != lowest) ? dl : 1e6);
-            any_risky = __ballot(mem && sum_risky(sv, B)) != 0ull;
-            P_STAMP(7);
-            if (lead && wave == 0) {
-                const double mu = dvs_wave_sum(mem ? dl : 0.0) / dn;
-                const double t = mem ? dl - mu : 0.0;
-                const double sd = sqrt(dvs_wave_sum(t * t) / (dn - 1.0));
-                if (mem) {
-                    d.dtmp[lane] = dl;
-                    d.dsum[lane] = sv;
-                    d.mDelta[lane] = dl;
+            // No barrier: one wave polls this group's replica (lane r = member r, lane n = the whole
+            // set) until every word carries K contributions, takes the decisions and hands them to
+            // the other waves through LDS.  Bounded like every other spin of the kernel.
+            if (wave == 0) {
+                const bool valid = lane <= n;
+                unsigned long long wh = 0, ws = 0;
+                uint32_t spins = 0;
+                int ok = 1;
+                for (;;) {
+                    if (valid) {
+                        wh = __hip_atomic_load(acc + uint64_t(lane) * 2, RLX_AGENT);
+                        ws = __hip_atomic_load(acc + uint64_t(lane) * 2 + 1, RLX_AGENT);
+                    }
+                    if (__ballot(valid && (p_acc_count(wh) != K || p_acc_count(ws) != K)) == 0ull) break;
+                    if ((++spins & 255u) == 0 &&
+                        (spins > P_SPIN_LIMIT || __hip_atomic_load(&sync->timeout, RLX_AGENT))) {
+                        __hip_atomic_store(&sync->timeout, 1u, RLX_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
                 }
+                P_STAMP(4);
+                const double h = p_acc_value(wh), sv = p_acc_value(ws);
+                const double hm = __shfl(h, int(n), 64), svn = __shfl(sv, int(n), 64);
+                const double tj = hm - st.sumH / dn;
+                const bool evr = sum_risky(svn, B) || !(hm == hm);
+                const bool mem = lane < n;
+                const double mH = mem ? s_mH[lane] : 0.0;
+                const double dl = mem ? tj - (h - (st.sumH - mH) * rdiv) : 1e6;  // delta_jsd
+                P_STAMP(6);
+                const double mn = dvs_wave_min(dl);
+                const unsigned long long at = __ballot(mem && dl == mn && mn < 1e6);
+                const uint32_t lw = at ? uint32_t(__builtin_ctzll(at)) : 0u;
+                const double sec = dvs_wave_min((mem && lane != lw) ? dl : 1e6);
+                const bool anyr = __ballot(mem && sum_risky(sv, B)) != 0ull;
                 if (lane == 0) {
-                    ctl->total_jsd = st.total_jsd;
-                    ctl->mean_delta = mu;
-                    ctl->std_delta = sd;
-                    ctl->cov_delta = sd / mu;
+                    scratch[100] = mn;
+                    scratch[101] = double(lw);
+                    scratch[102] = sec;
+                    scratch[103] = tj;
+                    scratch[104] = anyr ? 1.0 : 0.0;
+                    scratch[105] = evr ? 1.0 : 0.0;
+                    scratch[106] = double(ok);
+                }
+                P_STAMP(7);
+                if (lead) {
+                    const double mu = dvs_wave_sum(mem ? dl : 0.0) / dn;
+                    const double t = mem ? dl - mu : 0.0;
+                    const double sd = sqrt(dvs_wave_sum(t * t) / (dn - 1.0));
+                    if (mem) {
+                        d.dtmp[lane] = dl;
+                        d.dsum[lane] = sv;
+                        d.mDelta[lane] = dl;
+                    }
+                    if (lane == 0) {
+                        ctl->total_jsd = tj;
+                        ctl->mean_delta = mu;
+                        ctl->std_delta = sd;
+                        ctl->cov_delta = sd / mu;
+                    }
                 }
             }
+            __syncthreads();
+            dmin = scratch[100];
+            lowest = uint32_t(scratch[101]);
+            dsecond = scratch[102];
+            st.total_jsd = scratch[103];
+            any_risky = scratch[104] != 0.0;
+            ev_risky = scratch[105] != 0.0;
+            if (scratch[106] == 0.0) { exit_status = SEL_ERROR; break; }
         } else {
+            // larger sets: a grid barrier, then the words are complete (the jobs' adds were
+            // acknowledged before their workgroups arrived)
+            if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
+            P_STAMP(4);
             for (uint32_t r = tid; r <= n; r += P_THREADS) {
-                const double h = double((long long)__hip_atomic_load(acc + uint64_t(r) * 8, RLX_AGENT)) * 0x1p-56;
-                const double sv = double((long long)__hip_atomic_load(acc + uint64_t(r) * 8 + 1, RLX_AGENT)) * 0x1p-56;
+                const double h = p_acc_value(__hip_atomic_load(acc + uint64_t(r) * 2, RLX_AGENT));
+                const double sv = p_acc_value(__hip_atomic_load(acc + uint64_t(r) * 2 + 1, RLX_AGENT));
                 if (r == n) {
                     scratch[110] = h;
                     scratch[111] = sv;
