@@ -61,6 +61,9 @@ struct dvs_matrix {
     double *d_freqs = nullptr;     // kind 1
     uint32_t *d_totals = nullptr;  // valid k-mers per row (kind 1: 1 for every row)
     double *d_entropy = nullptr;   // H(row freq vector), bits
+    // totals of the first rows as the builder left them (copied in the build's own stream sync):
+    // the selectors need their seeds' totals on the host and would otherwise pay a round trip
+    std::vector<uint32_t> h_head_totals;
     int device = 0;
     dvs_ctx *ctx = nullptr;  // owner of the allocations
 };

@@ -421,6 +421,12 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
 #undef DVS_LAUNCH_HIST_ANY
 #undef DVS_LAUNCH_HIST
     if (!rc && (e = hipGetLastError()) != hipSuccess) rc = dvs_hip_fail(ctx, e, "histogram launch");
+    // the totals of the first rows travel back in the same synchronisation (seed rows of a selection)
+    m->h_head_totals.assign(std::min<size_t>(nseq, 4096), 0u);
+    if (!rc && !m->h_head_totals.empty() &&
+        hipMemcpyAsync(m->h_head_totals.data(), m->d_totals, m->h_head_totals.size() * 4, hipMemcpyDeviceToHost,
+                       ctx->stream) != hipSuccess)
+        m->h_head_totals.clear();
     // the lists go back to the cache; stream order protects them until the kernels ran
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc)
         rc = dvs_set_error(ctx, DVS_ERR_RUNTIME, "histogram kernels failed");

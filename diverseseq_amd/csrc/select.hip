@@ -998,7 +998,9 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     std::vector<uint64_t> seeds;
     {
         std::vector<uint32_t> h_tot(n_seed);
-        if (!order && n_seed) {
+        if (!order && n_seed && n_seed <= m->h_head_totals.size()) {
+            std::copy(m->h_head_totals.begin(), m->h_head_totals.begin() + n_seed, h_tot.begin());  // no round trip
+        } else if (!order && n_seed) {
             DVS_HIP(ctx, hipMemcpyAsync(h_tot.data(), m->d_totals, size_t(n_seed) * 4,
                                         hipMemcpyDeviceToHost, ctx->stream));
         } else {
@@ -1006,7 +1008,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
                 DVS_HIP(ctx, hipMemcpyAsync(&h_tot[p], m->d_totals + order[p], 4, hipMemcpyDeviceToHost,
                                             ctx->stream));
         }
-        DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (order || n_seed > m->h_head_totals.size()) DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (uint64_t p = 0; p < n_seed; p++)
             if (h_tot[p] > 0) seeds.push_back(p);
     }
