@@ -138,6 +138,134 @@ __global__ __launch_bounds__(MASH_THREADS) void hash_filter_kernel(
     }
 }
 
+// ---- DNA fast path (num_states == 4, k <= 32) ------------------------------------------------
+// The same hashes from 2-bit packed bases.  The tile's bytes are packed once into LDS words
+// (16 bases per word, the earliest base in the top bits, plus a 16-bit invalid mask), a window is
+// three LDS words and a funnel shift instead of k byte reads, the mash-canonical choice is one
+// integer comparison of the window with its bit-reversed complement, and a hash round has no
+// 32-bit multiply left: v * 0xCC9E2D51 -> rotl 15 -> * 0x1B873593 takes four values for v in 0..3
+// (selected, not computed) and h * 5 + c is a shift-add.  (v_mul_lo_u32 runs at a quarter of the
+// rate of the other integer instructions; the byte-wise kernel spends three per base.)
+__device__ __forceinline__ uint32_t mash_pack4(uint32_t w) {  // 4 bases -> 8 bits, earliest in the top pair
+    const uint32_t x = w & 0x03030303u;
+    return ((x << 6) | (x >> 4) | (x >> 14) | (x >> 24)) & 0xFFu;
+}
+__device__ __forceinline__ uint32_t mash_inv4(uint32_t w) {  // 4 bases -> 4 bits, set where the byte is >= 4
+    uint32_t t = w & 0xFCFCFCFCu;
+    t |= t >> 4;
+    t |= t >> 2;
+    t |= t >> 1;
+    t &= 0x01010101u;
+    return ((t << 3) | (t >> 6) | (t >> 15) | (t >> 24)) & 0xFu;
+}
+constexpr uint32_t mash_round_const(uint32_t v) {
+    uint32_t k = v * 0xCC9E2D51u;
+    k = (k << 15) | (k >> 17);
+    return k * 0x1B873593u;
+}
+__device__ __forceinline__ uint32_t mash_round(uint32_t h, uint32_t v) {
+    constexpr uint32_t c1 = mash_round_const(1), c2 = mash_round_const(2), c3 = mash_round_const(3);
+    const uint32_t odd = (v & 1u) ? c1 : 0u;
+    const uint32_t odd_hi = (v & 1u) ? c3 : c2;
+    h ^= (v & 2u) ? odd_hi : odd;
+    h = (h << 13) | (h >> 19);
+    // h * 5 + c as one shift-add (written (h << 2) + h the compiler turns it back into a
+    // v_mad_u64_u32, which issues at a quarter of the rate)
+    uint32_t t;
+    asm("v_lshl_add_u32 %0, %1, 2, %1" : "=v"(t) : "v"(h));
+    return t + 0xE6546B64u;
+}
+
+template <bool K16>  // K16: k <= 16, a window fits 32 bits
+__global__ __launch_bounds__(MASH_THREADS) void hash_filter_dna_kernel(
+    const uint8_t *__restrict__ seqs, uint64_t nbytes_all, const MTile *__restrict__ tiles, uint32_t k,
+    int canonical, const long long *__restrict__ lo, const uint32_t *__restrict__ hi,
+    const uint8_t *__restrict__ active, uint32_t *__restrict__ cand,
+    const uint64_t *__restrict__ cand_off, const uint32_t *__restrict__ cand_cap,
+    uint32_t *__restrict__ cand_cnt) {
+    constexpr uint32_t NW = (MASH_TILE + MAX_K + 15 + 15) / 16 + 3;
+    __shared__ uint2 pk[NW];  // x: 16 bases packed, y: their invalid mask
+    __shared__ uint32_t tbl[2 * MASH_TILE];
+    __shared__ uint32_t s_max_seen;
+    const MTile t = tiles[blockIdx.x];
+    if (!active[t.seq]) return;
+    const uint64_t base_al = t.begin & ~15ull;
+    const uint32_t nbytes = t.count + k - 1;
+    const uint32_t nwords = uint32_t((t.begin - base_al + nbytes + 15) >> 4);
+    for (uint32_t j = threadIdx.x; j < nwords + 3; j += MASH_THREADS) {
+        const uint64_t a = base_al + uint64_t(j) * 16;
+        uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);  // invalid filler
+        if (j < nwords) {
+            if (a + 16 <= nbytes_all) {
+                v = *reinterpret_cast<const uint4 *>(seqs + a);
+            } else {
+                uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                for (int i = 0; i < 16; i++)
+                    if (a + i < nbytes_all) {
+                        w[i >> 2] &= ~(0xFFu << (8 * (i & 3)));
+                        w[i >> 2] |= uint32_t(seqs[a + i]) << (8 * (i & 3));
+                    }
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        const uint32_t p = (mash_pack4(v.x) << 24) | (mash_pack4(v.y) << 16) | (mash_pack4(v.z) << 8) | mash_pack4(v.w);
+        const uint32_t m = (mash_inv4(v.x) << 12) | (mash_inv4(v.y) << 8) | (mash_inv4(v.z) << 4) | mash_inv4(v.w);
+        pk[j] = make_uint2(p, m);
+    }
+    for (uint32_t i = threadIdx.x; i < 2 * MASH_TILE; i += MASH_THREADS) tbl[i] = 0xFFFFFFFFu;
+    if (threadIdx.x == 0) s_max_seen = 0;
+    __syncthreads();
+    const long long lo_q = lo[t.seq];
+    const uint32_t hi_q = hi[t.seq];
+    const uint32_t cap = cand_cap[t.seq];
+    uint32_t *out = cand + cand_off[t.seq];
+    const uint32_t rel0 = uint32_t(t.begin - base_al);
+    const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    for (uint32_t i = threadIdx.x; i < t.count; i += MASH_THREADS) {
+        const uint32_t rel = rel0 + i, j = rel >> 4, sh = rel & 15u;
+        const uint2 w0 = pk[j], w1 = pk[j + 1], w2 = pk[j + 2];
+        // 48 bases from position j * 16; the window is bases sh .. sh + k - 1 of them
+        const uint64_t hi64 = (uint64_t(w0.x) << 32) | w1.x;
+        const uint64_t V = sh ? ((hi64 << (2 * sh)) | (uint64_t(w2.x) >> (32 - 2 * sh))) : hi64;
+        const uint64_t K = V >> (64 - 2 * k);  // first base in the top pair of the low 2k bits
+        const uint64_t I48 = (uint64_t(w0.y) << 32) | (uint64_t(w1.y) << 16) | w2.y;
+        const uint64_t Iw = ((I48 << (16 + sh)) >> (64 - k));  // invalid flags of the window's bases
+        if (Iw) continue;
+        uint64_t X = K;
+        if (canonical) {
+            // reverse complement: pairs in reverse order, each base + 2 mod 4 (= its top bit flipped)
+            uint64_t R = __brevll(K);  // pair order reversed, bits inside a pair swapped
+            R = ((R >> 1) & 0x5555555555555555ull) | ((R & 0x5555555555555555ull) << 1);
+            R = (R >> (64 - 2 * k)) ^ (0xAAAAAAAAAAAAAAAAull & kmask);
+            if (R < K) X = R;  // lexicographic order of the bases = numeric order (distance.rs:69-78)
+        }
+        uint32_t h = 0x9747B28Cu ^ k;
+        if (K16) {
+            uint32_t xt = uint32_t(X) << (32 - 2 * k);
+            for (uint32_t b = 0; b < k; b++) {
+                h = mash_round(h, xt >> 30);
+                xt <<= 2;
+            }
+        } else {
+            uint64_t xt = X << (64 - 2 * k);
+            for (uint32_t b = 0; b < k; b++) {
+                h = mash_round(h, uint32_t(xt >> 62));
+                xt <<= 2;
+            }
+        }
+        h = fmix32(h);
+        if ((long long)h > lo_q && h <= hi_q) {
+            bool fresh;
+            if (h == 0xFFFFFFFFu) fresh = atomicExch(&s_max_seen, 1u) == 0u;
+            else fresh = tile_insert(tbl, 2 * MASH_TILE - 1, h);
+            if (fresh) {
+                const uint32_t slot = atomicAdd(&cand_cnt[t.seq], 1u);
+                if (slot < cap) out[slot] = h;
+            }
+        }
+    }
+}
+
 // One workgroup per listed sequence: bitonic sort of <= SORT_CAP candidates in LDS,
 // unique, append after the lens[q] entries already final (they are all smaller).
 // status: 0 sketch complete, 1 range exhausted and more needed, 2 overflow.
@@ -377,11 +505,25 @@ extern "C" int dvs_mash_sketch(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_de
         DVS_HIP(ctx, hipMemcpyAsync(d_active.p, active.data(), nseq, hipMemcpyHostToDevice, ctx->stream));
         DVS_HIP(ctx, hipMemcpyAsync(d_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         DVS_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, nseq * 4, ctx->stream));
-        hipLaunchKernelGGL(hash_filter_kernel, dim3(uint32_t(tiles.size())), dim3(MASH_THREADS), 0,
-                           ctx->stream, d_seqs, d_tiles.as<MTile>(), k, num_states, mash_canonical,
-                           d_lo.as<long long>(), d_hi.as<uint32_t>(), d_active.as<uint8_t>(),
-                           d_cand.as<uint32_t>(), d_coff.as<uint64_t>(), d_cap.as<uint32_t>(),
-                           d_cnt.as<uint32_t>());
+        if (num_states == 4 && k <= 32 && !getenv("DVS_MASH_BYTEWISE")) {  // 2-bit packed windows
+            if (k <= 16)
+                hipLaunchKernelGGL((hash_filter_dna_kernel<true>), dim3(uint32_t(tiles.size())), dim3(MASH_THREADS),
+                                   0, ctx->stream, d_seqs, nbytes, d_tiles.as<MTile>(), k, mash_canonical,
+                                   d_lo.as<long long>(), d_hi.as<uint32_t>(), d_active.as<uint8_t>(),
+                                   d_cand.as<uint32_t>(), d_coff.as<uint64_t>(), d_cap.as<uint32_t>(),
+                                   d_cnt.as<uint32_t>());
+            else
+                hipLaunchKernelGGL((hash_filter_dna_kernel<false>), dim3(uint32_t(tiles.size())), dim3(MASH_THREADS),
+                                   0, ctx->stream, d_seqs, nbytes, d_tiles.as<MTile>(), k, mash_canonical,
+                                   d_lo.as<long long>(), d_hi.as<uint32_t>(), d_active.as<uint8_t>(),
+                                   d_cand.as<uint32_t>(), d_coff.as<uint64_t>(), d_cap.as<uint32_t>(),
+                                   d_cnt.as<uint32_t>());
+        } else
+            hipLaunchKernelGGL(hash_filter_kernel, dim3(uint32_t(tiles.size())), dim3(MASH_THREADS), 0,
+                               ctx->stream, d_seqs, d_tiles.as<MTile>(), k, num_states, mash_canonical,
+                               d_lo.as<long long>(), d_hi.as<uint32_t>(), d_active.as<uint8_t>(),
+                               d_cand.as<uint32_t>(), d_coff.as<uint64_t>(), d_cap.as<uint32_t>(),
+                               d_cnt.as<uint32_t>());
         hipLaunchKernelGGL(sort_select_kernel, dim3(uint32_t(list.size())), dim3(1024), sort_lds,
                            ctx->stream, d_list.as<uint32_t>(), d_cand.as<uint32_t>(),
                            d_coff.as<uint64_t>(), d_cap.as<uint32_t>(), d_cnt.as<uint32_t>(),
