@@ -1079,8 +1079,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     }
                 }
             }
-            h = dvs_wave_sum(h);
-            sv = dvs_wave_sum(sv);
+            h = dvs_wave_sum_dpp(h);
+            sv = dvs_wave_sum_dpp(sv);
             if (!first_job) __syncthreads();  // scratch[64..] still being read by thread 0
             first_job = false;
             if (lane == 0) {
