@@ -427,6 +427,38 @@ def test_euclidean(brca1):
     assert d[0, 1] < d[0, 3]  # tests/test_distance.py:37-39
 
 
+# ------------------------------------------------ every path of the persistent engine
+@pytest.mark.parametrize("k,n", [(6, 2), (6, 10), (6, 63), (6, 64), (6, 65), (5, 12), (7, 9), (4, 70)])
+def test_persistent_engine_set_sizes_and_bin_counts(ctx, k, n):
+    """the persistent engine's variants by set size (one polling wave below 64 members, a grid
+    barrier from 64 on), by state size (4^k <= 4096 with the candidate in registers and the f32
+    COARSE tier, 4^7 without) and by row mapping (row per workgroup / per wave): selected ids,
+    member order and rows bit-exact, floats to 1e-6, against the oracle"""
+    seqs = synth_seqs(2500, 900, seed=100 * k + n, ragged=True, invalid_frac=0.002)
+    m = ctx.build_matrix(seqs, k, 4)
+    sel = m.nmost(n)
+    s = _assert_selection(sel, oracle.nmost(seqs, n, k, 4))
+    assert s.engine == 1, "the persistent engine should have run"
+    sel.close()
+    m.close()
+
+
+@pytest.mark.parametrize("env", [{"DVS_PERSIST_WG_ROUNDS": "0"}, {"DVS_PERSIST_WG_ROUNDS": "100000"},
+                                 {"DVS_PERSIST_NO_COARSE": "1"}, {"DVS_NO_PERSIST": "1"}])
+def test_engine_knobs_do_not_change_the_answer(ctx, env, monkeypatch):
+    """row-per-wave only, row-per-workgroup only, without the COARSE tier, and the multi-launch
+    engine: one selection, one answer"""
+    seqs = synth_seqs(6000, 1200, seed=4242, ragged=True)
+    exp = oracle.nmost(seqs, 10, 6, 4)
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    m = ctx.build_matrix(seqs, 6, 4)
+    sel = m.nmost(10)
+    _assert_selection(sel, exp)
+    sel.close()
+    m.close()
+
+
 # ------------------------------------------------------------ _dvs drop-in level
 def test_selection_through_an_on_disk_store(brca1, tmp_path):
     """`dvs nmost` / `dvs max` over a .dvseqsz directory (diverseseq_amd/zarr_store.py): the store a
