@@ -73,41 +73,55 @@ __device__ __forceinline__ Agg chunk_agg(const uint8_t (&c)[ING_CHUNK], uint8_t 
     return a;
 }
 
-// inclusive scan of one Agg per thread over the block (Hillis-Steele in LDS); returns the
-// EXCLUSIVE prefix of this thread and the block total in `total`
+// scan of one Agg per thread over the block: a shuffle scan inside each wave, the four wave totals
+// through LDS; returns the EXCLUSIVE prefix of this thread and the block total in `total`
 __device__ __forceinline__ Agg block_scan_agg(Agg mine, Agg *lds, Agg &total) {
-    const int t = threadIdx.x;
-    lds[t] = mine;
-    __syncthreads();
-    for (int o = 1; o < ING_THREADS; o <<= 1) {
-        Agg v = lds[t];
-        if (t >= o) v = agg_join(lds[t - o], v);
-        __syncthreads();
-        lds[t] = v;
-        __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Agg inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const Agg up{__shfl_up(inc.nl, o, 64), __shfl_up(inc.gt, o, 64), __shfl_up(inc.ng, o, 64)};
+        if (lane >= o) inc = agg_join(up, inc);
     }
-    total = lds[ING_THREADS - 1];
-    const Agg ex = t ? lds[t - 1] : Agg{-1, -1, 0};
+    if (lane == 63) lds[wave] = inc;
     __syncthreads();
-    return ex;
+    Agg carry{-1, -1, 0}, all{-1, -1, 0};
+#pragma unroll
+    for (int w = 0; w < ING_THREADS / 64; w++) {
+        const Agg t = lds[w];
+        if (w < wave) carry = agg_join(carry, t);
+        all = agg_join(all, t);
+    }
+    total = all;
+    Agg ex{__shfl_up(inc.nl, 1, 64), __shfl_up(inc.gt, 1, 64), __shfl_up(inc.ng, 1, 64)};
+    if (lane == 0) ex = Agg{-1, -1, 0};
+    __syncthreads();  // lds is reused by the next scan
+    return agg_join(carry, ex);
 }
 
 __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long mine, unsigned long long *lds,
                                                              unsigned long long &total) {
-    const int t = threadIdx.x;
-    lds[t] = mine;
-    __syncthreads();
-    for (int o = 1; o < ING_THREADS; o <<= 1) {
-        unsigned long long v = lds[t];
-        if (t >= o) v += lds[t - o];
-        __syncthreads();
-        lds[t] = v;
-        __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
     }
-    total = lds[ING_THREADS - 1];
-    const unsigned long long ex = t ? lds[t - 1] : 0ull;
+    if (lane == 63) lds[wave] = inc;
     __syncthreads();
-    return ex;
+    unsigned long long carry = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < ING_THREADS / 64; w++) {
+        const unsigned long long t = lds[w];
+        if (w < wave) carry += t;
+        all += t;
+    }
+    total = all;
+    unsigned long long ex = __shfl_up(inc, 1, 64);
+    if (lane == 0) ex = 0;
+    __syncthreads();
+    return carry + ex;
 }
 
 // pass 1: aggregate of every block
