@@ -170,6 +170,26 @@ def main():
         stats["scan_stream_ms"], stats["scan_stream_rows"] = sel.bench_scan(5)
         sel.close()
         m.close()
+        if world == 1:
+            # also outside the timed region: BASELINE.json configs[1] (10k x 2 kb, k=6, nmost n=10) as a
+            # side number -- the headline workload above is the shape the north star quotes its target on
+            g.manual_seed(20260423)
+            c2 = torch.randint(0, 4, (10_000 * 2_000,), dtype=torch.uint8, device=dev, generator=g)
+            c2_off = np.arange(10_001, dtype=np.uint64) * np.uint64(2_000)
+            torch.cuda.synchronize()
+            best = None
+            for _ in range(4):
+                t0 = time.perf_counter()
+                m2 = ctx.build_matrix_device(c2.data_ptr(), c2_off, 6, 4)
+                s2 = m2.nmost(10)
+                acc2 = s2.summary().n_accepts
+                dt = time.perf_counter() - t0
+                s2.close()
+                m2.close()
+                best = dt if best is None or dt < best else best
+            stats["c2"] = {"workload": "BASELINE.json configs[1]: 10000 x 2000 bp, k=6, nmost n=10, inputs in HBM",
+                           "ms": best * 1e3, "sequences_per_s": 10_000 / best, "accepts": acc2}
+            del c2
     if rank == 0:
         total_seqs = a.nseq * world * a.steps
         scan_s = stats["scan_ms"] / 1e3
@@ -227,6 +247,8 @@ def main():
                 "ms": stats["scan_stream_ms"], "rows": stats["scan_stream_rows"],
                 "achieved": gbps, "unit": "GB/s", "frac": gbps / peak,
             }
+        if "c2" in stats:
+            out["config"]["also_configs_1"] = stats["c2"]
         # HBM traffic of the dominant kernel: measured separately with rocprofv3 PMC passes
         # (bench.py cannot run under the profiler and time itself); committed in profiles/
         try:
