@@ -876,6 +876,8 @@ static int sel_poll(dvs_ctx *ctx, dvs_select *s) {
 
 template <typename T>
 static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat) {
+    unsigned long long persist_cursor = 0;
+    unsigned persist_launches = 0;
     // the loo grid must cover the largest set a batch can reach
     for (;;) {
         int rc = sel_poll(ctx, s);
@@ -926,9 +928,18 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat) {
         if (c.status != SEL_RUN)
             return dvs_set_error(ctx, DVS_ERR_RUNTIME, "selection engine in state %u", c.status);
         if (s->persist) {
-            rc = dvs_persist_launch(ctx, s);
-            if (rc) return rc;
-            continue;
+            // a persistent launch that comes back still RUNNING with the cursor where it was did
+            // not take the state it found (e.g. an event left pending by the arbiter's hand-off):
+            // the multi-launch kernels, which take any state, carry on -- never a relaunch loop
+            if (persist_launches && c.cursor == persist_cursor) {
+                s->persist = false;
+            } else {
+                persist_cursor = c.cursor;
+                persist_launches++;
+                rc = dvs_persist_launch(ctx, s);
+                if (rc) return rc;
+                continue;
+            }
         }
         for (int i = 0; i < s->batch; i++) launch_iteration<T>(ctx, s, mat, 0);
         DVS_HIP(ctx, hipGetLastError());
