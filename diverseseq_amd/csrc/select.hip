@@ -875,9 +875,19 @@ static int sel_poll(dvs_ctx *ctx, dvs_select *s) {
 }
 
 template <typename T>
-static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat) {
+static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_unpolled = false) {
     unsigned long long persist_cursor = 0;
     unsigned persist_launches = 0;
+    bool persist_was_last = false;  // nothing but the poll happened since the last persistent launch
+    if (s->persist && first_unpolled) {
+        // straight behind the set-up kernels, no host round trip in between: the kernel itself
+        // returns at once unless the control block says RUN
+        persist_cursor = s->params.n_seed;  // the cursor the set-up leaves behind
+        persist_launches = 1;
+        persist_was_last = true;
+        int rc0 = dvs_persist_launch(ctx, s);
+        if (rc0) return rc0;
+    }
     // the loo grid must cover the largest set a batch can reach
     for (;;) {
         int rc = sel_poll(ctx, s);
@@ -917,6 +927,7 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat) {
                                      (unsigned long long)c.arb_pos, c.arb_stage);
             rc = dvs_select_arbitrate(ctx, s);
             if (rc) return rc;
+            persist_was_last = false;
             launch_iteration<T>(ctx, s, mat, c.arb_stage == ARB_RESOLVE ? 1 : 2);
             DVS_HIP(ctx, hipGetLastError());
             continue;
@@ -931,11 +942,12 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat) {
             // a persistent launch that comes back still RUNNING with the cursor where it was did
             // not take the state it found (e.g. an event left pending by the arbiter's hand-off):
             // the multi-launch kernels, which take any state, carry on -- never a relaunch loop
-            if (persist_launches && c.cursor == persist_cursor) {
+            if (persist_launches && persist_was_last && c.cursor == persist_cursor) {
                 s->persist = false;
             } else {
                 persist_cursor = c.cursor;
                 persist_launches++;
+                persist_was_last = true;
                 rc = dvs_persist_launch(ctx, s);
                 if (rc) return rc;
                 continue;
@@ -958,10 +970,9 @@ static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat, const std::vecto
     hipLaunchKernelGGL(rebuild_kernel, dim3(1), dim3(WIDE_THREADS), 0, ctx->stream, s->dev);
     launch_iteration<T>(ctx, s, mat, 2);  // loo + finalize of the initial set
     DVS_HIP(ctx, hipGetLastError());
-    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    dvs_dev_free(ctx, d_seed);
+    dvs_dev_free(ctx, d_seed);  // (back to the ctx cache: any later user is ordered behind seed_kernel on this stream)
     if (s->params.flags & DVS_SELECT_STEPWISE) return sel_poll(ctx, s);
-    return sel_run_loop<T>(ctx, s, mat);
+    return sel_run_loop<T>(ctx, s, mat, true);
 }
 
 extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t *order,
