@@ -172,7 +172,8 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                                             unsigned long long *softp,
                                             uint64_t first, uint64_t stride, uint64_t nrows,
                                             uint32_t lane, uint32_t &nread,
-                                            uint32_t &nprecise, uint32_t &nmid, bool coarse_on) {
+                                            uint32_t &nprecise, uint32_t &nmid, bool coarse_on,
+                                            bool burst_drop = true) {
     const double dn = double(st.n), rn = 1.0 / dn;
     const double thr_lo = st.thr - st.band;
     const double thr_fast = thr_lo - FAST_BAND, thr_sure = st.thr + st.band + FAST_BAND;
@@ -196,17 +197,26 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                 const float rtn = float(rt * rn);
                 const dvs_f2 r2 = {rtn, rtn};
                 double c0 = 0.0, c1 = 0.0;
-                const uint64_t full = B - B % (256 * P_CH);
+                // Bursts of C_CH chunks: 4 KiB of a row requested at a time keep the memory pipe as full
+                // as 16 KiB do (scripts/micro/stream_read.hip), and a row that an earlier event has made
+                // pointless is dropped at the next burst with its other bytes never requested.
+                constexpr int C_CH = 8;
+                const uint64_t full = B - B % (256 * C_CH);
                 uint64_t i0 = 0;
-                for (; i0 < full; i0 += 256 * P_CH) {
-                    Raw4<T> raw[P_CH];
+                bool dropped = false;
+                for (; i0 < full; i0 += 256 * C_CH) {
+                    if (i0 && burst_drop && __hip_atomic_load(evp, RLX_AGENT) < p) {
+                        dropped = true;
+                        break;
+                    }
+                    Raw4<T> raw[C_CH];
 #pragma unroll
-                    for (int j = 0; j < P_CH; j++) raw[j].load(rp + i0 + uint64_t(j) * 256 + lane * 4);
+                    for (int j = 0; j < C_CH; j++) raw[j].load(rp + i0 + uint64_t(j) * 256 + lane * 4);
                     // (the scheduler would otherwise sink each load to its use: one 1 KiB request in
-                    // flight per wave instead of sixteen)
+                    // flight per wave instead of four)
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < P_CH; j += 2) {
+                    for (int j = 0; j < C_CH; j += 2) {
                         const uint64_t i = i0 + uint64_t(j) * 256 + lane * 4;
                         raw[j].pin();  // nothing of chunk j is consumed (converted) above this point
                         raw[j + 1].pin();
@@ -214,6 +224,7 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                         c1 += double(coarse4(raw[j + 1].c, *reinterpret_cast<const float4 *>(slf + i + 256), r2));
                     }
                 }
+                if (dropped) break;  // (an earlier event exists: this wave's later rows are pointless too)
                 for (; i0 < B; i0 += 256) {
                     const uint64_t i = i0 + lane * 4;
                     Raw4<T> raw;
@@ -312,7 +323,8 @@ __device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const 
                                                unsigned long long *evs, unsigned long long *softp,
                                                uint64_t first, uint64_t stride,
                                                uint64_t nrows, double *red, uint32_t &nread,
-                                               uint32_t &nprecise, uint32_t &nmid, bool coarse_on) {
+                                               uint32_t &nprecise, uint32_t &nmid, bool coarse_on,
+                                            bool burst_drop = true) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double dn = double(st.n), rn = 1.0 / dn;
     const double thr_fast = st.thr - st.band - FAST_BAND, thr_sure = st.thr + st.band + FAST_BAND;
@@ -754,7 +766,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             else
                 p_scan_rows<T, COARSE>(mat, d.totals, d.rowH, sl, slf, B, st, st.sumH - s_mH[st.li], evp, evs,
                                        &sync->soft[epoch % 3][0], uint64_t(blockIdx.x) * wpb + wave, nwaves,
-                                       nrows, lane, nread, nprecise, nmid, coarse_on);
+                                       nrows, lane, nread, nprecise, nmid, coarse_on,
+                                       (sync->no_coarse & 8u) == 0);
         }
         P_STAMP(0);
         if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
@@ -1337,7 +1350,8 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     init.wg_scale = 1.5f;
     if (const char *e = getenv("DVS_PERSIST_WG_ROUNDS")) init.wg_thresh = uint32_t(atoi(e));
     if (const char *e = getenv("DVS_PERSIST_WG_SCALE")) init.wg_scale = float(atof(e));
-    init.no_coarse = (getenv("DVS_PERSIST_NO_COARSE") ? 1u : 0u) | (getenv("DVS_PERSIST_NO_EVENTS") ? 2u : 0u);
+    init.no_coarse = (getenv("DVS_PERSIST_NO_COARSE") ? 1u : 0u) | (getenv("DVS_PERSIST_NO_EVENTS") ? 2u : 0u) |
+                     (getenv("DVS_PERSIST_NO_BURST_DROP") ? 8u : 0u);
     DVS_HIP(ctx, hipMemcpyAsync(s->psync, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     DVS_HIP(ctx, hipMemsetAsync(s->ppart, 0, p_acc_bytes(s->persist_maxn), ctx->stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
