@@ -37,6 +37,9 @@ def parse():
                          "one all_gather + final_nmost); 'exact' = rows sharded block-cyclically, set state "
                          "replicated, one MIN + one SUM all-reduce per greedy step (same answer as 1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-runs", action="store_true",
+                    help="only the timed steps: no streaming passes, no configs[1] side number (profiling runs: "
+                         "every launch of the dominant kernel is then a headline launch)")
     ap.add_argument("--cpu-sample", type=int, default=100_000,
                     help="sequences of the same workload the 1-thread CPU oracle is timed on")
     return ap.parse_args()
@@ -163,7 +166,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    if rank == 0 and not exact:
+    if rank == 0 and not exact and not a.no_side_runs:
         # outside the timed region: the scan arithmetic alone, one launch over the whole stream
         m = ctx.build_matrix_device(seqs.data_ptr(), offsets, a.k, 4)
         sel = m.nmost(a.n, window=a.window)

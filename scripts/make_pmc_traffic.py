@@ -28,7 +28,7 @@ fetch, write = load(sys.argv[1]), load(sys.argv[2])
 tag = sys.argv[3]
 doc = {
     "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), "
-              f"bench.py --steps 2 --warmup 1, MI355X (round 1, build {tag}); summaries in "
+              f"bench.py --steps 2 --warmup 1 --no-side-runs, MI355X (round 1, build {tag}); summaries in "
               f"profiles/{tag}_pmc_fetch_size.csv and profiles/{tag}_pmc_write_size.csv",
     "units": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts the 128-B "
              "requests of wide coalesced reads as 64 B, so read bytes = 2 x FETCH_SIZE "
@@ -38,7 +38,9 @@ doc = {
     "workload": "nmost n=10, 100000 x 5000 bp, k=6",
 }
 for label in KERNELS.values():
+    if label not in fetch or label not in write:
+        continue  # (the profiled run skips the side passes: bench.py --no-side-runs)
     f, w = fetch[label], write[label]
     doc[label] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2 * f + w) * 1024}
 json.dump(doc, open("profiles/pmc_traffic.json", "w"), indent=1)
-print(json.dumps({k: doc[k] for k in KERNELS.values()}, indent=1))
+print(json.dumps({k: doc[k] for k in KERNELS.values() if k in doc}, indent=1))

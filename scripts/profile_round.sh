@@ -9,9 +9,9 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 python3 $GRAFT_REPO_ROOT/bench.py > $out/bench.json 2> $out/bench.err || { echo bench failed; tail -3 $out/bench.err; exit 1; }
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/kt -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $out/bench_kt.json 2> $out/kt.err || { echo kernel-trace failed; tail -3 $out/kt.err; exit 1; }
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_fetch.err || { echo pmc fetch failed; tail -3 $out/pmc_fetch.err; exit 1; }
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_write.err || { echo pmc write failed; tail -3 $out/pmc_write.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/kt -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-side-runs > $out/bench_kt.json 2> $out/kt.err || { echo kernel-trace failed; tail -3 $out/kt.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-side-runs > /dev/null 2> $out/pmc_fetch.err || { echo pmc fetch failed; tail -3 $out/pmc_fetch.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-side-runs > /dev/null 2> $out/pmc_write.err || { echo pmc write failed; tail -3 $out/pmc_write.err; exit 1; }
 cd $GRAFT_REPO_ROOT
 db() { find $out/$1 -name '*.db' | head -1; }
 python3 scripts/rocpd_summary.py stats $(db kt) > $out/kernel_stats.csv
