@@ -224,7 +224,10 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                         c1 += double(coarse4(raw[j + 1].c, *reinterpret_cast<const float4 *>(slf + i + 256), r2));
                     }
                 }
-                if (dropped) break;  // (an earlier event exists: this wave's later rows are pointless too)
+                if (dropped) {  // (an earlier event exists: this wave's later rows are pointless too)
+                    nread--;    // not a row scored: it does not count towards the algorithmic bytes
+                    break;
+                }
                 for (; i0 < B; i0 += 256) {
                     const uint64_t i = i0 + lane * 4;
                     Raw4<T> raw;
