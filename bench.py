@@ -93,8 +93,10 @@ def main():
     from diverseseq_amd.parallel import merge_nmost, nmost_exact, shard_order
 
     exact = a.mode == "exact"
-    stream = torch.cuda.Stream() if exact else None
-    if exact:  # kernels and collectives ordered on one torch stream
+    dist_on = world > 1 or force_dist
+    stream = torch.cuda.Stream() if (exact or dist_on) else None
+    merge_buffers = {}
+    if exact or dist_on:  # kernels and collectives ordered on one torch stream: no host waits in between
         torch.cuda.set_stream(stream)
         ctx = engine.Context(local, stream=stream.cuda_stream)
     else:
@@ -134,7 +136,8 @@ def main():
             sel = m.nmost(a.n, window=a.window)
         if (world > 1 or force_dist) and not exact:
             merged = merge_nmost(ctx, sel, a.n, rank, world, rank * a.nseq, dev,
-                                 chunk_starts=[r * a.nseq for r in range(world)])
+                                 chunk_starts=[r * a.nseq for r in range(world)], shared_stream=True,
+                                 buffers=merge_buffers)
             merged.close()
         if collect:
             s = sel.summary()

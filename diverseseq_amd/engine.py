@@ -292,6 +292,19 @@ class Selection:
 
     def __init__(self, matrix: CountMatrix, handle):
         self.matrix, self.ctx, self._h = matrix, matrix.ctx, handle
+        self._gids = None
+        self._lazy_gids = None
+
+    @property
+    def global_ids(self):
+        """(merged selections, parallel.merge_*) global stream position of every gathered row"""
+        if self._gids is None and self._lazy_gids is not None:
+            self._gids = self._lazy_gids.get()
+        return self._gids
+
+    @global_ids.setter
+    def global_ids(self, value):
+        self._gids = value
 
     def close(self):
         if getattr(self, "_h", None):

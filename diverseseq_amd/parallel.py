@@ -58,25 +58,39 @@ def gather_winners(rows: np.ndarray, ids: np.ndarray, world: int, device, cap: i
     return np.concatenate(out_rows), np.concatenate(out_ids)
 
 
-def gather_winners_device(ctx, sel, world: int, device, cap: int):
+def gather_winners_device(ctx, sel, world: int, device, cap: int, *, shared_stream: bool = False,
+                          buffers: dict | None = None):
     """The same exchange with no host round trip: the members are gathered on the device
     straight into the all_gather's send buffer.  Returns device tensors (rows [world*cap, B],
     meta [world*cap, 2] = (chunk-local position, valid)); ranks with fewer than `cap` members
-    contribute zero rows flagged invalid, which the merge skips."""
+    contribute zero rows flagged invalid, which the merge skips.
+
+    shared_stream: the ctx launches on torch's current stream (Context(stream=...)), so the gather
+    kernel, the collectives and whatever consumes their output are ordered by the stream alone and
+    nothing here waits on the host.  buffers: a dict the four tensors are kept in between calls."""
     import torch
     import torch.distributed as dist
 
     B = sel.matrix.nbins
-    t_rows = torch.empty((cap, B), dtype=torch.float64, device=device)
-    t_meta = torch.empty((cap, 2), dtype=torch.float64, device=device)
-    all_rows = torch.empty((world * cap, B), dtype=torch.float64, device=device)
-    all_meta = torch.empty((world * cap, 2), dtype=torch.float64, device=device)
-    torch.cuda.current_stream().synchronize()  # the buffers exist before the library writes them
+    key = (world, cap, B, str(device))
+    if buffers is not None and buffers.get("key") == key:
+        t_rows, t_meta, all_rows, all_meta = buffers["tensors"]
+    else:
+        t_rows = torch.empty((cap, B), dtype=torch.float64, device=device)
+        t_meta = torch.empty((cap, 2), dtype=torch.float64, device=device)
+        all_rows = torch.empty((world * cap, B), dtype=torch.float64, device=device)
+        all_meta = torch.empty((world * cap, 2), dtype=torch.float64, device=device)
+        if buffers is not None:
+            buffers["key"], buffers["tensors"] = key, (t_rows, t_meta, all_rows, all_meta)
+        if not shared_stream:
+            torch.cuda.current_stream().synchronize()  # the buffers exist before the library writes them
     sel.gather_members(t_rows.data_ptr(), t_meta.data_ptr(), cap)
-    ctx.sync()
+    if not shared_stream:
+        ctx.sync()
     dist.all_gather_into_tensor(all_rows, t_rows)
     dist.all_gather_into_tensor(all_meta, t_meta)
-    torch.cuda.current_stream().synchronize()
+    if not shared_stream:
+        torch.cuda.current_stream().synchronize()
     return all_rows, all_meta
 
 
@@ -87,18 +101,31 @@ def _global_ids(all_meta, chunk_starts, cap: int) -> np.ndarray:
     return np.where(meta[:, 1] != 0, meta[:, 0].astype(np.int64) + starts, -1)
 
 
+class _LazyGlobalIds:
+    """global ids of the gathered rows, copied from the device on first use"""
+
+    def __init__(self, all_meta, chunk_starts, cap):
+        self._args, self._val = (all_meta, chunk_starts, cap), None
+
+    def get(self):
+        if self._val is None:
+            self._val = _global_ids(*self._args)
+        return self._val
+
+
 def merge_nmost(ctx, sel, n: int, rank: int, world: int, chunk_start: int, device,
-                chunk_starts=None):
+                chunk_starts=None, *, shared_stream: bool = False, buffers: dict | None = None):
     """exchange the winners and run final_nmost on the device; returns the merged Selection
     (its member positions index the gathered row list; `merged.global_ids` maps them to
     global stream positions).  With `chunk_starts` (every rank's chunk start) on a GPU the
     rows never leave HBM."""
     if chunk_starts is not None and getattr(device, "type", str(device)) == "cuda":
-        all_rows, all_meta = gather_winners_device(ctx, sel, world, device, cap=n)
+        all_rows, all_meta = gather_winners_device(ctx, sel, world, device, cap=n, shared_stream=shared_stream,
+                                                   buffers=buffers)
         m = ctx.matrix_from_device_freqs(all_rows.data_ptr(), world * n, sel.matrix.nbins,
                                          all_meta.data_ptr())
         merged = m.nmost(n)
-        merged.global_ids = _global_ids(all_meta, chunk_starts, n)
+        merged._lazy_gids = _LazyGlobalIds(all_meta, chunk_starts, n)  # (a device -> host copy: on demand)
         merged._keep = m
         return merged
     mem = sel.members(with_freqs=True)
