@@ -87,7 +87,7 @@ def test_store_semantics():
     lz = st.get_lazyseq("s1", 4)
     assert lz.seqid == "s1" and lz.num_states == 4 and lz.get_seq() == dup
     assert [l.seqid for l in st.get_lazyseqs(4)] == st.get_seqids()
-    with pytest.raises(FileNotFoundError):  # on-disk stores: tests/test_zarr_store.py
+    with pytest.raises(FileNotFoundError):  # on-disk stores: tests/test_dvseqsz_store.py
         _dvs.make_zarr_store("/tmp/no-such-store.dvseqsz", mode="r")
 
 
