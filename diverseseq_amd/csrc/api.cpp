@@ -8,7 +8,7 @@
 uint64_t dvs_pow_u64(uint32_t base, uint32_t exp, bool *overflow);
 void dvs_matrix_free_fields(dvs_matrix *m);
 int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs, uint64_t nbytes,
-                           const uint64_t *offsets);
+                           const uint64_t *offsets, bool no_wait);
 int dvs_matrix_fill_freq_entropy(dvs_ctx *ctx, dvs_matrix *m);
 int dvs_matrix_fill_freq_totals(dvs_ctx *ctx, dvs_matrix *m, const double *d_meta);
 
@@ -262,7 +262,10 @@ int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, cons
         delete m;
         return dvs_set_error(ctx, DVS_ERR_VALUE, "device sequence buffer must be 16-byte aligned");
     }
-    rc = nseq ? dvs_matrix_fill_counts(ctx, m, d_seqs, seqs_on_device ? nbytes : readable, offsets)
+    // (a device-resident input needs no host wait: the kernels' completion is an event the consumers
+    // of the matrix wait on when they need host-side data, dvs_matrix_settle)
+    rc = nseq ? dvs_matrix_fill_counts(ctx, m, d_seqs, seqs_on_device ? nbytes : readable, offsets,
+                                       seqs_on_device != 0 && !getenv("DVS_BUILD_WAIT"))
               : DVS_OK;
     if (d_tmp) {
         (void)hipStreamSynchronize(ctx->stream);

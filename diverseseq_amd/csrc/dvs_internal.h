@@ -34,6 +34,9 @@ struct dvs_ctx {
     size_t pool_bytes = 0;
 };
 
+// waits for a build that is still in flight (no-op otherwise) and moves the head totals to the vector
+struct dvs_matrix;
+int dvs_matrix_settle(dvs_ctx *ctx, const dvs_matrix *m);
 int dvs_dev_alloc(dvs_ctx *ctx, void **ptr, size_t bytes, const char *what);
 void dvs_dev_free(dvs_ctx *ctx, void *ptr);
 void dvs_dev_trim(dvs_ctx *ctx);
@@ -64,6 +67,11 @@ struct dvs_matrix {
     // totals of the first rows as the builder left them (copied in the build's own stream sync):
     // the selectors need their seeds' totals on the host and would otherwise pay a round trip
     std::vector<uint32_t> h_head_totals;
+    // ... or, for a build that did not wait for its kernels (device-resident input), still on their
+    // way: a pinned block the copy lands in and the event recorded behind it
+    uint32_t *h_head_pinned = nullptr;
+    hipEvent_t ev_built = nullptr;
+    uint32_t head_count = 0;
     int device = 0;
     dvs_ctx *ctx = nullptr;  // owner of the allocations
 };

@@ -308,8 +308,23 @@ uint64_t dvs_pow_u64(uint32_t base, uint32_t exp, bool *overflow) {
     return r;
 }
 
+int dvs_matrix_settle(dvs_ctx *ctx, const dvs_matrix *cm) {
+    dvs_matrix *m = const_cast<dvs_matrix *>(cm);
+    if (!m || !m->ev_built) return DVS_OK;
+    const hipError_t e = hipEventSynchronize(m->ev_built);
+    if (e == hipSuccess) m->h_head_totals.assign(m->h_head_pinned, m->h_head_pinned + m->head_count);
+    else m->h_head_totals.clear();
+    dvs_event_put(m->ctx, m->ev_built);
+    dvs_pinned_put(m->ctx, m->h_head_pinned);
+    m->ev_built = nullptr;
+    m->h_head_pinned = nullptr;
+    if (e != hipSuccess) return dvs_hip_fail(ctx ? ctx : m->ctx, e, "histogram kernels");
+    return DVS_OK;
+}
+
 void dvs_matrix_free_fields(dvs_matrix *m) {
     if (!m) return;
+    (void)dvs_matrix_settle(m->ctx, m);  // the pinned block must not go back to the cache with a copy pending
     dvs_dev_free(m->ctx, m->d_counts);
     dvs_dev_free(m->ctx, m->d_freqs);
     dvs_dev_free(m->ctx, m->d_totals);
@@ -325,7 +340,7 @@ void dvs_matrix_free_fields(dvs_matrix *m) {
 // a single tile its own workgroup (tile derived from the offsets on the device);
 // genome-length sequences get an explicit tile list and a second launch.
 int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
-                           uint64_t nbytes, const uint64_t *offsets) {
+                           uint64_t nbytes, const uint64_t *offsets, bool no_wait) {
     const uint32_t nseq = m->nrows, k = m->k, ns = m->num_states;
     const uint64_t B = m->nbins;
     std::vector<KTile> tiles;
@@ -421,6 +436,29 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
 #undef DVS_LAUNCH_HIST_ANY
 #undef DVS_LAUNCH_HIST
     if (!rc && (e = hipGetLastError()) != hipSuccess) rc = dvs_hip_fail(ctx, e, "histogram launch");
+    if (!rc && no_wait) {
+        // Device-resident input: nothing here needs the host to wait.  The first rows' totals are
+        // copied to a pinned block behind the kernels and an event marks their arrival; whoever
+        // needs them (the selection's seeds) waits on that event -- after doing the rest of its
+        // set-up while the histogram kernel runs.
+        void *pin = nullptr;
+        if (dvs_pinned_get(ctx, &pin) == DVS_OK) {
+            m->head_count = uint32_t(std::min<size_t>(nseq, 4096 / sizeof(uint32_t)));
+            m->h_head_pinned = static_cast<uint32_t *>(pin);
+            m->ev_built = dvs_event_get(ctx);
+            if (m->ev_built &&
+                hipMemcpyAsync(m->h_head_pinned, m->d_totals, size_t(m->head_count) * 4, hipMemcpyDeviceToHost,
+                               ctx->stream) == hipSuccess &&
+                hipEventRecord(m->ev_built, ctx->stream) == hipSuccess) {
+                cleanup();  // (the lists go back to the cache; stream order protects them)
+                return DVS_OK;
+            }
+            if (m->ev_built) dvs_event_put(ctx, m->ev_built);
+            dvs_pinned_put(ctx, pin);
+            m->ev_built = nullptr;
+            m->h_head_pinned = nullptr;
+        }
+    }
     // the totals of the first rows travel back in the same synchronisation (seed rows of a selection)
     m->h_head_totals.assign(std::min<size_t>(nseq, 4096), 0u);
     if (!rc && !m->h_head_totals.empty() &&

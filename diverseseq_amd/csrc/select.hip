@@ -1017,26 +1017,6 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
                 return dvs_set_error(ctx, DVS_ERR_VALUE,
                                      "seed position %llu is not local: the first n rows must be replicated",
                                      (unsigned long long)p);
-    std::vector<uint64_t> seeds;
-    {
-        std::vector<uint32_t> h_tot(n_seed);
-        if (!order && n_seed && n_seed <= m->h_head_totals.size()) {
-            std::copy(m->h_head_totals.begin(), m->h_head_totals.begin() + n_seed, h_tot.begin());  // no round trip
-        } else if (!order && n_seed) {
-            DVS_HIP(ctx, hipMemcpyAsync(h_tot.data(), m->d_totals, size_t(n_seed) * 4,
-                                        hipMemcpyDeviceToHost, ctx->stream));
-        } else {
-            for (uint64_t p = 0; p < n_seed; p++)
-                DVS_HIP(ctx, hipMemcpyAsync(&h_tot[p], m->d_totals + order[p], 4, hipMemcpyDeviceToHost,
-                                            ctx->stream));
-        }
-        if (order || n_seed > m->h_head_totals.size()) DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (uint64_t p = 0; p < n_seed; p++)
-            if (h_tot[p] > 0) seeds.push_back(p);
-    }
-    if (seeds.empty()) return dvs_set_error(ctx, DVS_ERR_VALUE, "records cannot be empty");  // :28-30
-    if (seeds.size() < 2) return dvs_set_error(ctx, DVS_ERR_VALUE, "must have > 1 KmerSeq");  // :227-230
-
     dvs_select *s = new dvs_select();
     s->ctx = ctx;
     s->params = *params;
@@ -1053,7 +1033,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     d.nlabels = nlabels;
     d.totals = m->d_totals;
     d.rowH = m->d_entropy;
-    const uint32_t cap = std::max<uint32_t>(std::max<uint32_t>(max_size, uint32_t(seeds.size())) + 1, 2);
+    const uint32_t cap = std::max<uint32_t>(std::max<uint32_t>(max_size, n_seed) + 1, 2);  // (seeds <= n_seed)
     s->cap = cap;
     const size_t need = size_t(cap) * B * 8 + 5 * B * 8 + size_t(npos) * 8 + nlabels + (1 << 20);
     size_t free_b = 0, total_b = 0;
@@ -1145,6 +1125,39 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
             return prc;
         }
     }
+    std::vector<uint64_t> seeds;
+    {
+        std::vector<uint32_t> h_tot(n_seed);
+        // (a matrix whose build is still in flight is waited for HERE, with everything above -- the
+        // allocations, the memsets, the engine set-up -- done while its kernels ran)
+        {
+            int src = dvs_matrix_settle(ctx, m);
+            if (src) {
+                sel_free(s);
+                return src;
+            }
+        }
+        if (!order && n_seed && n_seed <= m->h_head_totals.size()) {
+            std::copy(m->h_head_totals.begin(), m->h_head_totals.begin() + n_seed, h_tot.begin());  // no round trip
+        } else if (!order && n_seed) {
+            (void)hipMemcpyAsync(h_tot.data(), m->d_totals, size_t(n_seed) * 4, hipMemcpyDeviceToHost, ctx->stream);
+        } else {
+            for (uint64_t p = 0; p < n_seed; p++)
+                (void)hipMemcpyAsync(&h_tot[p], m->d_totals + order[p], 4, hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if ((order || n_seed > m->h_head_totals.size()) && hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            sel_free(s);
+            return dvs_set_error(ctx, DVS_ERR_RUNTIME, "reading the seed rows' totals failed");
+        }
+        for (uint64_t p = 0; p < n_seed; p++)
+            if (h_tot[p] > 0) seeds.push_back(p);
+    }
+    if (seeds.size() < 2) {
+        sel_free(s);
+        return seeds.empty() ? dvs_set_error(ctx, DVS_ERR_VALUE, "records cannot be empty")   // :28-30
+                             : dvs_set_error(ctx, DVS_ERR_VALUE, "must have > 1 KmerSeq");     // :227-230
+    }
+
     SelCtl c;
     std::memset(&c, 0, sizeof c);
     c.cursor = n_seed;

@@ -64,8 +64,12 @@ int dvs_ctx_device_info(dvs_ctx *ctx, char *name, size_t name_len, int *n_cu,
  * Builds, on the device, row r = the k-mer histogram of sequence r (uint32),
  * plus per-row total (number of valid k-mers) and Shannon entropy (bits) of
  * the row's frequency vector.  `seqs` is a HOST pointer when seqs_on_device
- * is 0 (it is copied to HBM), else a 16-byte-aligned DEVICE pointer that must
- * stay valid until the call returns; `offsets` is always a host array. */
+ * is 0 (it is copied to HBM), else a 16-byte-aligned DEVICE pointer; `offsets` is always a
+ * host array.  With a device pointer the call does NOT wait for its kernels: they are ordered on
+ * the ctx stream in front of everything that uses the matrix, and the first call that needs
+ * host-side data of it (a selection's seeds, dvs_matrix_get_*, dvs_ctx_sync) waits for them -- so
+ * the device buffer must stay valid, and unmodified, until then (DVS_BUILD_WAIT=1 in the
+ * environment restores a build that returns only when its kernels have finished). */
 int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device,
                      const uint64_t *offsets, uint32_t nseq, uint32_t k,
                      uint32_t num_states, dvs_matrix **out);

@@ -7,5 +7,5 @@ for cfg in "$@"; do
   rc=$?
   if [ $rc -ne 0 ]; then echo "$cfg FAILED rc=$rc"; tail -3 gpurun_out/ab.err; exit 1; fi
   python -c "
-import json; d=json.load(open('gpurun_out/ab.json')); print('$cfg', round(d['value']/1e6,2), 'ms', round(d['ms_per_step'],3), 'hist', round(d['config']['hist_ms_per_step'],3), 'sel', round(d['config']['scan_ms_per_step'],3), 'rows', d['config']['rows_scored_per_step'], 'stream', round(d['roofline']['scan_streaming']['ms'],3))"
+import json; d=json.load(open('gpurun_out/ab.json')); print('$cfg', round(d['value']/1e6,2), 'ms', round(d['ms_per_step'],3), 'hist', round(d['config']['hist_host_ms_per_step'],3), 'sel', round(d['config']['scan_ms_per_step'],3), 'rows', d['config']['rows_scored_per_step'], 'stream', round(d['roofline']['scan_streaming']['ms'],3))"
 done
