@@ -100,6 +100,10 @@ struct PState {  // replicated scalars (identical in every workgroup)
     uint32_t n, li;
     double sumH, total_jsd, thr, band, wscale;
     uint32_t n_windows, n_events, n_accepts;
+    uint32_t n_loo;  // leave-one-out rounds of this launch (accumulator slot = n_loo % 3)
+    // MODE_MAX: the set grows while it is below max_size (tentative pushes, records.rs:427-451)
+    uint32_t max_size, stat;
+    double mean_d, std_d, cov_d;  // statistics of the current set's delta_jsd
 };
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -622,7 +626,14 @@ __device__ __forceinline__ void p_argmin(const double *s_dl, const double *s_ds,
 // maxn = p_maxn(CACHED): compile-time offsets (runtime ones cost registers the scan loop needs),
 // smaller beyond 4096 bins so that 4^7 bins (128 KB of sl) still fit.
 // CACHED: B <= P_J * 512, so a thread's share of the candidate row stays in registers
-template <typename T, bool CACHED>
+// MAXM: select_max_divergent (records.rs:390-454).  While the set is below max_size an accepted
+// candidate is a TENTATIVE push: clone + push (the running sums ARE the clone's re-sums while the
+// set has only grown, see resolve_kernel), leave-one-out over the n + 1 members, and the bigger set
+// is kept iff the standard deviation (or the coefficient of variation) of the members' delta_jsd
+// rose; a rollback leaves every replica untouched.  At max_size the stream continues as above
+// (replace_lowest).  The summed vector S lives in LDS beside sl.  Anything too close to call ends
+// the launch with the event unconsumed; the multi-launch kernels (and the arbiter) take it.
+template <typename T, bool CACHED, bool MAXM = false>
 __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, const T *__restrict__ mat,
                                                                     PSync *sync, unsigned long long *part, uint32_t G) {
     constexpr uint32_t maxn = p_maxn(CACHED);
@@ -633,7 +644,9 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     // f32 copy of sl / n for the COARSE tier (count matrices whose state fits the register cache)
     constexpr bool COARSE = CACHED && sizeof(T) == 4;
     float *slf = reinterpret_cast<float *>(sl + ((B + 1) & ~1ull));
-    double *scratch = sl + ((B + 1) & ~1ull) + (COARSE ? ((B + 3) & ~3ull) / 2 : 0);
+    static_assert(!MAXM || CACHED, "the growth phase keeps the candidate's frequencies in registers");
+    double *Sl = sl + ((B + 1) & ~1ull) + (COARSE ? ((B + 3) & ~3ull) / 2 : 0);  // S (MAXM only)
+    double *scratch = Sl + (MAXM ? ((B + 1) & ~1ull) : 0);
     double *s_mH = scratch + 128;
     double *s_tot = s_mH + maxn;  // member row totals and their correctly rounded reciprocals
     double *s_rt = s_tot + maxn;
@@ -665,8 +678,14 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     st.thr = ctl->thr;
     st.band = ctl->band;
     st.wscale = ctl->wscale;
-    st.n_windows = st.n_events = st.n_accepts = 0;
+    st.n_windows = st.n_events = st.n_accepts = st.n_loo = 0;
+    st.max_size = MAXM ? ctl->max_size : st.n;
+    st.stat = ctl->stat;
+    st.mean_d = ctl->mean_delta;
+    st.std_d = ctl->std_delta;
+    st.cov_d = ctl->cov_delta;
     if (ctl->status != SEL_RUN || ctl->ev_kind != 0 || st.n > maxn || st.n < 2) return;
+    if (MAXM && st.n < st.max_size && (ctl->s_is_resum == 0 || st.n + 2 > maxn)) return;  // (multi-launch kernels)
     for (uint32_t r = tid; r < st.n; r += P_THREADS) {
         const uint64_t mp = d.mPos[d.ord[r]];
         const double t = double(d.totals[mp]);
@@ -684,6 +703,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             const double v = d.S[i] - low[i];
             sl[i] = v;
             if (COARSE) slf[i] = coarse_sl(v, rn0);
+            if (MAXM) Sl[i] = d.S[i];
         }
     }
     __syncthreads();
@@ -694,6 +714,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     uint32_t arb_stage = 0;
     uint64_t arb_pos = 0;
     uint32_t pend_kind = 0;  // ev_kind left pending for the multi-launch kernels (finalize tie)
+    bool bail = false;       // leave with the state as it stands and status RUN (MAXM: an undecidable push)
     const uint64_t wpb = P_THREADS / 64;
     const uint32_t nwg = G > 1 ? G - 1 : 1;           // scanning workgroups
     const uint64_t nwaves = uint64_t(nwg) * wpb;      // scanning waves
@@ -708,14 +729,17 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     // whole new set (r == n).  K is a power of two so that, with the candidate's frequencies in
     // registers (fr[c], chunk c = bins c * 512 + tid), a thread's job bins are its own.
     const uint32_t nchunk = uint32_t((B + P_THREADS - 1) / P_THREADS);
-    uint32_t K = 1;
-    {
-        const uint32_t kmax = (st.n + 1 < G) ? (G - 1) / (st.n + 1) : 1u;
+    uint32_t K = 1, jobs = 0;
+    bool one_job = false, has_job = false;
+    auto set_geometry = [&](uint32_t members) {  // (again after every kept push: MAXM sets grow)
+        K = 1;
+        const uint32_t kmax = (members + 1 < G) ? (G - 1) / (members + 1) : 1u;
         while (K * 2 <= kmax && K * 2 <= nchunk && K * 2 <= 32u) K *= 2;
-    }
-    const uint32_t jobs = (st.n + 1) * K;
-    const bool one_job = jobs <= G - 1;  // at most one job per workgroup, none for the mirror block
-    const bool has_job = one_job ? (blockIdx.x < jobs) : true;
+        jobs = (members + 1) * K;
+        one_job = jobs <= G - 1;  // at most one job per workgroup, none for the mirror block
+        has_job = one_job ? (blockIdx.x < jobs) : true;
+    };
+    set_geometry(st.n);
 
 #ifdef DVS_PERSIST_STAMPS  // per-phase in-kernel timing (DVS_PERSIST_DEBUG prints it): costs registers
     unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
@@ -919,8 +943,208 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             break;
         }
         P_STAMP(2);
+        if constexpr (MAXM) {
+            if (st.n < st.max_size) {
+                // ================= tentative push (records.rs:427-451): clone + push, keep iff the stat rose
+                const uint32_t n = st.n, n1 = n + 1;
+                if (n1 + 1 > maxn) {  // the LDS replica holds no more members: the multi-launch kernels go on
+                    bail = true;
+                    st.n_windows--;
+                    break;
+                }
+                const uint32_t slot_t = st.n_loo % 3;
+                st.n_loo++;
+                const double sumH_t = st.sumH + cand_H;
+                uint32_t K1 = 1;
+                {
+                    const uint32_t kmax = (n1 + 1 < G) ? (G - 1) / (n1 + 1) : 1u;
+                    while (K1 * 2 <= kmax && K1 * 2 <= nchunk && K1 * 2 <= 32u) K1 *= 2;
+                }
+                const uint32_t jobs1 = (n1 + 1) * K1;
+                const bool one1 = jobs1 <= G - 1;
+                __syncthreads();  // every thread has read the member arrays of the resolve phase
+                if (tid == 0) {   // the candidate as member n (harmless beyond the set if rolled back)
+                    s_slot[n] = n;
+                    s_mH[n] = cand_H;
+                    s_pos[n] = p;
+                    s_tot[n] = tot;
+                    s_rt[n] = rtot;
+                }
+                __syncthreads();
+                if (lead) {  // the accumulators of the next round (eight replicas), as in the replace path
+                    unsigned long long *nx = part + uint64_t((slot_t + 1) % 3) * 8 * (maxn + 1) * 2;
+                    const uint32_t ne = (n1 + 2 <= maxn + 1 ? n1 + 2 : maxn + 1) * 2u;
+                    for (uint32_t i = tid; i < 8u * ne; i += P_THREADS)
+                        __hip_atomic_store(nx + (uint64_t(i / ne) * (maxn + 1)) * 2 + i % ne, 0ull, RLX_AGENT);
+                }
+                unsigned long long *accw = part + uint64_t(slot_t) * 8 * (maxn + 1) * 2;
+                const unsigned long long *accr = accw + uint64_t(blockIdx.x & 7u) * (maxn + 1) * 2;
+                const double rn1 = 1.0 / double(n1), rdiv1 = 1.0 / double(n);
+                bool first1 = true;
+                for (uint32_t job = blockIdx.x; job < jobs1; job += G) {
+                    if (lead && one1) break;
+                    const uint32_t r = job / K1, part_i = job % K1;
+                    const T *mrow = mat + (r < n ? s_pos[r] : 0) * B;
+                    const double mtot = r < n ? s_tot[r] : 1.0, mrt = r < n ? s_rt[r] : 1.0;
+                    double h = 0.0, sv = 0.0;
+#pragma unroll
+                    for (int j = 0; j < P_J; j++) {
+                        const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                        if ((uint32_t(j) & (K1 - 1)) == part_i && i < B) {
+                            const double f = fr[j];
+                            const double stv = Sl[i] + f;  // S of the bigger set
+                            double u;
+                            if (r == n1) {
+                                u = stv * rn1;
+                            } else {
+                                const double fm = r == n ? f : count_freq_x(mrow[i], mtot, mrt);
+                                u = (stv - fm) * rdiv1;  // updated_mean_freqs, records.rs:276-286
+                                if (u <= DVS_EPS) u = 0.0;
+                            }
+                            if (u > 0.0) h -= u * log2_acc(u);
+                            sv += u;
+                        }
+                    }
+                    h = dvs_wave_sum_dpp(h);
+                    sv = dvs_wave_sum_dpp(sv);
+                    if (!first1) __syncthreads();
+                    first1 = false;
+                    if (lane == 0) {
+                        scratch[64 + wave] = h;
+                        scratch[80 + wave] = sv;
+                    }
+                    __syncthreads();
+                    if (tid < 8) {
+                        double th = 0.0, ts = 0.0;
+                        for (uint32_t w = 0; w < P_THREADS / 64; w++) {
+                            th += scratch[64 + w];
+                            ts += scratch[80 + w];
+                        }
+                        unsigned long long *dst = accw + (uint64_t(tid) * (maxn + 1) + r) * 2;
+                        atomicAdd(dst, p_acc_word(th));
+                        atomicAdd(dst + 1, p_acc_word(ts));
+                    }
+                }
+                if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
+                for (uint32_t r = tid; r <= n1; r += P_THREADS) {
+                    const double h = p_acc_value(__hip_atomic_load(accr + uint64_t(r) * 2, RLX_AGENT));
+                    const double sv = p_acc_value(__hip_atomic_load(accr + uint64_t(r) * 2 + 1, RLX_AGENT));
+                    if (r == n1) {
+                        scratch[110] = h;
+                        scratch[111] = sv;
+                    } else {
+                        s_dl[r] = h - (sumH_t - s_mH[r]) * rdiv1;  // JSD of the bigger set without member r
+                        s_ds[r] = sv;
+                    }
+                }
+                __syncthreads();
+                const double hm = scratch[110];
+                const double tj = hm - sumH_t * rn1;
+                const bool evr = sum_risky(scratch[111], B) || !(hm == hm);
+                for (uint32_t r = tid; r < n1; r += P_THREADS) s_dl[r] = tj - s_dl[r];  // delta_jsd
+                __syncthreads();
+                if (wave == 0) p_argmin<(maxn + 63) / 64>(s_dl, s_ds, n1, B, lane, scratch);
+                __syncthreads();
+                const double dmin1 = scratch[100], dsec1 = scratch[102], mean1 = scratch[103], sd1 = scratch[104];
+                const uint32_t low1 = uint32_t(scratch[101]);
+                const bool anyr = scratch[105] != 0.0;
+                const double band1 = sel_band(tj + sumH_t * rn1, B);
+                const double cov1 = sd1 / mean1;
+                const double a = st.stat == DVS_STAT_STDEV ? sd1 : cov1;
+                const double b = st.stat == DVS_STAT_STDEV ? st.std_d : st.cov_d;
+                // every delta_jsd carries an error <= band, so std moves by <= ~band and cov = std / mean
+                // by ~ band (1 + |cov|) / |mean| (finalize_kernel); NaN compares false
+                const double mm = fmin(fabs(mean1), fabs(st.mean_d));
+                const double sband = st.stat == DVS_STAT_STDEV
+                                         ? 4.0 * band1
+                                         : 4.0 * band1 * (1.0 + fmax(fabs(a), fabs(b))) / fmax(mm, 1e-300);
+                if (anyr || evr || (dsec1 - dmin1 <= band1 && dsec1 < 1e6) || !(fabs(a - b) > sband)) {
+                    bail = true;  // too close to call (or NaN): the event stays unconsumed
+                    st.n_windows--;
+                    st.n_events--;
+                    __syncthreads();
+                    break;
+                }
+                st.cursor = p + 1;
+                if (a > b) {  // ---- commit: the bigger set is the set
+                    st.n_accepts++;
+                    st.n = n1;
+                    st.sumH = sumH_t;
+                    st.total_jsd = tj;
+                    st.li = low1;
+                    st.band = band1;
+                    st.thr = tj + DVS_EPS;
+                    st.mean_d = mean1;
+                    st.std_d = sd1;
+                    st.cov_d = cov1;
+                    set_geometry(n1);
+                    const bool low_is_new = low1 == n;
+                    const T *lrow = mat + s_pos[low1] * B;
+                    const double ltot = s_tot[low1], lrt = s_rt[low1];
+                    const double dn1 = double(n1);
+#pragma unroll
+                    for (int j = 0; j < P_J; j++) {
+                        const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                        if (i < B) {
+                            const double f = fr[j];
+                            const double stv = Sl[i] + f;
+                            const double nv = stv - (low_is_new ? f : count_freq_x(lrow[i], ltot, lrt));
+                            Sl[i] = stv;
+                            sl[i] = nv;
+                            if (COARSE) slf[i] = coarse_sl(nv, rn1);
+                            if (lead) {
+                                d.S[i] = stv;
+                                d.M[uint64_t(n) * B + i] = f;
+                                d.base[i] = nv / dn1;
+                            }
+                        }
+                    }
+                    if (lead) {
+                        for (uint32_t r = tid; r < n1; r += P_THREADS) {
+                            d.dtmp[r] = s_dl[r];
+                            d.dsum[r] = s_ds[r];
+                            d.mDelta[r] = s_dl[r];
+                        }
+                        if (tid == 0) {
+                            d.ord[n] = n;
+                            d.mH[n] = cand_H;
+                            d.mLabel[n] = uint32_t(p);
+                            d.mPos[n] = p;
+                            if (uint32_t(p) < d.nlabels) d.inset[uint32_t(p)] = 1;
+                            d.evlog_pos[ctl->n_logged] = p;
+                            d.evlog_kind[ctl->n_logged] = 2;
+                            ctl->n_logged++;
+                            ctl->size = n1;
+                            ctl->sum_entropy = sumH_t;
+                            ctl->total_jsd = tj;
+                            ctl->lowest = low1;
+                            ctl->mean_delta = mean1;
+                            ctl->std_delta = sd1;
+                            ctl->cov_delta = cov1;
+                            ctl->band = band1;
+                            ctl->he_base = sumH_t - s_mH[low1];
+                            ctl->thr = st.thr;
+                            ctl->cursor = st.cursor;
+                            ctl->event_pos = SEL_NONE;
+                            ctl->last_jsd = jsd;
+                            ctl->ev_n = n1;
+                            ctl->ev_risky = 0;
+                        }
+                    }
+                } else if (lead && tid == 0) {  // ---- rollback: nothing changed but the cursor
+                    ctl->cursor = st.cursor;
+                    ctl->event_pos = SEL_NONE;
+                }
+                __syncthreads();  // sl / scratch are rewritten by the next window
+                if (st.cursor >= st.npos) { exit_status = SEL_DONE; break; }
+                st.window = p_next_window(st, nwg, wg_thresh, wg_scale, wgmode);
+                epoch++;
+                continue;
+            }
+        }
         // ================= replace_lowest (records.rs:94-147) + leave-one-out
-        const uint32_t acc_slot = st.n_accepts % 3;
+        const uint32_t acc_slot = st.n_loo % 3;
+        st.n_loo++;
         st.n_accepts++;
         const uint32_t n = st.n, li = st.li;
         const uint32_t slot_low = s_slot[li];
@@ -1295,6 +1519,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                         const double sn = v + f;
                         const double nv = sn - (low_is_new ? f : count_freq_x(lv[j], ltot, lrt));
                         sl[i] = nv;
+                        if (MAXM) Sl[i] = sn;
                         if (COARSE) slf[i] = coarse_sl(nv, rn);
                         if (lead) d.base[i] = nv / dn;
                     }
@@ -1333,7 +1558,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             ctl->arb_pos = arb_pos;
             if (arb_stage == ARB_RESOLVE) ctl->event_pos = arb_pos;  // resolve_kernel re-evaluates it
         }
-        ctl->status = exit_status == SEL_RUN ? SEL_ERROR : exit_status;
+        ctl->status = bail ? SEL_RUN : (exit_status == SEL_RUN ? SEL_ERROR : exit_status);
     }
 }
 
@@ -1369,7 +1594,11 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
         s->ev_used += 2;
         (void)hipEventRecord(e0, ctx->stream);
     }
-    if (d.B <= uint64_t(P_J) * P_THREADS)
+    if (s->params.mode == DVS_MODE_MAX)
+        hipLaunchKernelGGL((persist_nmost_kernel<T, true, true>), dim3(s->persist_grid), dim3(P_THREADS),
+                           s->persist_lds, ctx->stream, d, mat, static_cast<PSync *>(s->psync),
+                           static_cast<unsigned long long *>(s->ppart), s->persist_grid);
+    else if (d.B <= uint64_t(P_J) * P_THREADS)
         hipLaunchKernelGGL((persist_nmost_kernel<T, true>), dim3(s->persist_grid), dim3(P_THREADS),
                            s->persist_lds, ctx->stream, d, mat, static_cast<PSync *>(s->psync),
                            static_cast<unsigned long long *>(s->ppart), s->persist_grid);
@@ -1386,18 +1615,23 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     const uint64_t B = s->dev.B;
     s->persist = false;
     if (getenv("DVS_NO_PERSIST")) return DVS_OK;
-    if (s->params.mode != DVS_MODE_NMOST || !s->h_order.empty() || !s->h_labels.empty()) return DVS_OK;
+    const bool maxm = s->params.mode == DVS_MODE_MAX && !getenv("DVS_NO_PERSIST_MAX");
+    if ((s->params.mode != DVS_MODE_NMOST && !maxm) || !s->h_order.empty() || !s->h_labels.empty()) return DVS_OK;
     s->persist_grid = uint32_t(ctx->n_cu);  // one 512-thread workgroup per CU: all resident
     const bool cached = B <= uint64_t(P_J) * P_THREADS;
+    if (maxm && !cached) return DVS_OK;  // (the growth phase wants the candidate in registers and S in LDS)
     s->persist_maxn = p_maxn(cached);
     s->persist_maxjobs = p_maxjobs(cached);
-    if (s->cap > s->persist_maxn) return DVS_OK;
-    const size_t lds = ((B + 1) & ~1ull) * 8 + (cached && s->mat_kind == 0 ? ((B + 3) & ~3ull) * 4 : 0) + 128 * 8 +
-                       size_t(s->persist_maxn) * 52 + 8 + P_SOFT * 8 + 64;
+    // (MODE_MAX: max_size may be the whole stream; the kernel hands over when its LDS replica is full)
+    if (!maxm && s->cap > s->persist_maxn) return DVS_OK;
+    const size_t lds = ((B + 1) & ~1ull) * 8 + (cached && s->mat_kind == 0 ? ((B + 3) & ~3ull) * 4 : 0) +
+                       (maxm ? ((B + 1) & ~1ull) * 8 : 0) + 128 * 8 + size_t(s->persist_maxn) * 52 + 8 + P_SOFT * 8 + 64;
     if (lds > ctx->lds_per_block) return DVS_OK;
     s->persist_lds = lds;
     const void *fn =
-        s->mat_kind == 0
+        maxm ? (s->mat_kind == 0 ? reinterpret_cast<const void *>(persist_nmost_kernel<uint32_t, true, true>)
+                                 : reinterpret_cast<const void *>(persist_nmost_kernel<double, true, true>))
+        : s->mat_kind == 0
             ? (cached ? reinterpret_cast<const void *>(persist_nmost_kernel<uint32_t, true>)
                       : reinterpret_cast<const void *>(persist_nmost_kernel<uint32_t, false>))
             : (cached ? reinterpret_cast<const void *>(persist_nmost_kernel<double, true>)

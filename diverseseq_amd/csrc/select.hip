@@ -943,7 +943,7 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
             // not take the state it found (e.g. an event left pending by the arbiter's hand-off):
             // the multi-launch kernels, which take any state, carry on -- never a relaunch loop
             if (persist_launches && persist_was_last && c.cursor == persist_cursor) {
-                s->persist = false;
+                persist_was_last = false;  // one batch of multi-launch iterations, then the engine again
             } else {
                 persist_cursor = c.cursor;
                 persist_launches++;

@@ -443,6 +443,23 @@ def test_persistent_engine_set_sizes_and_bin_counts(ctx, k, n):
     m.close()
 
 
+@pytest.mark.parametrize("k,min_size,max_size,stat", [(6, 5, 40, "stdev"), (6, 5, 40, "cov"), (5, 3, 12, "stdev"),
+                                                      (6, 10, None, "stdev"), (4, 20, 90, "cov")])
+def test_persistent_engine_max_mode(ctx, k, min_size, max_size, stat):
+    """`dvs max` in the persistent engine: tentative pushes while the set is below max_size (kept iff
+    the stat of the members' delta_jsd rose), replace_lowest once it is full; sizes, members, member
+    order and floats against the oracle"""
+    seqs = synth_seqs(1800, 1000, seed=7 * k + min_size, ragged=True, invalid_frac=0.001)
+    mx = len(seqs) if max_size is None else max_size
+    m = ctx.build_matrix(seqs, k, 4)
+    sel = m.max_divergent(min_size, mx, stat)
+    s = _assert_selection(sel, oracle.max_divergent(seqs, min_size, mx, k, 4, stat))
+    assert s.engine == 1, "the persistent engine should have run"
+    assert s.size > min_size, "the case should exercise kept pushes"
+    sel.close()
+    m.close()
+
+
 @pytest.mark.parametrize("env", [{"DVS_PERSIST_WG_ROUNDS": "0"}, {"DVS_PERSIST_WG_ROUNDS": "100000"},
                                  {"DVS_PERSIST_NO_COARSE": "1"}, {"DVS_NO_PERSIST": "1"}])
 def test_engine_knobs_do_not_change_the_answer(ctx, env, monkeypatch):
