@@ -83,7 +83,9 @@ class Context:
 
     def build_matrix_device(self, dev_ptr: int, offsets: np.ndarray, k: int,
                             num_states: int = 4) -> "CountMatrix":
-        """sequences already resident in HBM (e.g. a torch uint8 tensor's data_ptr())"""
+        """sequences already resident in HBM (e.g. a torch uint8 tensor's data_ptr()).  The call
+        does not wait for its kernels: keep the buffer alive and unmodified until the matrix is
+        first used from the host side (a selection, counts(), ctx.sync())"""
         h = C.c_void_p()
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         self.check(self._L.dvs_matrix_build(self._h, C.c_void_p(dev_ptr), 1,
