@@ -33,6 +33,7 @@ constexpr int MASH_THREADS = 256;
 constexpr uint32_t MASH_TILE = 8192;       // windows per workgroup
 constexpr uint32_t SORT_CAP = 16384;       // candidates one workgroup sorts in LDS (64 KB)
 constexpr int MAX_K = 64;
+constexpr uint32_t MASH_PAIR_LDS = 8192;   // hashes of the shared row a pairs block stages in LDS (32 KB)
 
 struct MTile {
     uint64_t begin;  // first window START (absolute byte offset)
@@ -338,14 +339,40 @@ __global__ __launch_bounds__(256) void mash_pairs_kernel(
     const uint32_t *__restrict__ sketches, const uint32_t *__restrict__ lens, uint32_t nseq,
     uint32_t k, uint32_t s, uint32_t stride, uint32_t row_start, uint32_t row_stride, int symmetric,
     double *__restrict__ dist, uint32_t *__restrict__ zerodiv) {
+    // The block's 256 pairs share row i: its sketch is staged once in LDS (when it fits), and a
+    // thread's walk over row j takes four hashes per 16-byte load instead of one per 4-byte load.
+    extern __shared__ uint32_t s_left[];
     const uint32_t i = row_start + blockIdx.y * row_stride;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nseq || j >= i) return;
-    const uint32_t *L = sketches + uint64_t(i) * stride, *R = sketches + uint64_t(j) * stride;
-    const uint32_t nl = lens[i], nr = lens[j];
+    if (i >= nseq) return;
+    const uint32_t nl = lens[i];
+    const uint32_t *Lg = sketches + uint64_t(i) * stride;
+    const bool staged = nl <= MASH_PAIR_LDS;
+    if (staged) {
+        for (uint32_t x = threadIdx.x; x < nl; x += blockDim.x) s_left[x] = Lg[x];
+        __syncthreads();
+    }
+    if (j >= i) return;
+    const uint32_t *L = staged ? s_left : Lg;
+    const uint32_t *R = sketches + uint64_t(j) * stride;
+    const uint32_t nr = lens[j];
+    const bool vec = (stride & 3u) == 0;  // rows 16-byte aligned
     uint32_t inter = 0, uni = 0, li = 0, ri = 0;
+    uint4 rb = make_uint4(0, 0, 0, 0);
+    uint32_t rb_at = 0xFFFFFFFFu;  // block of four of R held in rb
     while (uni < s && li < nl && ri < nr) {  // distance.py:260-274
-        const uint32_t l = L[li], r = R[ri];
+        uint32_t r;
+        if (vec) {
+            if ((ri >> 2) != rb_at) {
+                rb_at = ri >> 2;
+                rb = *reinterpret_cast<const uint4 *>(R + (ri & ~3u));
+            }
+            const uint32_t q = ri & 3u;
+            r = q == 0 ? rb.x : q == 1 ? rb.y : q == 2 ? rb.z : rb.w;
+        } else {
+            r = R[ri];
+        }
+        const uint32_t l = L[li];
         li += (l <= r);
         ri += (r <= l);
         inter += (l == r);
@@ -588,7 +615,7 @@ extern "C" int dvs_mash_distances(dvs_ctx *ctx, const uint32_t *sketches, uint32
     DVS_HIP(ctx, hipMemsetAsync(d_flag.p, 0, 4, ctx->stream));
     const uint32_t nrows = (nseq - 1 - row_start) / row_stride + 1;
     const dim3 grid((nseq + 255) / 256, nrows);
-    hipLaunchKernelGGL(mash_pairs_kernel, grid, dim3(256), 0, ctx->stream, d_sk.as<uint32_t>(),
+    hipLaunchKernelGGL(mash_pairs_kernel, grid, dim3(256), MASH_PAIR_LDS * 4, ctx->stream, d_sk.as<uint32_t>(),
                        d_lens.as<uint32_t>(), nseq, k, sketch_size, s, row_start, row_stride, symmetric,
                        d_dist.as<double>(), d_flag.as<uint32_t>());
     DVS_HIP(ctx, hipGetLastError());
