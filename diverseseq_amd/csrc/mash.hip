@@ -92,12 +92,16 @@ __device__ __forceinline__ uint32_t hash_window(const uint8_t *w, uint32_t k, ui
 // LDS hash set over one tile: returns true if h was not yet present
 __device__ __forceinline__ bool tile_insert(uint32_t *tbl, uint32_t mask, uint32_t h) {
     uint32_t slot = (h * 0x9E3779B1u) & mask;
-    for (;;) {
+    // (at most one trip round the table: a full table -- more distinct in-range hashes in the tile
+    // than it has slots, which only the small table of the DNA kernel can meet -- reports "fresh";
+    // the sort stage drops duplicates anyway, the set only keeps repeats from flooding the list)
+    for (uint32_t probes = 0; probes <= mask; probes++) {
         const uint32_t old = atomicCAS(&tbl[slot], 0xFFFFFFFFu, h);
         if (old == 0xFFFFFFFFu) return true;
         if (old == h) return false;
         slot = (slot + 1) & mask;
     }
+    return true;
 }
 
 // Hashes every window of a tile; hashes h with lo < h <= hi (lo as int64, -1 = none)
@@ -185,7 +189,10 @@ __device__ __forceinline__ uint32_t mash_round_k(uint32_t h, uint32_t kk) {  // 
     return t + 0xE6546B64u;
 }
 
-template <bool K16>  // K16: k <= 16, a window fits 32 bits
+// TBLW: words of the tile's hash set.  The full 2 x MASH_TILE (64 KB) leaves room for two workgroups
+// per CU; when the hash range lets only a few windows per tile through (genomes: ~0.2 %), 2048 words
+// do and the CU holds eight workgroups, which hides the serial chain of the rounds much better.
+template <bool K16, uint32_t TBLW>  // K16: k <= 16, a window fits 32 bits
 __global__ __launch_bounds__(MASH_THREADS) void hash_filter_dna_kernel(
     const uint8_t *__restrict__ seqs, uint64_t nbytes_all, const MTile *__restrict__ tiles, uint32_t k,
     int canonical, const long long *__restrict__ lo, const uint32_t *__restrict__ hi,
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(MASH_THREADS) void hash_filter_dna_kernel(
     uint32_t *__restrict__ cand_cnt) {
     constexpr uint32_t NW = (MASH_TILE + MAX_K + 15 + 15) / 16 + 3;
     __shared__ uint2 pk[NW];  // x: 16 bases packed, y: their invalid mask
-    __shared__ uint32_t tbl[2 * MASH_TILE];
+    __shared__ uint32_t tbl[TBLW];
     __shared__ uint32_t s_max_seen;
     __shared__ uint32_t s_kk[4];
     const MTile t = tiles[blockIdx.x];
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(MASH_THREADS) void hash_filter_dna_kernel(
         const uint32_t m = (mash_inv4(v.x) << 12) | (mash_inv4(v.y) << 8) | (mash_inv4(v.z) << 4) | mash_inv4(v.w);
         pk[j] = make_uint2(p, m);
     }
-    for (uint32_t i = threadIdx.x; i < 2 * MASH_TILE; i += MASH_THREADS) tbl[i] = 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < TBLW; i += MASH_THREADS) tbl[i] = 0xFFFFFFFFu;
     if (threadIdx.x == 0) s_max_seen = 0;
     __syncthreads();
     const long long lo_q = lo[t.seq];
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(MASH_THREADS) void hash_filter_dna_kernel(
         if ((long long)h > lo_q && h <= hi_q) {
             bool fresh;
             if (h == 0xFFFFFFFFu) fresh = atomicExch(&s_max_seen, 1u) == 0u;
-            else fresh = tile_insert(tbl, 2 * MASH_TILE - 1, h);
+            else fresh = tile_insert(tbl, TBLW - 1, h);
             if (fresh) {
                 const uint32_t slot = atomicAdd(&cand_cnt[t.seq], 1u);
                 if (slot < cap) out[slot] = h;
@@ -557,18 +564,22 @@ extern "C" int dvs_mash_sketch(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_de
         DVS_HIP(ctx, hipMemcpyAsync(d_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         DVS_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, nseq * 4, ctx->stream));
         if (num_states == 4 && k <= 32 && !getenv("DVS_MASH_BYTEWISE")) {  // 2-bit packed windows
-            if (k <= 16)
-                hipLaunchKernelGGL((hash_filter_dna_kernel<true>), dim3(uint32_t(tiles.size())), dim3(MASH_THREADS),
-                                   0, ctx->stream, d_seqs, nbytes, d_tiles.as<MTile>(), k, mash_canonical,
-                                   d_lo.as<long long>(), d_hi.as<uint32_t>(), d_active.as<uint8_t>(),
-                                   d_cand.as<uint32_t>(), d_coff.as<uint64_t>(), d_cap.as<uint32_t>(),
-                                   d_cnt.as<uint32_t>());
-            else
-                hipLaunchKernelGGL((hash_filter_dna_kernel<false>), dim3(uint32_t(tiles.size())), dim3(MASH_THREADS),
-                                   0, ctx->stream, d_seqs, nbytes, d_tiles.as<MTile>(), k, mash_canonical,
-                                   d_lo.as<long long>(), d_hi.as<uint32_t>(), d_active.as<uint8_t>(),
-                                   d_cand.as<uint32_t>(), d_coff.as<uint64_t>(), d_cap.as<uint32_t>(),
-                                   d_cnt.as<uint32_t>());
+            // the small hash set when no active sequence lets more than ~512 windows of a tile through
+            bool small = !getenv("DVS_MASH_BIG_TABLE");
+            for (uint32_t q : list) {
+                const long double frac = ((long double)hi[q] - (long double)lo[q]) / 4294967296.0L;
+                if (frac * MASH_TILE > 512.0L) small = false;
+            }
+#define DVS_LAUNCH_DNA(K16, TBLW)                                                                              \
+    hipLaunchKernelGGL((hash_filter_dna_kernel<K16, TBLW>), dim3(uint32_t(tiles.size())), dim3(MASH_THREADS), 0, \
+                       ctx->stream, d_seqs, nbytes, d_tiles.as<MTile>(), k, mash_canonical, d_lo.as<long long>(), \
+                       d_hi.as<uint32_t>(), d_active.as<uint8_t>(), d_cand.as<uint32_t>(), d_coff.as<uint64_t>(), \
+                       d_cap.as<uint32_t>(), d_cnt.as<uint32_t>())
+            if (k <= 16 && small) DVS_LAUNCH_DNA(true, 2048);
+            else if (k <= 16) DVS_LAUNCH_DNA(true, 2 * MASH_TILE);
+            else if (small) DVS_LAUNCH_DNA(false, 2048);
+            else DVS_LAUNCH_DNA(false, 2 * MASH_TILE);
+#undef DVS_LAUNCH_DNA
         } else
             hipLaunchKernelGGL(hash_filter_kernel, dim3(uint32_t(tiles.size())), dim3(MASH_THREADS), 0,
                                ctx->stream, d_seqs, d_tiles.as<MTile>(), k, num_states, mash_canonical,
