@@ -1364,21 +1364,28 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         uint32_t lowest;
         double dmin, dsecond;
         bool any_risky, ev_risky;
-        if (n < 64) {
-            // No barrier: one wave polls this group's replica (lane r = member r, lane n = the whole
-            // set) until every word carries K contributions, takes the decisions and hands them to
-            // the other waves through LDS.  Bounded like every other spin of the kernel.
+        if (n < 128) {
+            // No barrier: one wave polls this group's replica (lane l holds members l and l + 64, entry
+            // n is the whole set) until every word carries K contributions, takes the decisions and
+            // hands them to the other waves through LDS.  Bounded like every other spin of the kernel.
             if (wave == 0) {
-                const bool valid = lane <= n;
-                unsigned long long wh = 0, ws = 0;
+                const uint32_t r0 = lane, r1 = lane + 64;
+                const bool valid0 = r0 <= n, valid1 = r1 <= n;
+                unsigned long long wh0 = 0, ws0 = 0, wh1 = 0, ws1 = 0;
                 uint32_t spins = 0;
                 int ok = 1;
                 for (;;) {
-                    if (valid) {
-                        wh = __hip_atomic_load(acc + uint64_t(lane) * 2, RLX_AGENT);
-                        ws = __hip_atomic_load(acc + uint64_t(lane) * 2 + 1, RLX_AGENT);
+                    if (valid0) {
+                        wh0 = __hip_atomic_load(acc + uint64_t(r0) * 2, RLX_AGENT);
+                        ws0 = __hip_atomic_load(acc + uint64_t(r0) * 2 + 1, RLX_AGENT);
                     }
-                    if (__ballot(valid && (p_acc_count(wh) != K || p_acc_count(ws) != K)) == 0ull) break;
+                    if (valid1) {
+                        wh1 = __hip_atomic_load(acc + uint64_t(r1) * 2, RLX_AGENT);
+                        ws1 = __hip_atomic_load(acc + uint64_t(r1) * 2 + 1, RLX_AGENT);
+                    }
+                    if (__ballot((valid0 && (p_acc_count(wh0) != K || p_acc_count(ws0) != K)) ||
+                                 (valid1 && (p_acc_count(wh1) != K || p_acc_count(ws1) != K))) == 0ull)
+                        break;
                     if ((++spins & 255u) == 0 &&
                         (spins > P_SPIN_LIMIT || __hip_atomic_load(&sync->timeout, RLX_AGENT))) {
                         __hip_atomic_store(&sync->timeout, 1u, RLX_AGENT);
@@ -1388,19 +1395,24 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     __builtin_amdgcn_s_sleep(1);
                 }
                 P_STAMP(4);
-                const double h = p_acc_value(wh), sv = p_acc_value(ws);
-                const double hm = __shfl(h, int(n), 64), svn = __shfl(sv, int(n), 64);
+                const double h0 = p_acc_value(wh0), sv0 = p_acc_value(ws0);
+                const double h1 = p_acc_value(wh1), sv1 = p_acc_value(ws1);
+                const bool whole_hi = n >= 64;  // which of a lane's two entries the whole set is
+                const double hm = __shfl(whole_hi ? h1 : h0, int(n & 63u), 64);
+                const double svn = __shfl(whole_hi ? sv1 : sv0, int(n & 63u), 64);
                 const double tj = hm - st.sumH / dn;
                 const bool evr = sum_risky(svn, B) || !(hm == hm);
-                const bool mem = lane < n;
-                const double mH = mem ? s_mH[lane] : 0.0;
-                const double dl = mem ? tj - (h - (st.sumH - mH) * rdiv) : 1e6;  // delta_jsd
+                const bool mem0 = r0 < n, mem1 = r1 < n;
+                const double mH0 = mem0 ? s_mH[r0] : 0.0, mH1 = mem1 ? s_mH[r1] : 0.0;
+                const double dl0 = mem0 ? tj - (h0 - (st.sumH - mH0) * rdiv) : 1e6;  // delta_jsd
+                const double dl1 = mem1 ? tj - (h1 - (st.sumH - mH1) * rdiv) : 1e6;
                 P_STAMP(6);
-                const double mn = dvs_wave_min(dl);
-                const unsigned long long at = __ballot(mem && dl == mn && mn < 1e6);
-                const uint32_t lw = at ? uint32_t(__builtin_ctzll(at)) : 0u;
-                const double sec = dvs_wave_min((mem && lane != lw) ? dl : 1e6);
-                const bool anyr = __ballot(mem && sum_risky(sv, B)) != 0ull;
+                const double mn = dvs_wave_min(fmin(dl0, dl1));
+                const unsigned long long at0 = __ballot(mem0 && dl0 == mn && mn < 1e6);
+                const unsigned long long at1 = __ballot(mem1 && dl1 == mn && mn < 1e6);
+                const uint32_t lw = at0 ? uint32_t(__builtin_ctzll(at0)) : at1 ? 64u + uint32_t(__builtin_ctzll(at1)) : 0u;
+                const double sec = dvs_wave_min(fmin((mem0 && r0 != lw) ? dl0 : 1e6, (mem1 && r1 != lw) ? dl1 : 1e6));
+                const bool anyr = __ballot((mem0 && sum_risky(sv0, B)) || (mem1 && sum_risky(sv1, B))) != 0ull;
                 if (lane == 0) {
                     scratch[100] = mn;
                     scratch[101] = double(lw);
@@ -1412,13 +1424,18 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 }
                 P_STAMP(7);
                 if (lead) {
-                    const double mu = dvs_wave_sum(mem ? dl : 0.0) / dn;
-                    const double t = mem ? dl - mu : 0.0;
-                    const double sd = sqrt(dvs_wave_sum(t * t) / (dn - 1.0));
-                    if (mem) {
-                        d.dtmp[lane] = dl;
-                        d.dsum[lane] = sv;
-                        d.mDelta[lane] = dl;
+                    const double mu = dvs_wave_sum((mem0 ? dl0 : 0.0) + (mem1 ? dl1 : 0.0)) / dn;
+                    const double t0 = mem0 ? dl0 - mu : 0.0, t1 = mem1 ? dl1 - mu : 0.0;
+                    const double sd = sqrt(dvs_wave_sum(t0 * t0 + t1 * t1) / (dn - 1.0));
+                    if (mem0) {
+                        d.dtmp[r0] = dl0;
+                        d.dsum[r0] = sv0;
+                        d.mDelta[r0] = dl0;
+                    }
+                    if (mem1) {
+                        d.dtmp[r1] = dl1;
+                        d.dsum[r1] = sv1;
+                        d.mDelta[r1] = dl1;
                     }
                     if (lane == 0) {
                         ctl->total_jsd = tj;
