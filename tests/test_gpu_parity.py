@@ -460,6 +460,35 @@ def test_persistent_engine_max_mode(ctx, k, min_size, max_size, stat):
     m.close()
 
 
+def test_randomised_small_selections(ctx):
+    """sixty small random problems -- short sequences (many near-ties: the arbiter and the engines'
+    hand-overs get their share), duplicates, invalid symbols, every mode -- against the oracle"""
+    rng = np.random.default_rng(20261003)
+    engines = set()
+    for case in range(60):
+        nseq = int(rng.integers(12, 400))
+        length = int(rng.integers(24, 320))
+        k = int(rng.integers(2, 7))
+        n = int(rng.integers(2, min(12, nseq - 1)))
+        seqs = synth_seqs(nseq, length, seed=1000 + case, ragged=bool(case & 1), invalid_frac=0.01 if case % 3 == 0 else 0.0)
+        if case % 5 == 0:  # a few exact duplicates in the stream
+            for _ in range(3):
+                seqs[int(rng.integers(0, nseq))] = seqs[int(rng.integers(0, nseq))].copy()
+        m = ctx.build_matrix(seqs, k, 4)
+        mode = case % 3
+        if mode == 0:
+            sel, exp = m.nmost(n), oracle.nmost(seqs, n, k, 4)
+        else:
+            stat = "stdev" if mode == 1 else "cov"
+            mx = nseq if case % 2 else min(nseq, n + int(rng.integers(0, 20)))
+            sel, exp = m.max_divergent(n, mx, stat), oracle.max_divergent(seqs, n, mx, k, 4, stat)
+        s = _assert_selection(sel, exp)
+        engines.add(s.engine)
+        sel.close()
+        m.close()
+    assert engines == {0, 1} or engines == {1}
+
+
 @pytest.mark.parametrize("env", [{"DVS_PERSIST_WG_ROUNDS": "0"}, {"DVS_PERSIST_WG_ROUNDS": "100000"},
                                  {"DVS_PERSIST_NO_COARSE": "1"}, {"DVS_NO_PERSIST": "1"}])
 def test_engine_knobs_do_not_change_the_answer(ctx, env, monkeypatch):
