@@ -8,13 +8,15 @@ infrastructure only).
 from __future__ import annotations
 
 import ctypes as C
+import os
 import pathlib
 import threading
 
 import numpy as np
 
 _HERE = pathlib.Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libdvs_hip.so"
+# DVS_HIP_LIB: another build of the same library (csrc/Makefile's host-sanitizer `asan` target)
+LIB_PATH = pathlib.Path(os.environ["DVS_HIP_LIB"]).resolve() if os.environ.get("DVS_HIP_LIB") else _HERE / "libdvs_hip.so"
 
 OK, ERR_VALUE, ERR_RUNTIME, ERR_NOMEM, ERR_UNSUPPORTED, ERR_ZERODIV = range(6)
 MODE_NMOST, MODE_MAX, MODE_SET = 0, 1, 2

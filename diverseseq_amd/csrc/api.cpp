@@ -150,7 +150,19 @@ int dvs_ctx_create(int device, void *stream, dvs_ctx **out) {
 }
 
 void dvs_ctx_destroy(dvs_ctx *ctx) {
-    if (!ctx) return;
+    if (!ctx || ctx->owner_gone) return;
+    ctx->owner_gone = true;
+    dvs_ctx_release(ctx);
+}
+
+}  // extern "C"
+
+void dvs_ctx_retain(dvs_ctx *ctx) {
+    if (ctx) ctx->refs++;
+}
+
+void dvs_ctx_release(dvs_ctx *ctx) {
+    if (!ctx || --ctx->refs > 0) return;
     (void)hipSetDevice(ctx->device);
     dvs_dev_free(ctx, ctx->d_clog_tbl);
     dvs_dev_trim(ctx);
@@ -159,6 +171,8 @@ void dvs_ctx_destroy(dvs_ctx *ctx) {
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
+
+extern "C" {
 
 const char *dvs_last_error(const dvs_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -204,6 +218,7 @@ static int matrix_alloc(dvs_ctx *ctx, dvs_matrix *m) {
                              (unsigned long long)m->nbins, bytes, free_b);
     const size_t nr = m->nrows ? m->nrows : 1;
     m->ctx = ctx;
+    dvs_ctx_retain(ctx);
     int rc;
     if (m->kind == 0) rc = dvs_dev_alloc(ctx, (void **)&m->d_counts, bytes ? bytes : 4, "matrix counts");
     else rc = dvs_dev_alloc(ctx, (void **)&m->d_freqs, bytes ? bytes : 8, "matrix freqs");

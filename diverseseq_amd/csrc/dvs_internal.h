@@ -32,7 +32,14 @@ struct dvs_ctx {
     std::vector<hipEvent_t> event_pool;    // recycled HIP events
     std::map<void *, size_t> live;
     size_t pool_bytes = 0;
+    // one reference for the owner (dropped by dvs_ctx_destroy) and one per matrix, selection and
+    // sequence batch made from this context: their destroy functions hand blocks back to the caches
+    // above, so the context outlives them whatever order the caller tears things down in
+    int refs = 1;
+    bool owner_gone = false;
 };
+void dvs_ctx_retain(dvs_ctx *ctx);
+void dvs_ctx_release(dvs_ctx *ctx);
 
 // waits for a build that is still in flight (no-op otherwise) and moves the head totals to the vector
 struct dvs_matrix;

@@ -259,6 +259,7 @@ struct dvs_seqbatch {
 extern "C" void dvs_seqbatch_destroy(dvs_seqbatch *b) {
     if (!b) return;
     if (b->d_codes) dvs_dev_free(b->ctx, b->d_codes);
+    dvs_ctx_release(b->ctx);
     delete b;
 }
 
@@ -287,6 +288,7 @@ extern "C" int dvs_seqbatch_from_fasta(dvs_ctx *ctx, const uint8_t *raw, int raw
     const uint8_t gap = lut[(unsigned char)'-'];
     dvs_seqbatch *b = new dvs_seqbatch;
     b->ctx = ctx;
+    dvs_ctx_retain(ctx);
     const uint64_t nb = (nbytes + ING_BLOCK - 1) / ING_BLOCK;
     uint8_t *d_raw = nullptr, *d_lut = nullptr;
     Agg *d_agg = nullptr;

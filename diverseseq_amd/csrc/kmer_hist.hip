@@ -333,6 +333,8 @@ void dvs_matrix_free_fields(dvs_matrix *m) {
     m->d_freqs = nullptr;
     m->d_totals = nullptr;
     m->d_entropy = nullptr;
+    dvs_ctx_release(m->ctx);  // (taken in matrix_alloc; every path deletes the matrix right after this)
+    m->ctx = nullptr;
 }
 
 // Launches the histogram build for sequences already in HBM (d_seqs, nbytes

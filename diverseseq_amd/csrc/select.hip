@@ -824,6 +824,7 @@ static void sel_free(dvs_select *s) {
     dvs_dev_free(s->ctx, s->psync);
     dvs_dev_free(s->ctx, s->ppart);
     dvs_select_arbiter_free(s);
+    dvs_ctx_release(s->ctx);
     delete s;
 }
 
@@ -1019,6 +1020,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
                                      (unsigned long long)p);
     dvs_select *s = new dvs_select();
     s->ctx = ctx;
+    dvs_ctx_retain(ctx);
     s->params = *params;
     s->params.n_seed = n_seed;
     s->params.max_size = max_size;
@@ -1039,7 +1041,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     size_t free_b = 0, total_b = 0;
     if (need > (size_t(1) << 30)) DVS_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
     if (need > (size_t(1) << 30) && need > free_b + ctx->pool_bytes) {
-        delete s;
+        sel_free(s);
         return dvs_set_error(ctx, DVS_ERR_NOMEM, "selection state needs %zu bytes, %zu free", need,
                              free_b);
     }

@@ -46,6 +46,10 @@ int dvs_abi_version(void);
 /* device < 0: current device.  stream: a hipStream_t to launch on, or NULL for
  * a stream owned by the ctx. */
 int dvs_ctx_create(int device, void *stream, dvs_ctx **out);
+/* Drops the caller's reference.  Matrices, selections and sequence batches made from ctx hold
+ * one each, so they may be destroyed after it, in any order (a garbage-collected host language
+ * gives none); the caches and the stream go when the last reference does.  ctx itself must not
+ * be passed to another call afterwards. */
 void dvs_ctx_destroy(dvs_ctx *ctx);
 /* message of the last failing call on ctx (ctx == NULL: last ctx_create failure) */
 const char *dvs_last_error(const dvs_ctx *ctx);

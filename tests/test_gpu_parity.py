@@ -489,6 +489,45 @@ def test_randomised_small_selections(ctx):
     assert engines == {0, 1} or engines == {1}
 
 
+def test_sum_to_one_panic_is_the_references(ctx):
+    """k = 1 (tolerance 4 eps): after a few dozen pushes the running mean no longer sums to one
+    within the reference's check (record.rs:99-104) and `dvs max` panics there -- so must this
+    path, with the same message (case 212 of scripts/micro/stress_selections.py, seed 7)"""
+    seqs = synth_seqs(169, 67, seed=251128967)
+    with pytest.raises(oracle.OraclePanic) as exp:
+        oracle.max_divergent(seqs, 40, 78, 1, 4, "cov")
+    m = ctx.build_matrix(seqs, 1, 4)
+    with pytest.raises(ValueError) as got:
+        m.max_divergent(40, 78, "cov")
+    assert str(got.value) == str(exp.value)
+    assert "cannot calculate entropy as frequency vector total" in str(got.value)
+    m.close()
+
+
+def test_context_may_be_closed_before_its_objects():
+    """matrices, selections and sequence batches hold a reference on their context: closing the
+    context first (what interpreter shutdown may do to objects in a cycle) leaves them usable
+    and their own close() safe (include/dvs_hip.h, dvs_ctx_destroy)"""
+    from diverseseq_amd import engine
+
+    own = engine.Context()
+    seqs = synth_seqs(300, 400, seed=5)
+    exp = oracle.nmost(seqs, 5, 4, 4)
+    m = own.build_matrix(seqs, 4, 4)
+    sel = m.nmost(5)
+    batch = own.encode_fasta(b">a\nACGT\n>b\nGGTA\n")
+    own.close()
+    sel.close()
+    m.close()
+    batch.close()
+    # and a fresh context works afterwards
+    c2 = engine.Context()
+    m2 = c2.build_matrix(seqs, 4, 4)
+    sel2 = m2.nmost(5)
+    _assert_selection(sel2, exp)
+    sel2.close(); m2.close(); c2.close()
+
+
 @pytest.mark.parametrize("env", [{"DVS_PERSIST_WG_ROUNDS": "0"}, {"DVS_PERSIST_WG_ROUNDS": "100000"},
                                  {"DVS_PERSIST_NO_COARSE": "1"}, {"DVS_NO_PERSIST": "1"}])
 def test_engine_knobs_do_not_change_the_answer(ctx, env, monkeypatch):
