@@ -29,6 +29,40 @@ def concat(seqs) -> tuple[np.ndarray, np.ndarray]:
     return np.ascontiguousarray(data), offsets
 
 
+_GB_DROP = bytes(range(48, 58)) + b" \t\r\n"
+
+
+def genbank_to_fasta(raw: bytes) -> bytes:
+    """LOCUS name + the ORIGIN..// block of every record of a GenBank flat file, re-framed as FASTA
+    records (position numbers and blanks removed); the format the reference reaches through
+    cogent3's get_format_parser(path, "genbank") (diverse_seq/io.py:94-96).  A record without an
+    ORIGIN block becomes an empty record."""
+    out, pos = [], 0
+    while True:
+        loc = 0 if raw.startswith(b"LOCUS", pos) and pos == 0 else raw.find(b"\nLOCUS", pos)
+        if loc < 0:
+            break
+        if raw[loc:loc + 1] == b"\n":
+            loc += 1
+        eol = raw.find(b"\n", loc)
+        eol = len(raw) if eol < 0 else eol
+        toks = raw[loc:eol].split()
+        name = toks[1] if len(toks) > 1 else b""
+        end = raw.find(b"\n//", eol)
+        end = len(raw) if end < 0 else end
+        org = raw.find(b"\nORIGIN", eol, end)
+        seq = b""
+        if org >= 0:
+            first = raw.find(b"\n", org + 1, end)
+            if first >= 0:
+                seq = raw[first + 1:end].translate(None, _GB_DROP)
+        out.append(b">" + name + b"\n" + seq + b"\n")
+        pos = end + 1
+        if pos >= len(raw):
+            break
+    return b"".join(out)
+
+
 class Context:
     """one per process per GPU (dvs_ctx)"""
 
@@ -114,6 +148,12 @@ class Context:
                                                        host.size, _lib.ptr(lut, C.c_uint8), int(join_records),
                                                        C.byref(h)))
         return SeqBatch(self, h, host)
+
+    def encode_genbank(self, raw: bytes, join_records: bool = False, moltype: str = "dna") -> "SeqBatch":
+        """GenBank flat file -> index-coded sequences in HBM.  The host only re-frames the file
+        (`genbank_to_fasta`: byte searches and one `translate` per record, no per-base Python);
+        coding, line joining and the per-record offsets are the device ingest's, as for FASTA."""
+        return self.encode_fasta(genbank_to_fasta(bytes(raw)), join_records=join_records, moltype=moltype)
 
     def matrix_from_freqs(self, freqs: np.ndarray) -> "CountMatrix":
         f = np.ascontiguousarray(freqs, dtype=np.float64)

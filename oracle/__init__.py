@@ -449,3 +449,33 @@ def load_fasta(raw: bytes, join_records: bool = False, moltype: str = "dna"):
     if join_records:
         return [lab for lab, _ in recs], ([str2arr("-".join(s for _, s in recs), moltype)] if recs else [])
     return [lab for lab, _ in recs], [str2arr(s, moltype) for _, s in recs]
+
+
+def parse_genbank(raw: bytes):
+    """records of a GenBank flat file as (locus name, sequence text): the name is the second
+    token of the LOCUS line, the sequence is every letter of the lines between ORIGIN and // (the
+    position numbers and blanks dropped) -- what a GenBank parser hands diverse_seq/io.py:94-96
+    through cogent3's get_format_parser(path, "genbank"); a record without ORIGIN has no sequence"""
+    records, name, parts, in_seq = [], None, [], False
+    for line in raw.split(b"\n"):
+        line = line.rstrip(b"\r")
+        if line.startswith(b"LOCUS"):
+            toks = line.split()
+            name, parts, in_seq = (toks[1].decode("utf8", "replace") if len(toks) > 1 else ""), [], False
+        elif line.startswith(b"ORIGIN"):
+            in_seq = True
+        elif line.startswith(b"//"):
+            if name is not None:
+                records.append((name, "".join(parts)))
+            name, parts, in_seq = None, [], False
+        elif in_seq:
+            parts.append("".join(chr(ch) for ch in line if chr(ch).isalpha() or chr(ch) in "-?"))
+    return records
+
+
+def load_genbank(raw: bytes, join_records: bool = False, moltype: str = "dna"):
+    """as load_fasta, for GenBank files (letters are upper-cased first: the alphabet is upper case)"""
+    recs = [(lab, seq.upper()) for lab, seq in parse_genbank(raw)]
+    if join_records:
+        return [lab for lab, _ in recs], ([str2arr("-".join(s for _, s in recs), moltype)] if recs else [])
+    return [lab for lab, _ in recs], [str2arr(s, moltype) for _, s in recs]

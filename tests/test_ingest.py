@@ -39,6 +39,60 @@ def test_parse_brca1_records():
     assert len(joined) == 1 and joined[0].size == 55 * 3009 + 54
 
 
+GENBANK = b"""LOCUS       SCU49845     5028 bp    DNA             PLN       21-JUN-1999
+DEFINITION  Saccharomyces cerevisiae TCP1-beta gene.
+FEATURES             Location/Qualifiers
+     source          1..5028
+                     /organism="Saccharomyces cerevisiae"
+ORIGIN
+        1 gatcctccat atacaacggt atctccacct caggtttaga tctcaacaac ggaaccattg
+       61 ccgacatgag acagttaggt atcgtcgaga gttacaagct aaaacgagca gtagtcagct
+      121 ctgcatctga agccgctgaa gttctactaa gggtggataa catcatccgt gcaagaccaa
+//
+LOCUS       NOSEQ        10 bp    DNA
+DEFINITION  a record without a sequence block.
+//
+LOCUS       SECOND       12 bp    DNA
+ORIGIN
+        1 acgtnnacgt ry
+//
+"""
+
+
+def _random_genbank(rng, nrec):
+    out = bytearray()
+    for r in range(nrec):
+        length = int(rng.integers(0, 2000))
+        seq = bytes(rng.choice(np.frombuffer(b"acgtnry", dtype=np.uint8), size=length, p=[.24, .24, .24, .24, .02, .01, .01]))
+        out += b"LOCUS       REC%d  %d bp    DNA\nDEFINITION  LOCUS ORIGIN // in the text.\nFEATURES   x\n" % (r, length)
+        if r % 4 != 3:
+            out += b"ORIGIN\n"
+            for i in range(0, length, 60):
+                out += b"%9d" % (i + 1)
+                for j in range(i, min(i + 60, length), 10):
+                    out += b" " + seq[j:j + 10]
+                out += b"\n"
+        out += b"//\n"
+    return bytes(out)
+
+
+def test_genbank_reframing_matches_the_line_parser():
+    """the product's byte-search reframing (engine.genbank_to_fasta) against the oracle's
+    line-by-line GenBank reader, on a hand-made file and random ones (CRLF too)"""
+    from diverseseq_amd.engine import genbank_to_fasta
+
+    recs = oracle.parse_genbank(GENBANK)
+    assert [(lab, len(seq)) for lab, seq in recs] == [("SCU49845", 180), ("NOSEQ", 0), ("SECOND", 12)]
+    assert recs[2][1] == "acgtnnacgtry"
+    rng = np.random.default_rng(5)
+    for raw in [GENBANK, GENBANK.replace(b"\n", b"\r\n"), b"", b"no records here\n"] + \
+               [_random_genbank(rng, int(rng.integers(1, 12))) for _ in range(8)]:
+        assert oracle.parse_fasta(genbank_to_fasta(raw)) == oracle.parse_genbank(raw)
+    labels, seqs = oracle.load_genbank(GENBANK)
+    assert labels == ["SCU49845", "NOSEQ", "SECOND"] and seqs[2].tolist()[:4] == [2, 1, 3, 0]
+    assert seqs[2][4] > 3 and seqs[1].size == 0
+
+
 # ------------------------------------------------------------------ device vs oracle
 def _random_fasta(rng, nrec, crlf=False, junk_front=False, trailing_newline=True):
     out = bytearray()
@@ -129,3 +183,21 @@ def test_matrix_from_device_ingest_equals_matrix_from_host_sequences(ctx):
     assert sel.members(with_freqs=False).positions.tolist() == exp.members()[0].tolist()
     m.close()
     b.close()
+
+
+@pytest.mark.gpu
+def test_device_ingest_of_genbank_files(ctx):
+    rng = np.random.default_rng(9)
+    for raw in (GENBANK, _random_genbank(rng, 9)):
+        labels, seqs = oracle.load_genbank(raw)
+        b = ctx.encode_genbank(raw)
+        assert b.labels == labels
+        got = b.sequences()
+        assert len(got) == len(seqs)
+        for g, e in zip(got, seqs):
+            assert np.array_equal(g, e)
+        joined = ctx.encode_genbank(raw, join_records=True)
+        exp = oracle.load_genbank(raw, join_records=True)[1]
+        assert np.array_equal(joined.sequences()[0], exp[0])
+        b.close()
+        joined.close()
