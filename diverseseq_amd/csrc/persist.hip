@@ -1526,6 +1526,10 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                         if (!low_is_new) lv[j] = lrow[i];
                     }
                 }
+#ifdef DVS_PERSIST_STAMPS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                P_STAMP(8);
+#endif
 #pragma unroll
                 for (int j = 0; j < P_J; j++) {
                     const uint64_t i = b0 + uint64_t(j) * P_THREADS + tid;

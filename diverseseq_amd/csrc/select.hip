@@ -907,7 +907,7 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
             unsigned long long dbg[32];
             if (hipMemcpy(dbg, static_cast<char *>(s->psync) + dvs_persist_dbg_offset(), sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
                 for (int w = 0; w < 2; w++)
-                    fprintf(stderr, "[dvs persist %s] us: scan %.1f bar1 %.1f resolve %.1f loo %.1f bar2 %.1f | partials %.1f combine %.1f argmin %.1f rebuild %.1f\n",
+                    fprintf(stderr, "[dvs persist %s] us: scan %.1f bar1 %.1f resolve %.1f loo %.1f bar2 %.1f | partials %.1f combine %.1f lowest-row fetch %.1f rebuild %.1f\n",
                             w ? "mirror block" : "block 0", dbg[0 + 16 * w] / 100.0, dbg[1 + 16 * w] / 100.0,
                             dbg[2 + 16 * w] / 100.0, dbg[3 + 16 * w] / 100.0, dbg[4 + 16 * w] / 100.0,
                             dbg[6 + 16 * w] / 100.0, dbg[7 + 16 * w] / 100.0, dbg[8 + 16 * w] / 100.0,
