@@ -12,8 +12,9 @@ constexpr uint32_t SPIN_LIMIT = 1u << 22;
 struct Line { uint32_t v; uint32_t pad[63]; };
 struct Sync {
     Line count, gen, timeout;
-    Line gcount[8], ggen[8];
+    Line gcount[32], ggen[32];
     Line flags[4];  // 256 words
+    Line gdone[8];  // replica r: word g = generation group g has completed
 };
 
 template <bool FENCED>
@@ -59,13 +60,13 @@ __device__ bool bar_flat(Sync *s, uint32_t G, uint32_t target) {
     return ok;
 }
 // V1: 8 group counters (blockIdx % 8 ~ XCD), a top counter, one generation word per group
-template <bool FENCED>
+template <bool FENCED, uint32_t NG = 8>
 __device__ bool bar_hier(Sync *s, uint32_t G, uint32_t target) {
     pre<FENCED>();
     bool ok = true;
     if (threadIdx.x == 0) {
-        const uint32_t x = blockIdx.x & 7u, ng = G < 8 ? G : 8;
-        const uint32_t gsz = (G - x + 7) >> 3;
+        const uint32_t x = blockIdx.x & (NG - 1), ng = G < NG ? G : NG;
+        const uint32_t gsz = (G - x + NG - 1) / NG;
         bool released = false;
         if (__hip_atomic_fetch_add(&s->gcount[x].v, 1u, RLX) == gsz * target - 1) {
             if (__hip_atomic_fetch_add(&s->count.v, 1u, RLX) == ng * target - 1) {
@@ -77,6 +78,37 @@ __device__ bool bar_hier(Sync *s, uint32_t G, uint32_t target) {
     }
     post<FENCED>();
     return ok;
+}
+// V7: group counters only; the last arrival of a group publishes the group's generation in every
+// replica line, wave 0's lanes 0..7 poll the eight words of their group's replica (3 hops, not 4)
+template <bool FENCED>
+__device__ bool bar_groups(Sync *s, uint32_t G, uint32_t target) {
+    pre<FENCED>();
+    __shared__ int s_ok2;
+    if (threadIdx.x < 64) {
+        const uint32_t x = blockIdx.x & 7u, ng = G < 8 ? G : 8;
+        const uint32_t gsz = (G - x + 7) >> 3;
+        uint32_t last = 0;
+        if (threadIdx.x == 0) last = __hip_atomic_fetch_add(&s->gcount[x].v, 1u, RLX) == gsz * target - 1;
+        last = __shfl(last, 0, 64);
+        if (last && threadIdx.x < ng) __hip_atomic_store(&s->gdone[threadIdx.x].v + x, target, RLX);
+        bool ok = true;
+        uint32_t spins = 0;
+        const uint32_t *mine = &s->gdone[x].v;
+        for (;;) {
+            const bool done = threadIdx.x >= ng || __hip_atomic_load(mine + threadIdx.x, RLX) >= target;
+            if (__all(done)) break;
+            if ((++spins & 255u) == 0 && (spins > SPIN_LIMIT || __hip_atomic_load(&s->timeout.v, RLX))) {
+                __hip_atomic_store(&s->timeout.v, 1u, RLX);
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (threadIdx.x == 0) s_ok2 = ok;
+    }
+    post<FENCED>();
+    return s_ok2;
 }
 // V2: one flag word per workgroup (plain stores, no atomics); wave 0 of every workgroup polls all flags
 template <bool FENCED>
@@ -146,6 +178,10 @@ __global__ __launch_bounds__(512) void kern(Sync *s, uint32_t iters, unsigned lo
         bool ok;
         if (V == 0) ok = bar_flat<FENCED>(s, G, it);
         else if (V == 1) ok = bar_hier<FENCED>(s, G, it);
+        else if (V == 7) ok = bar_groups<FENCED>(s, G, it);
+        else if (V == 4) ok = bar_hier<FENCED, 4>(s, G, it);
+        else if (V == 5) ok = bar_hier<FENCED, 16>(s, G, it);
+        else if (V == 6) ok = bar_hier<FENCED, 32>(s, G, it);
         else if (V == 2) ok = bar_flags<FENCED>(s, G, it);
         else ok = bar_flags_master<FENCED>(s, G, it);
         if (!ok) break;
@@ -179,6 +215,10 @@ int main() {
     for (int G : {256, 64}) {
         run<0, false>("flat unfenced", d, dt, sink, G);
         run<1, false>("hier unfenced", d, dt, sink, G);
+        run<7, false>("group words, 3 hops, unfenced", d, dt, sink, G);
+        run<4, false>("hier unfenced, 4 groups", d, dt, sink, G);
+        run<5, false>("hier unfenced, 16 groups", d, dt, sink, G);
+        run<6, false>("hier unfenced, 32 groups", d, dt, sink, G);
         run<2, false>("flags all-poll unfenced", d, dt, sink, G);
         run<3, false>("flags master unfenced", d, dt, sink, G);
         run<0, true>("flat fenced", d, dt, sink, G);
