@@ -157,6 +157,15 @@ void dvs_ctx_destroy(dvs_ctx *ctx) {
 
 }  // extern "C"
 
+int dvs_raise_dyn_lds(dvs_ctx *ctx, const void *fn, size_t bytes) {
+    if (bytes <= 48 * 1024) return DVS_OK;
+    size_t &have = ctx->lds_raised[fn];
+    if (have >= bytes) return DVS_OK;
+    DVS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+    have = bytes;
+    return DVS_OK;
+}
+
 void dvs_ctx_retain(dvs_ctx *ctx) {
     if (ctx) ctx->refs++;
 }

@@ -37,7 +37,10 @@ struct dvs_ctx {
     // above, so the context outlives them whatever order the caller tears things down in
     int refs = 1;
     bool owner_gone = false;
+    std::map<const void *, size_t> lds_raised;  // kernels whose dynamic-LDS limit was raised, and to what
 };
+// hipFuncAttributeMaxDynamicSharedMemorySize >= bytes for kernel fn on this context's device
+int dvs_raise_dyn_lds(dvs_ctx *ctx, const void *fn, size_t bytes);
 void dvs_ctx_retain(dvs_ctx *ctx);
 void dvs_ctx_release(dvs_ctx *ctx);
 

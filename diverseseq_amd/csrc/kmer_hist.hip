@@ -293,13 +293,7 @@ __global__ void freq_totals_kernel(uint32_t *__restrict__ totals, const double *
 
 template <typename K>
 int set_dyn_lds(dvs_ctx *ctx, K kernel, size_t bytes) {
-    static std::map<const void *, size_t> set_lds;
-    const void *fn = reinterpret_cast<const void *>(kernel);
-    if (bytes > 48 * 1024 && set_lds[fn] < bytes) {
-        DVS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
-        set_lds[fn] = bytes;
-    }
-    return DVS_OK;
+    return dvs_raise_dyn_lds(ctx, reinterpret_cast<const void *>(kernel), bytes);
 }
 
 }  // namespace

@@ -548,8 +548,10 @@ extern "C" int dvs_mash_sketch(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_de
     for (uint32_t q = 0; q < nseq; q++)
         if (nwin[q] == 0) active[q] = 0;  // L < k: empty sketch (distance.rs:102-104)
     const size_t sort_lds = SORT_CAP * 4;
-    DVS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(sort_select_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(sort_lds)));
+    {
+        const int lrc = dvs_raise_dyn_lds(ctx, reinterpret_cast<const void *>(sort_select_kernel), sort_lds);
+        if (lrc) return lrc;
+    }
 
     for (int round = 0;; round++) {
         std::vector<uint32_t> list;

@@ -1657,12 +1657,9 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
                       : reinterpret_cast<const void *>(persist_nmost_kernel<uint32_t, false>))
             : (cached ? reinterpret_cast<const void *>(persist_nmost_kernel<double, true>)
                       : reinterpret_cast<const void *>(persist_nmost_kernel<double, false>));
-    static std::map<const void *, size_t> set_lds;
-    if (lds > 48 * 1024 && set_lds[fn] < lds) {
-        DVS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        set_lds[fn] = lds;
-    }
-    int rc = dvs_dev_alloc(ctx, &s->psync, sizeof(PSync), "persistent sync block");
+    int rc = dvs_raise_dyn_lds(ctx, fn, lds);
+    if (rc) return rc;
+    rc = dvs_dev_alloc(ctx, &s->psync, sizeof(PSync), "persistent sync block");
     if (!rc) rc = dvs_dev_alloc(ctx, &s->ppart, p_acc_bytes(s->persist_maxn), "leave-one-out accumulators");
     if (rc) return rc;
     s->persist = true;

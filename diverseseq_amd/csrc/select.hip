@@ -1019,6 +1019,15 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
                                      "seed position %llu is not local: the first n rows must be replicated",
                                      (unsigned long long)p);
     dvs_select *s = new dvs_select();
+    // (a failing HIP call after this point releases the half-built selection)
+#define SEL_HIP(call)                                    \
+    do {                                                 \
+        hipError_t e__ = (call);                         \
+        if (e__ != hipSuccess) {                         \
+            sel_free(s);                                 \
+            return dvs_hip_fail(ctx, e__, #call);        \
+        }                                                \
+    } while (0)
     s->ctx = ctx;
     dvs_ctx_retain(ctx);
     s->params = *params;
@@ -1039,7 +1048,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     s->cap = cap;
     const size_t need = size_t(cap) * B * 8 + 5 * B * 8 + size_t(npos) * 8 + nlabels + (1 << 20);
     size_t free_b = 0, total_b = 0;
-    if (need > (size_t(1) << 30)) DVS_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+    if (need > (size_t(1) << 30)) SEL_HIP(hipMemGetInfo(&free_b, &total_b));
     if (need > (size_t(1) << 30) && need > free_b + ctx->pool_bytes) {
         sel_free(s);
         return dvs_set_error(ctx, DVS_ERR_NOMEM, "selection state needs %zu bytes, %zu free", need,
@@ -1065,11 +1074,10 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
                                : reinterpret_cast<const void *>(scan_kernel<uint32_t, false>))
                 : (s->scan_hot ? reinterpret_cast<const void *>(scan_kernel<double, true>)
                                : reinterpret_cast<const void *>(scan_kernel<double, false>));
-        static std::map<const void *, size_t> set_lds;  // attribute already raised to this size
-        if (set_lds[fn] < s->scan_lds) {
-            DVS_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             int(s->scan_lds)));
-            set_lds[fn] = s->scan_lds;
+        const int lrc = dvs_raise_dyn_lds(ctx, fn, s->scan_lds);
+        if (lrc) {
+            sel_free(s);
+            return lrc;
         }
     }
 
@@ -1100,17 +1108,17 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     SEL_ALLOC(d.evlog_kind, size_t(npos - n_seed + 2) * 4);
     if (order) {
         SEL_ALLOC(d.order, size_t(npos) * 4);
-        DVS_HIP(ctx, hipMemcpyAsync((void *)d.order, order, size_t(npos) * 4, hipMemcpyHostToDevice,
+        SEL_HIP(hipMemcpyAsync((void *)d.order, order, size_t(npos) * 4, hipMemcpyHostToDevice,
                                     ctx->stream));
     }
     if (labels) {
         SEL_ALLOC(d.labels, size_t(npos) * 4);
-        DVS_HIP(ctx, hipMemcpyAsync((void *)d.labels, labels, size_t(npos) * 4,
+        SEL_HIP(hipMemcpyAsync((void *)d.labels, labels, size_t(npos) * 4,
                                     hipMemcpyHostToDevice, ctx->stream));
     }
 #undef SEL_ALLOC
-    DVS_HIP(ctx, hipMemsetAsync(d.inset, 0, std::max<size_t>(nlabels, 1), ctx->stream));
-    DVS_HIP(ctx, hipMemsetAsync(d.wg_rows, 0, size_t(s->scan_grid) * 8, ctx->stream));
+    SEL_HIP(hipMemsetAsync(d.inset, 0, std::max<size_t>(nlabels, 1), ctx->stream));
+    SEL_HIP(hipMemsetAsync(d.wg_rows, 0, size_t(s->scan_grid) * 8, ctx->stream));
     static_assert(sizeof(SelCtl) <= 4096, "control block must fit a cached pinned block");
     {
         int prc = dvs_pinned_get(ctx, (void **)&s->h_ctl);
@@ -1184,7 +1192,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     // wc * gap^0.5..0.75 for the early stream, are all within 3 % of each other
     c.wscale = 4.0;
     if (const char *e = getenv("DVS_WINDOW_SCALE")) c.wscale = atof(e);
-    DVS_HIP(ctx, hipMemcpyAsync(d.ctl, &c, sizeof c, hipMemcpyHostToDevice, ctx->stream));
+    SEL_HIP(hipMemcpyAsync(d.ctl, &c, sizeof c, hipMemcpyHostToDevice, ctx->stream));
     s->seed_positions = seeds;
 
     int rc = (m->kind == 0) ? sel_start<uint32_t>(ctx, s, m->d_counts, seeds)
@@ -1195,6 +1203,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     }
     *out = s;
     return DVS_OK;
+#undef SEL_HIP
 }
 
 extern "C" void dvs_select_destroy(dvs_select *s) { sel_free(s); }
