@@ -1,5 +1,5 @@
 """Wide random sweep of small selections against the oracle (a one-off, GPU box only):
-    python scripts/micro/stress_selections.py SEED NCASES
+    python scripts/micro/stress_selections.py SEED NCASES [big]
 Sequence count 12..900, length 20..600, k 1..6, n 2..70, nmost / max stdev / max cov, with
 duplicates and invalid symbols.  A case passes when the ids and total_jsd agree, or when both
 sides raise the reference's panic with the same message (k = 1 sets do: record.rs:99-104)."""
@@ -22,16 +22,24 @@ def attempt(fn):
         return None, str(e)
 
 
-def main(seed: int, ncases: int) -> int:
+def main(seed: int, ncases: int, big: bool = False) -> int:
     ctx = engine.default_context()
     rng = np.random.default_rng(seed)
     bad = panics = arb = 0
     eng = {0: 0, 1: 0}
     for case in range(ncases):
-        nseq = int(rng.integers(12, 900))
-        length = int(rng.integers(20, 600))
-        k = int(rng.integers(1, 7))
-        n = int(rng.integers(2, min(70, nseq - 1)))
+        if big:  # thousands of rows, sets up to 300 members (the barrier path from 128 on), k up to 7
+            nseq = int(rng.integers(2000, 30000))
+            length = int(rng.integers(200, 3000))
+            k = int(rng.integers(4, 8))
+            n = int(rng.choice([2, 5, 10, 33, 64, 100, 127, 128, 129, 200, 300]))
+            if k == 7:
+                n = min(n, 100)  # (the oracle's leave-one-out pass costs n * 4^k log2 per event)
+        else:
+            nseq = int(rng.integers(12, 900))
+            length = int(rng.integers(20, 600))
+            k = int(rng.integers(1, 7))
+            n = int(rng.integers(2, min(70, nseq - 1)))
         seqs = synth_seqs(nseq, length, seed=int(rng.integers(0, 1 << 30)), ragged=bool(case & 1),
                           invalid_frac=0.01 if case % 3 == 0 else 0.0)
         if case % 5 == 0:
@@ -39,12 +47,16 @@ def main(seed: int, ncases: int) -> int:
                 seqs[int(rng.integers(0, nseq))] = seqs[int(rng.integers(0, nseq))].copy()
         m = ctx.build_matrix(seqs, k, 4)
         mode = case % 3
+        if big and n > 64:
+            mode = 0  # (`max` clones the set per tentative push: minutes in the oracle at this size)
+        if big:
+            print("case", case, nseq, length, k, n, mode, flush=True)
         if mode == 0:
             sel, gerr = attempt(lambda: m.nmost(n))
             exp, oerr = attempt(lambda: oracle.nmost(seqs, n, k, 4))
         else:
             stat = "stdev" if mode == 1 else "cov"
-            mx = nseq if case % 2 else min(nseq, n + int(rng.integers(0, 40)))
+            mx = nseq if (case % 2 and not big) else min(nseq, n + int(rng.integers(0, 40)))
             sel, gerr = attempt(lambda: m.max_divergent(n, mx, stat))
             exp, oerr = attempt(lambda: oracle.max_divergent(seqs, n, mx, k, 4, stat))
         if gerr is not None or oerr is not None:
@@ -74,4 +86,4 @@ def main(seed: int, ncases: int) -> int:
 
 
 if __name__ == "__main__":
-    sys.exit(main(int(sys.argv[1]), int(sys.argv[2])))
+    sys.exit(main(int(sys.argv[1]), int(sys.argv[2]), len(sys.argv) > 3 and sys.argv[3] == "big"))
