@@ -114,6 +114,26 @@ def test_counts_device_resident_input(ctx):
     assert (m.counts().astype(np.uint64) == _oracle_counts(seqs, 4, 5)).all()
 
 
+@pytest.mark.parametrize("bad_seeds", [(), (1,), (0, 3), (0, 1, 4)])
+def test_selection_behind_a_device_resident_build(ctx, bad_seeds):
+    """device-resident input (the build does not wait for its kernels; the selection picks the
+    first rows' totals up from the pinned block): seed rows without a valid k-mer -- too short,
+    all invalid -- are skipped as records.rs:299-306 does"""
+    torch = pytest.importorskip("torch")
+    seqs = synth_seqs(3000, 700, seed=77, ragged=True)
+    for i, r in enumerate(bad_seeds):
+        seqs[r] = np.full(40, 4, dtype=np.uint8) if i % 2 else seqs[r][:3].copy()
+    exp = oracle.nmost(seqs, 5, 5, 4)
+    data, offs = oracle.concat(seqs)
+    t = torch.from_numpy(np.concatenate([data, np.zeros(16, np.uint8)])).to("cuda:0")
+    torch.cuda.synchronize()
+    m = ctx.build_matrix_device(t.data_ptr(), offs, 5, 4)
+    sel = m.nmost(5)
+    _assert_selection(sel, exp)
+    sel.close()
+    m.close()
+
+
 # -------------------------------------------------------------------- selection
 def _assert_selection(sel, exp, rtol=RTOL):
     got = sel.members(with_freqs=True)
