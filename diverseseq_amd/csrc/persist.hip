@@ -656,6 +656,9 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     uint32_t *s_slot = reinterpret_cast<uint32_t *>(s_pos + maxn);
     uint64_t *s_soft = reinterpret_cast<uint64_t *>(s_slot + maxn + (maxn & 1));  // this window's listed candidates
     int *s_flag = reinterpret_cast<int *>(s_soft + P_SOFT);
+    static_assert(maxn % 4 == 0 && P_SOFT % 2 == 0, "s_ltab below must sit on a 16-byte boundary");
+    double2 *s_ltab = reinterpret_cast<double2 *>(s_soft + P_SOFT + 2);  // log2_tab's 128 entries
+    if (threadIdx.x < 128) log2_tab_fill(s_ltab, threadIdx.x);
     SelCtl *ctl = d.ctl;
     const int tid0 = threadIdx.x;
     const int tid = tid0;
@@ -852,7 +855,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     if (i < B) {
                         const double f = cand_freq_x(rp, i, tot, rtot);
                         if (CACHED) fr[j] = f;
-                        e.add((sl[i] + f) * rn);
+                        e.add((sl[i] + f) * rn, s_ltab);
                     }
                 }
             }
@@ -1001,7 +1004,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                                 u = (stv - fm) * rdiv1;  // updated_mean_freqs, records.rs:276-286
                                 if (u <= DVS_EPS) u = 0.0;
                             }
-                            if (u > 0.0) h -= u * log2_acc(u);
+                            if (u > 0.0) h -= u * log2_tab(u, s_ltab);
                             sv += u;
                         }
                     }
@@ -1286,7 +1289,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     u = (sn - (is_new ? f : fm)) * rdiv;
                     if (u <= DVS_EPS) u = 0.0;
                 }
-                if (u > 0.0) h -= u * log2_acc(u);
+                if (u > 0.0) h -= u * log2_tab(u, s_ltab);
                 sv += u;
             };
             if (CACHED) {
@@ -1646,7 +1649,8 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     // (MODE_MAX: max_size may be the whole stream; the kernel hands over when its LDS replica is full)
     if (!maxm && s->cap > s->persist_maxn) return DVS_OK;
     const size_t lds = ((B + 1) & ~1ull) * 8 + (cached && s->mat_kind == 0 ? ((B + 3) & ~3ull) * 4 : 0) +
-                       (maxm ? ((B + 1) & ~1ull) * 8 : 0) + 128 * 8 + size_t(s->persist_maxn) * 52 + 8 + P_SOFT * 8 + 64;
+                       (maxm ? ((B + 1) & ~1ull) * 8 : 0) + 128 * 8 + size_t(s->persist_maxn) * 52 + 8 + P_SOFT * 8 + 64 +
+                       128 * 16;  // (+ log2_tab's table)
     if (lds > ctx->lds_per_block) return DVS_OK;
     s->persist_lds = lds;
     const void *fn =

@@ -1288,8 +1288,11 @@ extern "C" int dvs_select_delta_jsd(dvs_ctx *ctx, const dvs_select *s, const dvs
     return DVS_OK;
 }
 
-// max |log2_acc(x) - log2(x)| / max(1, |log2 x|) over 2^17 mantissas x 80 exponents
+// max |log2_acc(x) - log2(x)| / max(1, |log2 x|), and the same of log2_tab, over 2^17 mantissas x 80 exponents
 __global__ void log2_acc_selftest_kernel(double *out) {
+    __shared__ double2 tab[128];
+    if (threadIdx.x < 128) log2_tab_fill(tab, threadIdx.x);
+    __syncthreads();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;  // 2^17 threads
     double worst = 0.0;
     for (int e = -78; e <= 1; e++) {
@@ -1300,7 +1303,8 @@ __global__ void log2_acc_selftest_kernel(double *out) {
         for (int q = 0; q < 3; q++) {
             const double ref = log2(xs[q]);
             const double err = fabs(log2_acc(xs[q]) - ref) / fmax(1.0, fabs(ref));
-            worst = fmax(worst, err);
+            const double err_t = fabs(log2_tab(xs[q], tab) - ref) / fmax(1.0, fabs(ref));
+            worst = fmax(worst, fmax(err, err_t));
         }
     }
     for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o, 64));

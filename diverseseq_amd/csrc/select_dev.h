@@ -37,10 +37,41 @@ __device__ __forceinline__ double log2_acc(double x) {
     return fma(lm, 2.8853900817779268, double(e));  // 2 / ln 2
 }
 
+// The same number by table: the mantissa m in [0.5, 1) is split by its top seven fraction bits,
+// m = c_i (1 + r) with c_i the middle of interval i (|r| <= 2^-8), so that
+//   log2 x = e + log2 c_i + log(1 + r) / ln 2,   log(1 + r) = r - r^2/2 + ... + r^7/7  (r^8/8 < 7e-21).
+// tab[i] = (log2 c_i, 1 / c_i): 128 entries, 2 KB of LDS, filled by log2_tab_fill.  No division and
+// about half the instructions of log2_acc; the same ~1 ulp of the result (the rounding of
+// e + log2 c_i dominates both), measured side by side by dvs_selftest_log2_acc.
+__device__ __forceinline__ void log2_tab_fill(double2 *tab, int i) {  // one thread per entry, i < 128
+    const double c = 0.5 + (double(i) + 0.5) / 256.0;
+    tab[i] = make_double2(log2_acc(c), 1.0 / c);
+}
+__device__ __forceinline__ double log2_tab(double x, const double2 *tab) {
+    const double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+    const int e = __builtin_amdgcn_frexp_exp(x);
+    const uint32_t i = (uint32_t(__double2hiint(m)) >> 13) & 127u;
+    const double2 t = tab[i];
+    const double r = fma(m, t.y, -1.0);
+    double p = 1.0 / 7.0;
+    p = fma(p, r, -1.0 / 6.0);
+    p = fma(p, r, 1.0 / 5.0);
+    p = fma(p, r, -1.0 / 4.0);
+    p = fma(p, r, 1.0 / 3.0);
+    p = fma(p, r, -1.0 / 2.0);
+    p = fma(p, r, 1.0);
+    return fma(p * r, 1.4426950408889634, double(e) + t.x);  // 1 / ln 2
+}
+
 struct Ent {
     double h = 0.0, sum = 0.0, mn = 0.0;
     __device__ __forceinline__ void add(double x) {
         if (x > 0.0) h -= x * log2_acc(x);
+        sum += x;
+        mn = fmin(mn, x);
+    }
+    __device__ __forceinline__ void add(double x, const double2 *tab) {  // the same through log2_tab
+        if (x > 0.0) h -= x * log2_tab(x, tab);
         sum += x;
         mn = fmin(mn, x);
     }
