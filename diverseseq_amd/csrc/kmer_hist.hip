@@ -79,9 +79,12 @@ __device__ __forceinline__ uint32_t inv16(uint4 v) {
     return (inv4(v.x) << 12) | (inv4(v.y) << 8) | (inv4(v.z) << 4) | inv4(v.w);
 }
 
-template <bool LDS_HIST>
+// PK16: two 16-bit counters to a word (a tile holds at most TILE_LEN = 32768 windows, so the low
+// half never carries into the high one): half the LDS, twice the workgroups a CU can hold
+template <bool LDS_HIST, bool PK16 = false>
 __device__ __forceinline__ void bump(uint32_t *hist, uint32_t idx) {
-    atomicAdd(&hist[idx], 1u);  // ds_add_u32 / global_atomic_add, no return
+    if (PK16) atomicAdd(&hist[idx >> 1], (idx & 1u) ? 0x10000u : 1u);
+    else atomicAdd(&hist[idx], 1u);  // ds_add_u32 / global_atomic_add, no return
 }
 
 __device__ __forceinline__ double clog2c(uint32_t c, const double *tbl) {
@@ -93,7 +96,10 @@ __device__ __forceinline__ double clog2c(uint32_t c, const double *tbl) {
 // LDS: [hist B u32 (LDS_HIST)] [tbl 256 f64] [scratch 32 f64]
 // tiles == NULL: workgroup b owns sequence b outright (its tile comes from the
 // offsets; sequences needing more than one tile are left to the tile-list launch).
-template <bool NS4, bool LDS_HIST>
+// PK16 (whole sequences only, 128 threads, 4 | B): the LDS histogram is packed (see bump) and the
+// flush emulates the 256-thread partition of the bins -- thread t stands for threads t and t + 128
+// -- so that the row entropy has the same bits as from the unpacked kernel.
+template <bool NS4, bool LDS_HIST, bool PK16 = false>
 __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
     const uint8_t *__restrict__ seqs, uint64_t nbytes, const uint64_t *__restrict__ offsets,
     const KTile *__restrict__ tiles, uint32_t *__restrict__ counts, uint32_t *__restrict__ totals,
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
     }
     uint32_t *row = counts + uint64_t(t.row) * B;
     uint32_t *hist = LDS_HIST ? reinterpret_cast<uint32_t *>(smem) : row;
-    double *tbl = reinterpret_cast<double *>(smem + (LDS_HIST ? ((B * 4 + 15) & ~15ull) : 0));
+    double *tbl = reinterpret_cast<double *>(smem + (LDS_HIST ? ((B * (PK16 ? 2 : 4) + 15) & ~15ull) : 0));
     double *scratch = tbl + CLOG_TBL;
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
@@ -125,12 +131,13 @@ __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
     if (LDS_HIST) {
         if ((B & 3) == 0) {
             uint4 *h4 = reinterpret_cast<uint4 *>(hist);
-            for (uint64_t i = tid; i < B / 4; i += nthreads) h4[i] = make_uint4(0, 0, 0, 0);
+            for (uint64_t i = tid; i < B / (PK16 ? 8 : 4); i += nthreads) h4[i] = make_uint4(0, 0, 0, 0);
+            if (PK16 && (B & 7) && tid == 0) reinterpret_cast<uint2 *>(hist)[B / 4 - 1] = make_uint2(0, 0);
         } else {
             for (uint64_t i = tid; i < B; i += nthreads) hist[i] = 0;
         }
     }
-    if (tid < CLOG_TBL) tbl[tid] = clog_tbl[tid];  // c log2 c, c < 256 (clog_tbl_kernel)
+    for (int i = tid; i < CLOG_TBL; i += nthreads) tbl[i] = clog_tbl[i];  // c log2 c, c < 256 (clog_tbl_kernel)
     __syncthreads();
 
     const uint64_t abase = t.begin & ~15ull;
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const uint32_t idx = uint32_t(P >> (2 * (15 - j))) & bmask;
-                if ((ok >> (15 - j)) & 1u) bump<LDS_HIST>(hist, idx);
+                if ((ok >> (15 - j)) & 1u) bump<LDS_HIST, PK16>(hist, idx);
             }
         } else {
             const uint32_t w[8] = {prev.x, prev.y, prev.z, prev.w, cur.x, cur.y, cur.z, cur.w};
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
                 run = ok ? run + 1 : 0u;
                 if (q >= 16) {
                     const uint64_t p = A + (q - 16);
-                    if (p >= t.begin && p < t.end && run >= k) bump<LDS_HIST>(hist, idx);
+                    if (p >= t.begin && p < t.end && run >= k) bump<LDS_HIST, PK16>(hist, idx);
                 }
             }
         }
@@ -185,7 +192,41 @@ __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
     if (!LDS_HIST) __threadfence();  // this thread's global atomics on `row` have been performed
     __syncthreads();
 
-    if (t.single) {
+    if constexpr (PK16) {
+        const uint2 *h2 = reinterpret_cast<const uint2 *>(hist);  // unit u = bins 4u .. 4u + 3
+        uint4 *r4 = reinterpret_cast<uint4 *>(row);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        double sv[2] = {0.0, 0.0}, tv[2] = {0.0, 0.0};
+#pragma unroll
+        for (int half = 0; half < 2; half++)  // virtual threads tid and tid + 128 of the 256-thread flush
+            for (uint64_t u = uint64_t(tid) + 128u * half; u < B / 4; u += HIST_THREADS) {
+                const uint2 w = h2[u];
+                const uint4 v = make_uint4(w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16);
+                if (t.row < hot_rows) r4[u] = v;
+                else __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4 *>(r4 + u));
+                sv[half] += clog2c(v.x, tbl) + clog2c(v.y, tbl) + clog2c(v.z, tbl) + clog2c(v.w, tbl);
+                tv[half] += double(v.x) + double(v.y) + double(v.z) + double(v.w);
+            }
+        const int lane = tid & 63, wave = tid >> 6;  // (two real waves = virtual waves {0, 2} and {1, 3})
+        double sums[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const double a = dvs_wave_sum(q ? tv[0] : sv[0]), b = dvs_wave_sum(q ? tv[1] : sv[1]);
+            __syncthreads();
+            if (lane == 0) {
+                scratch[wave] = a;
+                scratch[wave + 2] = b;
+            }
+            __syncthreads();
+            double acc = 0.0;
+            for (int i = 0; i < 4; i++) acc += scratch[i];
+            sums[q] = acc;
+        }
+        if (tid == 0) {
+            totals[t.row] = uint32_t(sums[1]);
+            entropy[t.row] = sums[1] > 0.0 ? log2(sums[1]) - sums[0] / sums[1] : 0.0;
+        }
+    } else if (t.single) {
         double s = 0.0, tot = 0.0;
         if (tid >= HIST_THREADS) {
             // the row is flushed and reduced by the first HIST_THREADS threads only
@@ -415,9 +456,9 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
     const size_t lds = (lds_hist ? ((B * 4 + 15) & ~15ull) : 0) + (CLOG_TBL + 32) * sizeof(double);
 #define DVS_LAUNCH_HIST(NS4, LH, GRID, TILES, NTHR, HOT)                                                  \
     do {                                                                                         \
-        rc = set_dyn_lds(ctx, kmer_hist_kernel<NS4, LH>, lds);                                   \
+        rc = set_dyn_lds(ctx, kmer_hist_kernel<NS4, LH, false>, lds);                            \
         if (!rc)                                                                                 \
-            hipLaunchKernelGGL((kmer_hist_kernel<NS4, LH>), dim3(GRID), dim3(NTHR), lds,         \
+            hipLaunchKernelGGL((kmer_hist_kernel<NS4, LH, false>), dim3(GRID), dim3(NTHR), lds,  \
                                ctx->stream, d_seqs, nbytes, d_off, TILES, m->d_counts,           \
                                m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, HOT);       \
     } while (0)
@@ -434,7 +475,25 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
     // streaming stores -0.04 ms per build + selection, the hot head another -0.01 ms.
     uint32_t hot_rows = uint32_t(std::min<uint64_t>(nseq, (192ull << 20) / (B * 4)));
     if (const char *e = getenv("DVS_HIST_HOT_ROWS")) hot_rows = uint32_t(atoi(e));
-    DVS_LAUNCH_HIST_ANY(nseq, static_cast<const KTile *>(nullptr), nthreads, hot_rows);
+    // whole sequences: the packed histogram at 128 threads when the row layout allows it
+    const bool pk16 = lds_hist && (B & 3) == 0 && !getenv("DVS_HIST_NO_PK16") && !getenv("DVS_HIST_THREADS");
+    if (pk16) {
+        const size_t lds16 = ((B * 2 + 15) & ~15ull) + (CLOG_TBL + 32) * sizeof(double);
+        if (ns4) {
+            rc = set_dyn_lds(ctx, kmer_hist_kernel<true, true, true>, lds16);
+            if (!rc)
+                hipLaunchKernelGGL((kmer_hist_kernel<true, true, true>), dim3(nseq), dim3(128), lds16, ctx->stream,
+                                   d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), m->d_counts,
+                                   m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_rows);
+        } else {
+            rc = set_dyn_lds(ctx, kmer_hist_kernel<false, true, true>, lds16);
+            if (!rc)
+                hipLaunchKernelGGL((kmer_hist_kernel<false, true, true>), dim3(nseq), dim3(128), lds16, ctx->stream,
+                                   d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), m->d_counts,
+                                   m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_rows);
+        }
+    } else
+        DVS_LAUNCH_HIST_ANY(nseq, static_cast<const KTile *>(nullptr), nthreads, hot_rows);
     if (!rc && !tiles.empty()) {
         DVS_LAUNCH_HIST_ANY(uint32_t(tiles.size()), d_tiles, tile_threads, 0u);
         if (!rc)
