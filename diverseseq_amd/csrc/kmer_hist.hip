@@ -35,6 +35,7 @@ constexpr int HIST_THREADS = 256;      // threads that flush / reduce a row (fix
                                        // depend on the launch geometry)
 constexpr int HIST_MAX_THREADS = 512;  // a tile's chunks are spread over up to this many
 constexpr uint32_t TILE_LEN = 32768;  // k-mer end positions per workgroup
+static_assert(TILE_LEN < 65536, "a whole-sequence tile's counts must fit the packed 16-bit LDS counters");
 constexpr int CLOG_TBL = 256;
 
 struct KTile {

@@ -83,6 +83,18 @@ def test_counts_long_sequences_multi_tile(ctx):
     _check_matrix(ctx, seqs, 3)
 
 
+def test_counts_fullest_single_tile(ctx):
+    """the longest sequence that is still one tile (32 768 windows), as a homopolymer: one bin takes
+    every count -- the packed 16-bit LDS counters of the whole-sequence kernel must not carry (low
+    half: index 0; high half: the odd index of poly-C), nor may the neighbours change"""
+    k = 6
+    for base in (0, 1):
+        seqs = [np.full(32768 + k - 1, base, dtype=np.uint8), np.full(32768 + k, base, dtype=np.uint8),
+                np.full(40000, base, dtype=np.uint8)]
+        seqs[0][-1] = 3 - base  # one other k-mer at the end
+        _check_matrix(ctx, seqs, k)
+
+
 def test_counts_large_k_global_histogram(ctx):
     """4^k * 4 B > 64 KB: the row in L2 takes the atomics (k = 8, 9)"""
     seqs = synth_seqs(6, 5000, 21, invalid_frac=0.002)
