@@ -426,17 +426,32 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, uint32_t scan
 // seed_kernel.  One block.
 __global__ __launch_bounds__(WIDE_THREADS) void rebuild_kernel(SelDev d) {
     __shared__ double scratch[48];
+    // the member order and entropies go through LDS first: read straight from global memory every
+    // row's address (and thread 0's whole entropy sum) is a chain of dependent round trips
+    __shared__ uint32_t s_ord[WIDE_THREADS];
+    __shared__ double s_mh[WIDE_THREADS];
     SelCtl *ctl = d.ctl;
     const uint32_t n = ctl->size;
-    for (uint64_t i = threadIdx.x; i < d.B; i += WIDE_THREADS) {
-        double acc = 0.0;
-        for (uint32_t r = 0; r < n; r++) acc += d.M[uint64_t(d.ord[r]) * d.B + i];
-        d.S[i] = acc;
+    double sh = 0.0;  // (thread 0's, in member order)
+    for (uint32_t base = 0; base < n; base += WIDE_THREADS) {
+        const uint32_t cnt = n - base < WIDE_THREADS ? n - base : WIDE_THREADS;
+        __syncthreads();
+        if (threadIdx.x < cnt) {
+            const uint32_t o = d.ord[base + threadIdx.x];
+            s_ord[threadIdx.x] = o;
+            s_mh[threadIdx.x] = d.mH[o];
+        }
+        __syncthreads();
+        for (uint64_t i = threadIdx.x; i < d.B; i += WIDE_THREADS) {
+            double acc = base ? d.S[i] : 0.0;
+            for (uint32_t r = 0; r < cnt; r++) acc += d.M[uint64_t(s_ord[r]) * d.B + i];
+            d.S[i] = acc;
+        }
+        if (threadIdx.x == 0)
+            for (uint32_t r = 0; r < cnt; r++) sh += s_mh[r];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double sh = 0.0;
-        for (uint32_t r = 0; r < n; r++) sh += d.mH[d.ord[r]];
         ctl->sum_entropy = sh;
         ctl->s_is_resum = 1;
     }
