@@ -173,6 +173,9 @@ void dvs_ctx_retain(dvs_ctx *ctx) {
 void dvs_ctx_release(dvs_ctx *ctx) {
     if (!ctx || --ctx->refs > 0) return;
     (void)hipSetDevice(ctx->device);
+    dvs_dev_free(ctx, ctx->off_cache.d_off);
+    dvs_dev_free(ctx, ctx->off_cache.d_rows);
+    dvs_dev_free(ctx, ctx->off_cache.d_tiles);
     dvs_dev_free(ctx, ctx->d_clog_tbl);
     dvs_dev_trim(ctx);
     for (void *p : ctx->pinned_pool) (void)hipHostFree(p);

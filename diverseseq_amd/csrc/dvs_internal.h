@@ -38,6 +38,17 @@ struct dvs_ctx {
     int refs = 1;
     bool owner_gone = false;
     std::map<const void *, size_t> lds_raised;  // kernels whose dynamic-LDS limit was raised, and to what
+    // The offsets of the last histogram build, on both sides (kmer_hist.hip): a caller that builds
+    // again over the same sequences -- same offsets, k, byte count, compared by content -- skips the
+    // validation pass, the tile lists and their uploads (~0.1 ms of host time per 100k sequences,
+    // during which the GPU would wait for its first launch).
+    struct OffsetsCache {
+        std::vector<uint64_t> h_off;
+        uint64_t nbytes = 0;
+        uint32_t k = 0;
+        void *d_off = nullptr, *d_rows = nullptr, *d_tiles = nullptr;
+        size_t n_long = 0, n_tiles = 0;
+    } off_cache;
 };
 // hipFuncAttributeMaxDynamicSharedMemorySize >= bytes for kernel fn on this context's device
 int dvs_raise_dyn_lds(dvs_ctx *ctx, const void *fn, size_t bytes);

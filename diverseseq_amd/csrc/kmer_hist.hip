@@ -26,6 +26,7 @@
 #include "dvs_internal.h"
 
 #include <algorithm>
+#include <cstring>
 #include <cmath>
 #include <cstdlib>
 
@@ -387,60 +388,77 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
                            uint64_t nbytes, const uint64_t *offsets, bool no_wait) {
     const uint32_t nseq = m->nrows, k = m->k, ns = m->num_states;
     const uint64_t B = m->nbins;
-    std::vector<KTile> tiles;
-    std::vector<uint32_t> long_rows;
-    for (uint32_t r = 0; r < nseq; r++) {
-        const uint64_t s0 = offsets[r], s1 = offsets[r + 1];
-        if (s1 < s0 || s1 > nbytes)
-            return dvs_set_error(ctx, DVS_ERR_VALUE, "offsets[%u..%u] = %llu..%llu out of range", r,
-                                 r + 1, (unsigned long long)s0, (unsigned long long)s1);
-        if (s1 - s0 < k) continue;
-        const uint64_t first = s0 + k - 1;
-        if (s1 - first <= TILE_LEN) continue;
-        long_rows.push_back(r);
-        for (uint64_t b = first; b < s1; b += TILE_LEN) {
-            KTile t;
-            t.begin = b;
-            t.end = std::min<uint64_t>(b + TILE_LEN, s1);
-            t.seq_begin = s0;
-            t.row = r;
-            t.single = 0;
-            tiles.push_back(t);
-        }
-    }
     const bool lds_hist = B * 4 <= 64 * 1024;
     const bool ns4 = ns == 4;
-    uint64_t *d_off = nullptr;
-    uint32_t *d_rows = nullptr;
-    KTile *d_tiles = nullptr;
-    int rc = dvs_dev_alloc(ctx, (void **)&d_off, size_t(nseq + 1) * 8, "offsets");
-    if (!rc && !long_rows.empty()) rc = dvs_dev_alloc(ctx, (void **)&d_rows, long_rows.size() * 4, "row list");
-    if (!rc && !tiles.empty()) rc = dvs_dev_alloc(ctx, (void **)&d_tiles, tiles.size() * sizeof(KTile), "tile list");
-    auto cleanup = [&]() {
-        dvs_dev_free(ctx, d_off);
-        dvs_dev_free(ctx, d_rows);
-        dvs_dev_free(ctx, d_tiles);
-    };
-    if (rc) {
-        cleanup();
-        return rc;
+    dvs_ctx::OffsetsCache &oc = ctx->off_cache;
+    const bool hit = oc.d_off && oc.k == k && oc.nbytes == nbytes && oc.h_off.size() == size_t(nseq) + 1 &&
+                     std::memcmp(oc.h_off.data(), offsets, (size_t(nseq) + 1) * 8) == 0 &&
+                     !getenv("DVS_NO_OFFSETS_CACHE");
+    if (!hit) {
+        std::vector<KTile> tiles;
+        std::vector<uint32_t> long_rows;
+        for (uint32_t r = 0; r < nseq; r++) {
+            const uint64_t s0 = offsets[r], s1 = offsets[r + 1];
+            if (s1 < s0 || s1 > nbytes)
+                return dvs_set_error(ctx, DVS_ERR_VALUE, "offsets[%u..%u] = %llu..%llu out of range", r,
+                                     r + 1, (unsigned long long)s0, (unsigned long long)s1);
+            if (s1 - s0 < k) continue;
+            const uint64_t first = s0 + k - 1;
+            if (s1 - first <= TILE_LEN) continue;
+            long_rows.push_back(r);
+            for (uint64_t b = first; b < s1; b += TILE_LEN) {
+                KTile t;
+                t.begin = b;
+                t.end = std::min<uint64_t>(b + TILE_LEN, s1);
+                t.seq_begin = s0;
+                t.row = r;
+                t.single = 0;
+                tiles.push_back(t);
+            }
+        }
+        // (the previous lists go back to the block cache; stream order protects them until the
+        // kernels that read them have run)
+        dvs_dev_free(ctx, oc.d_off);
+        dvs_dev_free(ctx, oc.d_rows);
+        dvs_dev_free(ctx, oc.d_tiles);
+        oc = dvs_ctx::OffsetsCache();
+        int arc = dvs_dev_alloc(ctx, &oc.d_off, size_t(nseq + 1) * 8, "offsets");
+        if (!arc && !long_rows.empty()) arc = dvs_dev_alloc(ctx, &oc.d_rows, long_rows.size() * 4, "row list");
+        if (!arc && !tiles.empty()) arc = dvs_dev_alloc(ctx, &oc.d_tiles, tiles.size() * sizeof(KTile), "tile list");
+        hipError_t ue = hipSuccess;
+        if (!arc) ue = hipMemcpyAsync(oc.d_off, offsets, size_t(nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (!arc && ue == hipSuccess && !long_rows.empty()) {
+            ue = hipMemcpyAsync(oc.d_rows, long_rows.data(), long_rows.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+            if (ue == hipSuccess)
+                ue = hipMemcpyAsync(oc.d_tiles, tiles.data(), tiles.size() * sizeof(KTile), hipMemcpyHostToDevice,
+                                    ctx->stream);
+        }
+        if (arc || ue != hipSuccess) {
+            dvs_dev_free(ctx, oc.d_off);
+            dvs_dev_free(ctx, oc.d_rows);
+            dvs_dev_free(ctx, oc.d_tiles);
+            oc = dvs_ctx::OffsetsCache();
+            return arc ? arc : dvs_hip_fail(ctx, ue, "histogram setup");
+        }
+        oc.h_off.assign(offsets, offsets + size_t(nseq) + 1);
+        oc.nbytes = nbytes;
+        oc.k = k;
+        oc.n_long = long_rows.size();
+        oc.n_tiles = tiles.size();
     }
-    hipError_t e = hipMemcpyAsync(d_off, offsets, size_t(nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && !lds_hist)  // the rows take the atomics directly: all start at zero
+    uint64_t *d_off = static_cast<uint64_t *>(oc.d_off);
+    uint32_t *d_rows = static_cast<uint32_t *>(oc.d_rows);
+    KTile *d_tiles = static_cast<KTile *>(oc.d_tiles);
+    const size_t n_long = oc.n_long, n_tiles = oc.n_tiles;
+    auto cleanup = [&]() {};  // (the lists belong to the context's cache now)
+    int rc = DVS_OK;
+    hipError_t e = hipSuccess;
+    if (!lds_hist)  // the rows take the atomics directly: all start at zero
         e = hipMemsetAsync(m->d_counts, 0, size_t(nseq) * B * 4, ctx->stream);
-    if (e == hipSuccess && !long_rows.empty()) {
-        e = hipMemcpyAsync(d_rows, long_rows.data(), long_rows.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(KTile), hipMemcpyHostToDevice,
-                               ctx->stream);
-        if (e == hipSuccess && lds_hist)
-            hipLaunchKernelGGL(zero_rows_kernel, dim3(uint32_t(long_rows.size())), dim3(HIST_THREADS), 0,
-                               ctx->stream, m->d_counts, d_rows, B);
-    }
-    if (e != hipSuccess) {
-        cleanup();
-        return dvs_hip_fail(ctx, e, "histogram setup");
-    }
+    if (e == hipSuccess && n_long && lds_hist)
+        hipLaunchKernelGGL(zero_rows_kernel, dim3(uint32_t(n_long)), dim3(HIST_THREADS), 0, ctx->stream,
+                           m->d_counts, d_rows, B);
+    if (e != hipSuccess) return dvs_hip_fail(ctx, e, "histogram setup");
     if (!ctx->d_clog_tbl) {
         rc = dvs_dev_alloc(ctx, (void **)&ctx->d_clog_tbl, CLOG_TBL * sizeof(double), "c log2 c table");
         if (rc) {
@@ -495,10 +513,10 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
         }
     } else
         DVS_LAUNCH_HIST_ANY(nseq, static_cast<const KTile *>(nullptr), nthreads, hot_rows);
-    if (!rc && !tiles.empty()) {
-        DVS_LAUNCH_HIST_ANY(uint32_t(tiles.size()), d_tiles, tile_threads, 0u);
+    if (!rc && n_tiles) {
+        DVS_LAUNCH_HIST_ANY(uint32_t(n_tiles), d_tiles, tile_threads, 0u);
         if (!rc)
-            hipLaunchKernelGGL(row_stats_kernel, dim3(uint32_t(long_rows.size())), dim3(HIST_THREADS), 0,
+            hipLaunchKernelGGL(row_stats_kernel, dim3(uint32_t(n_long)), dim3(HIST_THREADS), 0,
                                ctx->stream, m->d_counts, d_rows, m->d_totals, m->d_entropy, B);
     }
 #undef DVS_LAUNCH_HIST_ANY

@@ -95,6 +95,16 @@ def test_counts_fullest_single_tile(ctx):
         _check_matrix(ctx, seqs, k)
 
 
+def test_counts_offsets_cache_is_compared_by_content(ctx):
+    """the context remembers the last build's offsets and tile lists; the same number of sequences
+    with other boundaries, another k, or other bytes of the same total must not reuse them"""
+    rng = np.random.default_rng(17)
+    a = [rng.integers(0, 4, size=n, dtype=np.uint8) for n in (900, 40_000, 1200, 700)]
+    b = [rng.integers(0, 4, size=n, dtype=np.uint8) for n in (40_000, 900, 700, 1200)]  # same total, other cuts
+    for seqs, k in ((a, 5), (a, 5), (b, 5), (a, 6), (b, 6), (b, 6), (a, 5)):
+        _check_matrix(ctx, seqs, k)
+
+
 def test_counts_large_k_global_histogram(ctx):
     """4^k * 4 B > 64 KB: the row in L2 takes the atomics (k = 8, 9)"""
     seqs = synth_seqs(6, 5000, 21, invalid_frac=0.002)
