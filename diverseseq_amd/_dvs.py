@@ -6,8 +6,8 @@ arithmetic runs in libdvs_hip.so (HIP kernels for gfx950) through ctypes.
 
     reference                                     here
     ---------                                     ----
-    make_zarr_store(path=None, mode="r")          in-memory store (on-disk .dvseqsz: SURVEY 8f, next)
-    get_seqids_from_store(path)                   NotImplementedError (storage engine, out of scope)
+    make_zarr_store(path=None, mode="r")          in-memory store, or an on-disk .dvseqsz directory (zarr_store.py)
+    get_seqids_from_store(path)                   ids of an on-disk .dvseqsz store
     nmost_divergent / final_nmost                 dvs_select_run MODE_NMOST
     max_divergent / final_max                     dvs_select_run MODE_MAX
     get_delta_jsd_calculator                      dvs_select_run MODE_SET + dvs_select_delta_jsd
@@ -239,7 +239,7 @@ def _result(sel: engine.Selection, ids, k: int, num_states: int) -> SummedRecord
     r.records = [(ids[int(p)], mem.kfreqs[i].tolist(), float(mem.delta_jsd[i]))
                  for i, p in enumerate(mem.positions)]
     r.stats = {n: getattr(s, n) for n in ("rows_scored", "rows_rechecked", "n_windows", "n_events",
-                                          "n_accepts", "n_arbitrated", "scan_ms", "scan_launches")}
+                                          "n_accepts", "n_arbitrated", "scan_ms", "scan_launches", "engine")}
     return r
 
 

@@ -28,7 +28,7 @@ ROW_REMOTE = 0xFFFFFFFF
 # every symbol include/dvs_hip.h declares (tests/test_boundary.py checks the .so exports them)
 EXPORTS = (
     "dvs_abi_version", "dvs_ctx_create", "dvs_ctx_destroy", "dvs_last_error", "dvs_ctx_sync",
-    "dvs_ctx_trim", "dvs_ctx_device_info", "dvs_ctx_set_timing", "dvs_matrix_build", "dvs_matrix_from_freqs", "dvs_matrix_from_device_freqs",
+    "dvs_ctx_trim", "dvs_ctx_device_info", "dvs_ctx_set_timing", "dvs_matrix_build", "dvs_matrix_from_freqs", "dvs_matrix_from_device_freqs", "dvs_matrix_get_source_rows",
     "dvs_matrix_destroy", "dvs_matrix_nrows", "dvs_matrix_nbins", "dvs_matrix_dev_counts",
     "dvs_matrix_dev_totals", "dvs_matrix_dev_entropy", "dvs_matrix_get_counts",
     "dvs_matrix_get_totals", "dvs_matrix_get_entropy", "dvs_kmer_counts", "dvs_select_run",
@@ -56,7 +56,7 @@ class SelectSummary(C.Structure):
                 ("n_windows", C.c_uint32), ("n_events", C.c_uint32),
                 ("n_accepts", C.c_uint32), ("n_arbitrated", C.c_uint32),
                 ("scan_ms", C.c_double), ("scan_launches", C.c_uint64),
-                ("engine", C.c_uint32), ("reserved", C.c_uint32)]
+                ("engine", C.c_uint32), ("rows_coarse_passed", C.c_uint32)]
 
 
 class DvsLibraryMissing(RuntimeError):
@@ -136,6 +136,7 @@ def load() -> C.CDLL:
         L.dvs_matrix_get_counts.argtypes = [vp, vp, C.c_uint32, C.c_uint32, u32p]
         L.dvs_matrix_get_totals.argtypes = [vp, vp, u32p]
         L.dvs_matrix_get_entropy.argtypes = [vp, vp, f64p]
+        L.dvs_matrix_get_source_rows.argtypes = [vp, vp, u32p]
         L.dvs_kmer_counts.argtypes = [vp, u8p, u64p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p,
                                       f64p]
         L.dvs_select_run.argtypes = [vp, vp, u32p, u32p, C.c_uint64, C.POINTER(SelectParams),

@@ -11,6 +11,7 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs, u
                            const uint64_t *offsets, bool no_wait);
 int dvs_matrix_fill_freq_entropy(dvs_ctx *ctx, dvs_matrix *m);
 int dvs_matrix_fill_freq_totals(dvs_ctx *ctx, dvs_matrix *m, const double *d_meta);
+int dvs_matrix_fill_compacted(dvs_ctx *ctx, dvs_matrix *m, const double *d_in, const double *d_meta);
 
 static std::string g_create_err;
 
@@ -279,9 +280,15 @@ int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, cons
             delete m;
             return rc;
         }
-        (void)hipMemsetAsync(d_tmp + (nbytes & ~15ull), 0xFF, padded - (nbytes & ~15ull), ctx->stream);
-        if (nbytes)
-            (void)hipMemcpyAsync(d_tmp, seqs, nbytes, hipMemcpyHostToDevice, ctx->stream);
+        hipError_t ue = hipMemsetAsync(d_tmp + (nbytes & ~15ull), 0xFF, padded - (nbytes & ~15ull), ctx->stream);
+        if (ue == hipSuccess && nbytes) ue = hipMemcpyAsync(d_tmp, seqs, nbytes, hipMemcpyHostToDevice, ctx->stream);
+        if (ue != hipSuccess) {  // a failed upload must not become a silently wrong matrix
+            (void)hipStreamSynchronize(ctx->stream);
+            dvs_dev_free(ctx, d_tmp);
+            dvs_matrix_free_fields(m);
+            delete m;
+            return dvs_hip_fail(ctx, ue, "sequence upload");
+        }
         d_seqs = d_tmp;
         readable = padded;
     } else if (reinterpret_cast<uintptr_t>(seqs) & 15) {
@@ -370,11 +377,16 @@ int dvs_matrix_from_device_freqs(dvs_ctx *ctx, const double *d_freqs, const doub
     m->nbins = nbins;
     m->device = ctx->device;
     int rc = matrix_alloc(ctx, m);
-    if (!rc && nrows) {
+    if (!rc && nrows && d_meta) {
+        // flagged rows: real ones first (in input order), padding behind them, in one copy pass
+        rc = dvs_dev_alloc(ctx, (void **)&m->d_src_row, size_t(nrows) * 4, "source rows");
+        if (!rc) rc = dvs_matrix_fill_compacted(ctx, m, d_freqs, d_meta);
+        if (!rc) rc = dvs_matrix_fill_freq_entropy(ctx, m);
+    } else if (!rc && nrows) {
         hipError_t e = hipMemcpyAsync(m->d_freqs, d_freqs, size_t(nrows) * nbins * 8, hipMemcpyDeviceToDevice,
                                       ctx->stream);
         if (e != hipSuccess) rc = dvs_hip_fail(ctx, e, "hipMemcpyAsync(freqs)");
-        if (!rc) rc = dvs_matrix_fill_freq_totals(ctx, m, d_meta);
+        if (!rc) rc = dvs_matrix_fill_freq_totals(ctx, m, nullptr);
         if (!rc) rc = dvs_matrix_fill_freq_entropy(ctx, m);
     }
     if (rc) {
@@ -383,6 +395,17 @@ int dvs_matrix_from_device_freqs(dvs_ctx *ctx, const double *d_freqs, const doub
         return rc;
     }
     *out = m;
+    return DVS_OK;
+}
+
+int dvs_matrix_get_source_rows(dvs_ctx *ctx, const dvs_matrix *m, uint32_t *out) {
+    if (!ctx || !m || !out) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (!m->d_src_row) {
+        for (uint32_t r = 0; r < m->nrows; r++) out[r] = r;
+        return DVS_OK;
+    }
+    DVS_HIP(ctx, hipMemcpyAsync(out, m->d_src_row, size_t(m->nrows) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return DVS_OK;
 }
 

@@ -44,6 +44,10 @@ struct dvs_ctx {
     // during which the GPU would wait for its first launch).
     struct OffsetsCache {
         std::vector<uint64_t> h_off;
+        // host sources of the uploads below: pageable memory an async copy may still read after the
+        // call returned, so they live as long as the cache entry
+        std::vector<uint32_t> h_long_rows;
+        std::vector<unsigned char> h_tiles;
         uint64_t nbytes = 0;
         uint32_t k = 0;
         void *d_off = nullptr, *d_rows = nullptr, *d_tiles = nullptr;
@@ -85,6 +89,7 @@ struct dvs_matrix {
     double *d_freqs = nullptr;     // kind 1
     uint32_t *d_totals = nullptr;  // valid k-mers per row (kind 1: 1 for every row)
     double *d_entropy = nullptr;   // H(row freq vector), bits
+    uint32_t *d_src_row = nullptr; // kind 1 built from flagged device rows: row r came from input row d_src_row[r]
     // totals of the first rows as the builder left them (copied in the build's own stream sync):
     // the selectors need their seeds' totals on the host and would otherwise pay a round trip
     std::vector<uint32_t> h_head_totals;

@@ -327,6 +327,37 @@ __global__ __launch_bounds__(HIST_THREADS) void freq_entropy_kernel(
     if (threadIdx.x == 0) entropy[blockIdx.x] = h;
 }
 
+// Rows flagged by meta[2 r + 1] (0: padding) -> the matrix, real rows first in their input order,
+// padding behind them (total 0: skipped like a sequence without valid k-mers), so that the first n
+// positions of the merge stream are the first n REAL records of the concatenated results
+// (get_kmerseqs_and_init_summed_records, records.rs:344-360).  src[dest] = input row.
+__global__ __launch_bounds__(HIST_THREADS) void compact_freq_rows_kernel(
+    const double *__restrict__ in, const double *__restrict__ meta, double *__restrict__ out,
+    uint32_t *__restrict__ totals, uint32_t *__restrict__ src, uint32_t nrows, uint64_t B) {
+    __shared__ uint32_t s_cnt[2];
+    const uint32_t r = blockIdx.x;
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t before = 0, all = 0;  // real rows in front of r / in total
+    for (uint32_t q = threadIdx.x; q < nrows; q += HIST_THREADS) {
+        const uint32_t v = meta[2 * q + 1] != 0.0 ? 1u : 0u;
+        all += v;
+        if (q < r) before += v;
+    }
+    atomicAdd(&s_cnt[0], before);
+    atomicAdd(&s_cnt[1], all);
+    __syncthreads();
+    const bool real = meta[2 * r + 1] != 0.0;
+    const uint32_t dest = real ? s_cnt[0] : s_cnt[1] + (r - s_cnt[0]);
+    const double *a = in + uint64_t(r) * B;
+    double *o = out + uint64_t(dest) * B;
+    for (uint64_t i = threadIdx.x; i < B; i += HIST_THREADS) o[i] = a[i];
+    if (threadIdx.x == 0) {
+        totals[dest] = real ? 1u : 0u;
+        src[dest] = r;
+    }
+}
+
 // totals of a frequency-row matrix: 1, or 0 for a padding row (meta[2 r + 1] == 0)
 __global__ void freq_totals_kernel(uint32_t *__restrict__ totals, const double *__restrict__ meta,
                                    uint32_t nrows) {
@@ -372,6 +403,8 @@ void dvs_matrix_free_fields(dvs_matrix *m) {
     dvs_dev_free(m->ctx, m->d_freqs);
     dvs_dev_free(m->ctx, m->d_totals);
     dvs_dev_free(m->ctx, m->d_entropy);
+    dvs_dev_free(m->ctx, m->d_src_row);
+    m->d_src_row = nullptr;
     m->d_counts = nullptr;
     m->d_freqs = nullptr;
     m->d_totals = nullptr;
@@ -426,11 +459,16 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
         if (!arc && !long_rows.empty()) arc = dvs_dev_alloc(ctx, &oc.d_rows, long_rows.size() * 4, "row list");
         if (!arc && !tiles.empty()) arc = dvs_dev_alloc(ctx, &oc.d_tiles, tiles.size() * sizeof(KTile), "tile list");
         hipError_t ue = hipSuccess;
-        if (!arc) ue = hipMemcpyAsync(oc.d_off, offsets, size_t(nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        // (every upload reads from the cache entry's own copies, which outlive the call)
+        oc.h_off.assign(offsets, offsets + size_t(nseq) + 1);
+        oc.h_tiles.assign(reinterpret_cast<const unsigned char *>(tiles.data()),
+                          reinterpret_cast<const unsigned char *>(tiles.data()) + tiles.size() * sizeof(KTile));
+        oc.h_long_rows = long_rows;
+        if (!arc) ue = hipMemcpyAsync(oc.d_off, oc.h_off.data(), size_t(nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
         if (!arc && ue == hipSuccess && !long_rows.empty()) {
-            ue = hipMemcpyAsync(oc.d_rows, long_rows.data(), long_rows.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+            ue = hipMemcpyAsync(oc.d_rows, oc.h_long_rows.data(), long_rows.size() * 4, hipMemcpyHostToDevice, ctx->stream);
             if (ue == hipSuccess)
-                ue = hipMemcpyAsync(oc.d_tiles, tiles.data(), tiles.size() * sizeof(KTile), hipMemcpyHostToDevice,
+                ue = hipMemcpyAsync(oc.d_tiles, oc.h_tiles.data(), oc.h_tiles.size(), hipMemcpyHostToDevice,
                                     ctx->stream);
         }
         if (arc || ue != hipSuccess) {
@@ -440,7 +478,6 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
             oc = dvs_ctx::OffsetsCache();
             return arc ? arc : dvs_hip_fail(ctx, ue, "histogram setup");
         }
-        oc.h_off.assign(offsets, offsets + size_t(nseq) + 1);
         oc.nbytes = nbytes;
         oc.k = k;
         oc.n_long = long_rows.size();
@@ -561,6 +598,13 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
 int dvs_matrix_fill_freq_entropy(dvs_ctx *ctx, dvs_matrix *m) {
     hipLaunchKernelGGL(freq_entropy_kernel, dim3(m->nrows), dim3(HIST_THREADS), 0, ctx->stream,
                        m->d_freqs, m->d_entropy, m->nbins);
+    DVS_HIP(ctx, hipGetLastError());
+    return DVS_OK;
+}
+
+int dvs_matrix_fill_compacted(dvs_ctx *ctx, dvs_matrix *m, const double *d_in, const double *d_meta) {
+    hipLaunchKernelGGL(compact_freq_rows_kernel, dim3(m->nrows), dim3(HIST_THREADS), 0, ctx->stream, d_in, d_meta,
+                       m->d_freqs, m->d_totals, m->d_src_row, m->nrows, m->nbins);
     DVS_HIP(ctx, hipGetLastError());
     return DVS_OK;
 }

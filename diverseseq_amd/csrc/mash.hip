@@ -431,23 +431,38 @@ __global__ __launch_bounds__(256) void mash_pairs_kernel(
     if (symmetric) dist[uint64_t(j) * nseq + i] = d;
 }
 
-// ||f_i - f_j||_2, one workgroup per pair (i, j<i); f = counts / total
+// ||f_i - f_j||_2 (diverse_seq/distance.py:335-336), f = counts / total.  Workgroup (i, g) stages row
+// i's frequencies in LDS chunk by chunk and its eight waves take the rows j = 8 g .. 8 g + 7 below the
+// diagonal, one each: row i is read once per eight pairs, row j streamed by one wave with 16-byte loads
+// where the bin count allows.  Only the lower triangle does work; both mirror cells are written.
+constexpr int EUC_THREADS = 512;
+constexpr uint32_t EUC_CHUNK = 4096;  // bins of row i staged at a time (32 KB)
 template <typename T>
-__global__ __launch_bounds__(256) void euclid_kernel(const T *__restrict__ mat,
-                                                    const uint32_t *__restrict__ totals, uint64_t B,
-                                                    uint32_t n, double *__restrict__ dist) {
-    __shared__ double scratch[32];
-    const uint32_t i = blockIdx.y, j = blockIdx.x;
-    if (j >= i) return;
-    const T *a = mat + uint64_t(i) * B, *b = mat + uint64_t(j) * B;
-    const double ta = double(totals[i]), tb = double(totals[j]);
+__global__ __launch_bounds__(EUC_THREADS) void euclid_kernel(const T *__restrict__ mat,
+                                                            const uint32_t *__restrict__ totals, uint64_t B,
+                                                            uint32_t n, double *__restrict__ dist) {
+    __shared__ double fi[EUC_CHUNK];
+    const uint32_t i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t j = blockIdx.y * (EUC_THREADS / 64) + wave;
+    if (blockIdx.y * (EUC_THREADS / 64) >= i) return;  // the whole group is on or above the diagonal
+    const T *a = mat + uint64_t(i) * B;
+    const bool live = j < i;
+    const T *b = mat + uint64_t(live ? j : 0) * B;
+    const double ta = double(totals[i]), tb = double(totals[live ? j : 0]);
     double acc = 0.0;
-    for (uint64_t x = threadIdx.x; x < B; x += 256) {
-        const double d = double(a[x]) / ta - double(b[x]) / tb;
-        acc += d * d;
+    for (uint64_t c0 = 0; c0 < B; c0 += EUC_CHUNK) {
+        const uint32_t cn = uint32_t(B - c0 < EUC_CHUNK ? B - c0 : EUC_CHUNK);
+        __syncthreads();
+        for (uint32_t x = threadIdx.x; x < cn; x += EUC_THREADS) fi[x] = double(a[c0 + x]) / ta;
+        __syncthreads();
+        if (live)
+            for (uint32_t x = lane; x < cn; x += 64) {
+                const double d = fi[x] - double(b[c0 + x]) / tb;
+                acc += d * d;
+            }
     }
-    acc = dvs_block_sum(acc, scratch);
-    if (threadIdx.x == 0) {
+    acc = dvs_wave_sum(acc);
+    if (live && lane == 0) {
         const double d = sqrt(acc);
         dist[uint64_t(i) * n + j] = d;
         dist[uint64_t(j) * n + i] = d;
@@ -667,21 +682,33 @@ extern "C" int dvs_mash_distances(dvs_ctx *ctx, const uint32_t *sketches, uint32
 extern "C" int dvs_euclidean_distances(dvs_ctx *ctx, const dvs_matrix *m, double *dist) {
     if (!ctx || !m || !dist) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
     const uint32_t n = m->nrows;
-    for (uint64_t i = 0; i < uint64_t(n) * n; i++) dist[i] = 0.0;
-    if (n < 2) return DVS_OK;
+    if (n == 0) return DVS_OK;
+    if (n == 1) {
+        dist[0] = 0.0;
+        return DVS_OK;
+    }
+    const uint32_t groups = (n + EUC_THREADS / 64 - 1) / (EUC_THREADS / 64);
+    if (groups > 65535u)
+        return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "%u rows: the %u x %u distance matrix is beyond this path", n, n, n);
     DVS_HIP(ctx, hipSetDevice(ctx->device));
-    DevBuf d_dist;
-    DVS_HIP(ctx, hipMalloc(&d_dist.p, size_t(n) * n * 8));
-    DVS_HIP(ctx, hipMemsetAsync(d_dist.p, 0, size_t(n) * n * 8, ctx->stream));
-    const dim3 grid(n, n);
-    if (m->kind == 0)
-        hipLaunchKernelGGL((euclid_kernel<uint32_t>), grid, dim3(256), 0, ctx->stream, m->d_counts,
-                           m->d_totals, m->nbins, n, d_dist.as<double>());
-    else
-        hipLaunchKernelGGL((euclid_kernel<double>), grid, dim3(256), 0, ctx->stream, m->d_freqs,
-                           m->d_totals, m->nbins, n, d_dist.as<double>());
-    DVS_HIP(ctx, hipGetLastError());
-    DVS_HIP(ctx, hipMemcpyAsync(dist, d_dist.p, size_t(n) * n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double *d_dist = nullptr;
+    int rc = dvs_dev_alloc(ctx, (void **)&d_dist, size_t(n) * n * 8, "distance matrix");
+    if (rc) return rc;
+    hipError_t e = hipMemsetAsync(d_dist, 0, size_t(n) * n * 8, ctx->stream);  // the diagonal
+    const dim3 grid(n, groups);
+    if (e == hipSuccess) {
+        if (m->kind == 0)
+            hipLaunchKernelGGL((euclid_kernel<uint32_t>), grid, dim3(EUC_THREADS), 0, ctx->stream, m->d_counts,
+                               m->d_totals, m->nbins, n, d_dist);
+        else
+            hipLaunchKernelGGL((euclid_kernel<double>), grid, dim3(EUC_THREADS), 0, ctx->stream, m->d_freqs,
+                               m->d_totals, m->nbins, n, d_dist);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(dist, d_dist, size_t(n) * n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t se = hipStreamSynchronize(ctx->stream);
+    dvs_dev_free(ctx, d_dist);
+    if (e != hipSuccess) return dvs_hip_fail(ctx, e, "euclidean distances");
+    if (se != hipSuccess) return dvs_hip_fail(ctx, se, "euclidean distances");
     return DVS_OK;
 }

@@ -1568,7 +1568,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     if (lane == 0 && nread) {
         atomicAdd(&ctl->rows_scored, (unsigned long long)nread);
         if (nprecise) atomicAdd(&ctl->rows_rechecked, (unsigned long long)nprecise);
-        if (nmid) atomicAdd(&sync->dbg[15], (unsigned long long)nmid);  // rows the COARSE tier passed on
+        if (nmid) atomicAdd(&ctl->rows_coarse_passed, (unsigned long long)nmid);
     }
     if (lead && tid == 0) {
         ctl->cursor = st.cursor;
@@ -1593,8 +1593,9 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
 template <typename T>
 static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     const SelDev &d = s->dev;
-    PSync init;
-    memset(&init, 0, sizeof init);
+    // (the block's host image belongs to the selection: the async upload may read it after this returns)
+    s->h_psync.assign(sizeof(PSync), 0);
+    PSync &init = *reinterpret_cast<PSync *>(s->h_psync.data());
     for (int i = 0; i < 3; i++)
         for (int w = 0; w < 16; w++) init.ev[i][w * 16] = SEL_NONE;
     // a row per workgroup while a window is at most this many rounds of the grid (default policy only)
@@ -1618,19 +1619,28 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
         s->ev_used += 2;
         (void)hipEventRecord(e0, ctx->stream);
     }
-    if (s->params.mode == DVS_MODE_MAX)
-        hipLaunchKernelGGL((persist_nmost_kernel<T, true, true>), dim3(s->persist_grid), dim3(P_THREADS),
-                           s->persist_lds, ctx->stream, d, mat, static_cast<PSync *>(s->psync),
-                           static_cast<unsigned long long *>(s->ppart), s->persist_grid);
-    else if (d.B <= uint64_t(P_J) * P_THREADS)
-        hipLaunchKernelGGL((persist_nmost_kernel<T, true>), dim3(s->persist_grid), dim3(P_THREADS),
-                           s->persist_lds, ctx->stream, d, mat, static_cast<PSync *>(s->psync),
-                           static_cast<unsigned long long *>(s->ppart), s->persist_grid);
-    else
-        hipLaunchKernelGGL((persist_nmost_kernel<T, false>), dim3(s->persist_grid), dim3(P_THREADS),
-                           s->persist_lds, ctx->stream, d, mat, static_cast<PSync *>(s->psync),
-                           static_cast<unsigned long long *>(s->ppart), s->persist_grid);
+    const void *fn = s->params.mode == DVS_MODE_MAX ? reinterpret_cast<const void *>(persist_nmost_kernel<T, true, true>)
+                     : d.B <= uint64_t(P_J) * P_THREADS ? reinterpret_cast<const void *>(persist_nmost_kernel<T, true>)
+                                                        : reinterpret_cast<const void *>(persist_nmost_kernel<T, false>);
+    SelDev d_arg = d;
+    const T *mat_arg = mat;
+    PSync *sync_arg = static_cast<PSync *>(s->psync);
+    unsigned long long *part_arg = static_cast<unsigned long long *>(s->ppart);
+    uint32_t g_arg = s->persist_grid;
+    void *args[] = {&d_arg, &mat_arg, &sync_arg, &part_arg, &g_arg};
+    // The grid barrier needs every workgroup resident.  A cooperative launch makes the runtime
+    // refuse a grid the device cannot hold at once (a CU mask, a partition) instead of letting the
+    // workgroups spin into their timeout; kernels of other streams that occupy CUs for a while
+    // are what the bounded spins and the caller's fall-back to the multi-launch engine are for.
+    hipError_t le = s->persist_coop
+                        ? hipLaunchCooperativeKernel(fn, dim3(s->persist_grid), dim3(P_THREADS), args,
+                                                     uint32_t(s->persist_lds), ctx->stream)
+                        : hipLaunchKernel(fn, dim3(s->persist_grid), dim3(P_THREADS), args, s->persist_lds, ctx->stream);
     if (s->time_scan) (void)hipEventRecord(e1, ctx->stream);
+    if (le != hipSuccess) {
+        (void)hipGetLastError();
+        return DVS_ERR_UNSUPPORTED;  // (the caller falls back; no message: nothing failed for the user)
+    }
     DVS_HIP(ctx, hipGetLastError());
     return DVS_OK;
 }
@@ -1663,6 +1673,16 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
                       : reinterpret_cast<const void *>(persist_nmost_kernel<double, false>));
     int rc = dvs_raise_dyn_lds(ctx, fn, lds);
     if (rc) return rc;
+    {   // one 512-thread workgroup with this much LDS must fit a CU, or the grid can never be resident
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, P_THREADS, lds) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            return DVS_OK;
+        }
+    }
+    int coop = 0;
+    (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, ctx->device);
+    s->persist_coop = coop != 0 && !getenv("DVS_PERSIST_NO_COOP");
     rc = dvs_dev_alloc(ctx, &s->psync, sizeof(PSync), "persistent sync block");
     if (!rc) rc = dvs_dev_alloc(ctx, &s->ppart, p_acc_bytes(s->persist_maxn), "leave-one-out accumulators");
     if (rc) return rc;

@@ -17,6 +17,7 @@ struct SelCtl {
     unsigned long long event_pos;  // first position of the window whose score clears thr - band
     unsigned long long arb_pos;
     unsigned long long rows_scored, rows_rechecked;
+    unsigned long long rows_coarse_passed;  // rows the persistent engine's COARSE tier handed to the FAST tier
     uint32_t window, window_min, window_max;
     uint32_t status, arb_stage, forced, forced_lowest;
     uint32_t size, lowest, mode, max_size, stat;
@@ -76,7 +77,11 @@ struct dvs_select {
     uint32_t cap = 0;
     SelDev dev;
     SelCtl *h_ctl = nullptr;  // pinned mirror
+    SelCtl ctl0{};            // the control block of the fresh selection (sel_seed)
     std::vector<uint32_t> h_order, h_labels;
+    // labels that were all distinct: the engine runs label-free (label = stream position, the same
+    // decisions) and the caller's values are put back on the way out
+    std::vector<uint32_t> h_out_labels;
     std::vector<uint64_t> seed_positions;
     // launch geometry
     uint32_t scan_grid = 0, loo_grid = 0;
@@ -86,9 +91,12 @@ struct dvs_select {
     bool fused = false;  // resolve + leave-one-out + finalize in one launch (small sets)
     // persistent single-launch engine (persist.hip)
     bool persist = false;
+    bool persist_coop = false;       // launched with hipLaunchCooperativeKernel
+    bool persist_fell_back = false;  // the persistent kernel gave up (not co-resident): multi-launch engine from the seeds
     uint32_t persist_grid = 0, persist_maxn = 0, persist_maxjobs = 0;
     size_t persist_lds = 0;
     void *psync = nullptr;
+    std::vector<unsigned char> h_psync;  // host image of the sync block (source of its upload)
     void *ppart = nullptr;
     int batch = 16;
     // timing

@@ -891,6 +891,9 @@ static int sel_poll(dvs_ctx *ctx, dvs_select *s) {
 }
 
 template <typename T>
+static int sel_seed(dvs_ctx *ctx, dvs_select *s, const T *mat);
+
+template <typename T>
 static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_unpolled = false) {
     unsigned long long persist_cursor = 0;
     unsigned persist_launches = 0;
@@ -902,7 +905,13 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
         persist_launches = 1;
         persist_was_last = true;
         int rc0 = dvs_persist_launch(ctx, s);
-        if (rc0) return rc0;
+        if (rc0 == DVS_ERR_UNSUPPORTED) {  // the runtime refused the grid: the multi-launch engine takes over
+            s->persist = false;
+            s->persist_fell_back = true;
+            persist_launches = 0;
+        } else if (rc0) {
+            return rc0;
+        }
     }
     // the loo grid must cover the largest set a batch can reach
     for (;;) {
@@ -927,12 +936,25 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
                             dbg[2 + 16 * w] / 100.0, dbg[3 + 16 * w] / 100.0, dbg[4 + 16 * w] / 100.0,
                             dbg[6 + 16 * w] / 100.0, dbg[7 + 16 * w] / 100.0, dbg[8 + 16 * w] / 100.0,
                             dbg[5 + 16 * w] / 100.0);
-                fprintf(stderr, "[dvs persist] rows passed on by the coarse tier: %llu\n", dbg[16 + 15]);
                 if (dbg[16 + 10] + dbg[16 + 12])
                     fprintf(stderr, "[dvs persist] scan + rendezvous: row-per-workgroup windows %llu (%.1f us, %llu rows), "
                             "row-per-wave windows %llu (%.1f us, %llu rows)\n", dbg[16 + 10], dbg[16 + 9] / 100.0,
                             dbg[16 + 13], dbg[16 + 12], dbg[16 + 11] / 100.0, dbg[16 + 14]);
             }
+        }
+        const bool fake_error = getenv("DVS_PERSIST_FAKE_ERROR") != nullptr;  // (test knob)
+        if (s->persist && persist_launches && (c.status == SEL_ERROR || (fake_error && persist_launches == 1))) {
+            // The persistent kernel gave up at a grid barrier: its workgroups were not all resident
+            // (a CU mask, a partitioned device, another stream's kernels holding CUs).  The
+            // replicas may have stopped mid-update, so the selection starts over from its seeds and
+            // the multi-launch engine, which needs no co-residency, serves the request.
+            s->persist = false;
+            s->persist_fell_back = true;
+            dvs_select_arbiter_free(s);  // (its replay of the event log belongs to the abandoned run)
+            rc = sel_seed<T>(ctx, s, mat);
+            if (rc) return rc;
+            persist_launches = 0;
+            continue;
         }
         if (c.status == SEL_DONE) return DVS_OK;
         if (c.status == SEL_ARBITER) {
@@ -949,9 +971,7 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
             continue;
         }
         if (c.status == SEL_ERROR)
-            return dvs_set_error(ctx, DVS_ERR_RUNTIME,
-                                 "persistent selection kernel gave up at a grid barrier (not all "
-                                 "workgroups resident?); set DVS_NO_PERSIST=1 for the multi-launch engine");
+            return dvs_set_error(ctx, DVS_ERR_RUNTIME, "selection engine stopped with an internal error");
         if (c.status != SEL_RUN)
             return dvs_set_error(ctx, DVS_ERR_RUNTIME, "selection engine in state %u", c.status);
         if (s->persist) {
@@ -965,8 +985,14 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
                 persist_launches++;
                 persist_was_last = true;
                 rc = dvs_persist_launch(ctx, s);
-                if (rc) return rc;
-                continue;
+                if (rc == DVS_ERR_UNSUPPORTED) {
+                    s->persist = false;
+                    s->persist_fell_back = true;
+                } else if (rc) {
+                    return rc;
+                } else {
+                    continue;
+                }
             }
         }
         for (int i = 0; i < s->batch; i++) launch_iteration<T>(ctx, s, mat, 0);
@@ -975,7 +1001,32 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
 }
 
 template <typename T>
-static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat, const std::vector<uint64_t> &seeds) {
+static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat) {
+    int rc = sel_seed<T>(ctx, s, mat);
+    if (rc) return rc;
+    if (s->params.flags & DVS_SELECT_STEPWISE) return sel_poll(ctx, s);
+    return sel_run_loop<T>(ctx, s, mat, true);
+}
+
+// control block of a fresh selection + the initial set from the seed positions (SummedRecords::new
+// over the first n usable records, records.rs:288-308); also the way back to a clean state when
+// the persistent engine has to be abandoned
+template <typename T>
+static int sel_seed(dvs_ctx *ctx, dvs_select *s, const T *mat) {
+    const std::vector<uint64_t> &seeds = s->seed_positions;
+    SelDev &d = s->dev;
+    SelCtl c = s->ctl0;
+    // default window: a quarter of the persistent grid's waves (measured best: early in the
+    // stream an accept comes every few hundred rows), else 4096 rows per scan launch
+    const uint32_t wdef = s->params.window ? s->params.window : (s->persist ? s->persist_grid * 2u : 4096u);
+    c.window_min = wdef;
+    c.window_max = std::max<uint32_t>(wdef, s->scan_grid * (SCAN_THREADS / 64) * 8);
+    c.window = wdef;
+    // (the control block travels through the pinned mirror: a pageable source would have to stay
+    // alive until the copy has been performed)
+    *s->h_ctl = c;
+    DVS_HIP(ctx, hipMemsetAsync(d.inset, 0, std::max<size_t>(d.nlabels, 1), ctx->stream));
+    DVS_HIP(ctx, hipMemcpyAsync(d.ctl, s->h_ctl, sizeof c, hipMemcpyHostToDevice, ctx->stream));
     uint64_t *d_seed = nullptr;
     int rc0 = dvs_dev_alloc(ctx, (void **)&d_seed, seeds.size() * sizeof(uint64_t), "seed list");
     if (rc0) return rc0;
@@ -987,8 +1038,7 @@ static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat, const std::vecto
     launch_iteration<T>(ctx, s, mat, 2);  // loo + finalize of the initial set
     DVS_HIP(ctx, hipGetLastError());
     dvs_dev_free(ctx, d_seed);  // (back to the ctx cache: any later user is ordered behind seed_kernel on this stream)
-    if (s->params.flags & DVS_SELECT_STEPWISE) return sel_poll(ctx, s);
-    return sel_run_loop<T>(ctx, s, mat, true);
+    return DVS_OK;
 }
 
 extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t *order,
@@ -1004,6 +1054,23 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     uint32_t n_seed = params->n_seed;
     uint32_t max_size = params->max_size;
     if (params->mode == DVS_MODE_SET) n_seed = uint32_t(npos);
+    // Labels only say which positions are the same sequence id (records.rs:71-73: an id already in
+    // the set scores 0.0).  When every label occurs once -- what the reference's callers pass: the
+    // ids of a store are unique -- no position can meet its own id in the set, so the engine runs
+    // label-free (label = position: the persistent engine qualifies) and the caller's values are
+    // put back on the way out (dvs_select_get_members, dvs_select_delta_jsd).
+    const uint32_t *caller_labels = nullptr;
+    if (labels && !order && params->mode != DVS_MODE_SET && !getenv("DVS_KEEP_LABELS")) {
+        bool distinct = true;
+        std::vector<uint32_t> sorted(labels, labels + npos);
+        std::sort(sorted.begin(), sorted.end());
+        for (uint64_t p = 1; p < npos && distinct; p++)
+            distinct = sorted[p] != sorted[p - 1] || sorted[p] == 0xFFFFFFFFu;
+        if (distinct) {
+            caller_labels = labels;
+            labels = nullptr;
+        }
+    }
     // src/records.rs:323-325, 404-410, 369-371, 464-469
     if (npos < n_seed)
         return dvs_set_error(ctx, DVS_ERR_VALUE, "The number of sequences %llu is < n %u",
@@ -1054,6 +1121,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     s->npos = npos;
     s->h_order.assign(order ? order : nullptr, order ? order + npos : nullptr);
     s->h_labels.assign(labels ? labels : nullptr, labels ? labels + npos : nullptr);
+    if (caller_labels) s->h_out_labels.assign(caller_labels, caller_labels + npos);
     SelDev &d = s->dev;
     d.B = B;
     d.nlabels = nlabels;
@@ -1132,7 +1200,6 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
                                     hipMemcpyHostToDevice, ctx->stream));
     }
 #undef SEL_ALLOC
-    SEL_HIP(hipMemsetAsync(d.inset, 0, std::max<size_t>(nlabels, 1), ctx->stream));
     SEL_HIP(hipMemsetAsync(d.wg_rows, 0, size_t(s->scan_grid) * 8, ctx->stream));
     static_assert(sizeof(SelCtl) <= 4096, "control block must fit a cached pinned block");
     {
@@ -1162,15 +1229,17 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
                 return src;
             }
         }
+        hipError_t ce = hipSuccess;
         if (!order && n_seed && n_seed <= m->h_head_totals.size()) {
             std::copy(m->h_head_totals.begin(), m->h_head_totals.begin() + n_seed, h_tot.begin());  // no round trip
         } else if (!order && n_seed) {
-            (void)hipMemcpyAsync(h_tot.data(), m->d_totals, size_t(n_seed) * 4, hipMemcpyDeviceToHost, ctx->stream);
+            ce = hipMemcpyAsync(h_tot.data(), m->d_totals, size_t(n_seed) * 4, hipMemcpyDeviceToHost, ctx->stream);
         } else {
-            for (uint64_t p = 0; p < n_seed; p++)
-                (void)hipMemcpyAsync(&h_tot[p], m->d_totals + order[p], 4, hipMemcpyDeviceToHost, ctx->stream);
+            for (uint64_t p = 0; p < n_seed && ce == hipSuccess; p++)
+                ce = hipMemcpyAsync(&h_tot[p], m->d_totals + order[p], 4, hipMemcpyDeviceToHost, ctx->stream);
         }
-        if ((order || n_seed > m->h_head_totals.size()) && hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        if ((order || n_seed > m->h_head_totals.size()) &&
+            (hipStreamSynchronize(ctx->stream) != hipSuccess || ce != hipSuccess)) {
             sel_free(s);
             return dvs_set_error(ctx, DVS_ERR_RUNTIME, "reading the seed rows' totals failed");
         }
@@ -1188,14 +1257,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     c.cursor = n_seed;
     c.npos = npos;
     c.event_pos = SEL_NONE;
-    // default window: a quarter of the persistent grid's waves (measured best: early in the
-    // stream an accept comes every few hundred rows), else 4096 rows per scan launch
-    const uint32_t wdef = params->window ? params->window
-                                         : (s->persist ? s->persist_grid * 2u : 4096u);
-    c.window_min = wdef;
-    c.window_max = std::max<uint32_t>(wdef, s->scan_grid * (SCAN_THREADS / 64) * 8);
-    c.window = wdef;
-    c.status = (npos > n_seed) ? SEL_RUN : SEL_RUN;  // finalize flips to DONE when cursor >= npos
+    c.status = SEL_RUN;  // finalize flips to DONE when cursor >= npos
     c.size = uint32_t(seeds.size());
     c.mode = params->mode;
     c.max_size = max_size;
@@ -1207,11 +1269,11 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     // wc * gap^0.5..0.75 for the early stream, are all within 3 % of each other
     c.wscale = 4.0;
     if (const char *e = getenv("DVS_WINDOW_SCALE")) c.wscale = atof(e);
-    SEL_HIP(hipMemcpyAsync(d.ctl, &c, sizeof c, hipMemcpyHostToDevice, ctx->stream));
+    s->ctl0 = c;  // (sel_seed adds the window policy of the engine in charge and uploads it)
     s->seed_positions = seeds;
 
-    int rc = (m->kind == 0) ? sel_start<uint32_t>(ctx, s, m->d_counts, seeds)
-                            : sel_start<double>(ctx, s, m->d_freqs, seeds);
+    int rc = (m->kind == 0) ? sel_start<uint32_t>(ctx, s, m->d_counts)
+                            : sel_start<double>(ctx, s, m->d_freqs);
     if (rc) {
         sel_free(s);
         return rc;
@@ -1243,6 +1305,7 @@ extern "C" int dvs_select_get_summary(dvs_ctx *ctx, const dvs_select *s, dvs_sel
     out->scan_ms = s->scan_ms;
     out->scan_launches = s->scan_launches;
     out->engine = s->persist ? 1u : 0u;
+    out->rows_coarse_passed = uint32_t(std::min<unsigned long long>(c.rows_coarse_passed, 0xFFFFFFFFull));
     return DVS_OK;
 }
 
@@ -1264,7 +1327,7 @@ extern "C" int dvs_select_get_members(dvs_ctx *ctx, const dvs_select *s, uint64_
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t sl = ord[i];
         if (positions) positions[i] = pos[sl];
-        if (labels) labels[i] = lab[sl];
+        if (labels) labels[i] = s->h_out_labels.empty() ? lab[sl] : s->h_out_labels[pos[sl]];
         if (entropy) entropy[i] = mh[sl];
         if (freqs)
             DVS_HIP(ctx, hipMemcpy(freqs + uint64_t(i) * B, s->dev.M + uint64_t(sl) * B, B * 8,
@@ -1283,6 +1346,27 @@ extern "C" int dvs_select_delta_jsd(dvs_ctx *ctx, const dvs_select *s, const dvs
     DVS_HIP(ctx, hipSetDevice(ctx->device));
     double *d_out = nullptr;
     uint32_t *d_lab = nullptr;
+    std::vector<uint32_t> qtrans;
+    if (qlabels && !s->h_out_labels.empty()) {
+        // label-free engine: a query carrying a member's (caller) label gets that member's engine
+        // label (its stream position), any other query none
+        const uint32_t n = s->h_ctl->size;
+        std::vector<uint64_t> pos(s->cap);
+        std::vector<uint32_t> ord(n);
+        DVS_HIP(ctx, hipMemcpy(ord.data(), s->dev.ord, size_t(n) * 4, hipMemcpyDeviceToHost));
+        DVS_HIP(ctx, hipMemcpy(pos.data(), s->dev.mPos, size_t(s->cap) * 8, hipMemcpyDeviceToHost));
+        std::map<uint32_t, uint32_t> member_of;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint64_t p = pos[ord[i]];
+            if (s->h_out_labels[p] != 0xFFFFFFFFu) member_of[s->h_out_labels[p]] = uint32_t(p);
+        }
+        qtrans.resize(q->nrows);
+        for (uint32_t i = 0; i < q->nrows; i++) {
+            auto it = member_of.find(qlabels[i]);
+            qtrans[i] = it == member_of.end() ? 0xFFFFFFFFu : it->second;
+        }
+        qlabels = qtrans.data();
+    }
     DVS_HIP(ctx, hipMalloc(&d_out, size_t(q->nrows) * 8));
     if (qlabels) {
         DVS_HIP(ctx, hipMalloc(&d_lab, size_t(q->nrows) * 4));

@@ -290,6 +290,12 @@ class CountMatrix:
                                                           _lib.ptr(out, C.c_double)))
         return out
 
+    def source_rows(self) -> np.ndarray:
+        """(matrix_from_device_freqs with flags) the input row every matrix row was copied from"""
+        out = np.zeros(self.nrows, dtype=np.uint32)
+        self.ctx.check(self.ctx._L.dvs_matrix_get_source_rows(self.ctx._h, self._h, _lib.ptr(out, C.c_uint32)))
+        return out
+
     def dev_counts(self) -> int:
         return int(self.ctx._L.dvs_matrix_dev_counts(self._h) or 0)
 

@@ -7,7 +7,11 @@ stream with no communication; the only exchange step is ONE all_gather of every
 rank's winning frequency rows (n x 4^k f64 per rank; RCCL over xGMI on GPUs,
 gloo in the CPU tests), after which every rank runs the reference's merge
 (`final_nmost` / `final_max`, src/records.rs:363-382,456-507) on the G*n rows.
-The result equals the reference run with `-np G`.
+The result equals `final_nmost` / `final_max` over the per-chunk results taken in CHUNK order.
+(The reference's `apply_app` collects its workers' results in completion order,
+records.py:236-243, and the merge is order-dependent -- the first n rows seed the set -- so the
+reference's own `-np G` output is this one whenever its workers finish in chunk order, and one of
+the other orderings otherwise; the order here is fixed so that runs are reproducible.)
 """
 
 from __future__ import annotations
@@ -94,22 +98,25 @@ def gather_winners_device(ctx, sel, world: int, device, cap: int, *, shared_stre
     return all_rows, all_meta
 
 
-def _global_ids(all_meta, chunk_starts, cap: int) -> np.ndarray:
-    """global stream position of every gathered row (-1 for padding)"""
+def _global_ids(all_meta, chunk_starts, cap: int, src_rows=None) -> np.ndarray:
+    """global stream position of every row of the merge matrix (-1 for padding); src_rows maps a
+    matrix row to the gathered row it was copied from (the matrix keeps the real rows first)"""
     meta = all_meta.cpu().numpy()
     starts = np.repeat(np.asarray(chunk_starts, dtype=np.int64), cap)
-    return np.where(meta[:, 1] != 0, meta[:, 0].astype(np.int64) + starts, -1)
+    gids = np.where(meta[:, 1] != 0, meta[:, 0].astype(np.int64) + starts, -1)
+    return gids if src_rows is None else gids[np.asarray(src_rows, dtype=np.int64)]
 
 
 class _LazyGlobalIds:
-    """global ids of the gathered rows, copied from the device on first use"""
+    """global ids of the merge matrix's rows, copied from the device on first use"""
 
-    def __init__(self, all_meta, chunk_starts, cap):
-        self._args, self._val = (all_meta, chunk_starts, cap), None
+    def __init__(self, all_meta, chunk_starts, cap, matrix=None):
+        self._args, self._matrix, self._val = (all_meta, chunk_starts, cap), matrix, None
 
     def get(self):
         if self._val is None:
-            self._val = _global_ids(*self._args)
+            src = self._matrix.source_rows() if self._matrix is not None else None
+            self._val = _global_ids(*self._args, src_rows=src)
         return self._val
 
 
@@ -125,7 +132,7 @@ def merge_nmost(ctx, sel, n: int, rank: int, world: int, chunk_start: int, devic
         m = ctx.matrix_from_device_freqs(all_rows.data_ptr(), world * n, sel.matrix.nbins,
                                          all_meta.data_ptr())
         merged = m.nmost(n)
-        merged._lazy_gids = _LazyGlobalIds(all_meta, chunk_starts, n)  # (a device -> host copy: on demand)
+        merged._lazy_gids = _LazyGlobalIds(all_meta, chunk_starts, n, m)  # (device -> host copies: on demand)
         merged._keep = m
         return merged
     mem = sel.members(with_freqs=True)

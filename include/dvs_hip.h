@@ -84,10 +84,15 @@ int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device,
 int dvs_matrix_from_freqs(dvs_ctx *ctx, const double *freqs, uint32_t nrows,
                           uint64_t nbins, dvs_matrix **out);
 /* the same for rows already in HBM (the all-gathered winners of a chunked multi-GPU run);
- * d_meta may be NULL, else d_meta[2 r + 1] == 0 marks row r as padding (skipped like a
- * sequence without valid k-mers).  Rows are copied; no host round trip. */
+ * d_meta may be NULL, else d_meta[2 r + 1] == 0 marks input row r as padding.  Rows are copied, no
+ * host round trip; with d_meta the real rows come first in their input order and the padding
+ * rows behind them (skipped like sequences without valid k-mers), so that the first n stream
+ * positions are the first n real records of the concatenated results, as
+ * get_kmerseqs_and_init_summed_records takes them (src/records.rs:344-360);
+ * dvs_matrix_get_source_rows gives the input row of every matrix row. */
 int dvs_matrix_from_device_freqs(dvs_ctx *ctx, const double *d_freqs, const double *d_meta,
                                  uint32_t nrows, uint64_t nbins, dvs_matrix **out);
+int dvs_matrix_get_source_rows(dvs_ctx *ctx, const dvs_matrix *m, uint32_t *out); /* [nrows] */
 void dvs_matrix_destroy(dvs_matrix *m);
 uint32_t dvs_matrix_nrows(const dvs_matrix *m);
 uint64_t dvs_matrix_nbins(const dvs_matrix *m);
@@ -172,7 +177,7 @@ typedef struct dvs_select_summary {
     double scan_ms;          /* sum of scan-kernel durations (HIP events) when timing is on, else 0 */
     uint64_t scan_launches;  /* scan-kernel launches the events bracket (no-op launches included) */
     uint32_t engine;         /* 0: one scan launch per window + state kernels; 1: persistent single launch */
-    uint32_t reserved;
+    uint32_t rows_coarse_passed; /* persistent engine: rows its all-f32 tier could not decide (scored again by the f32-log tier) */
 } dvs_select_summary;
 
 int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t *order,

@@ -293,16 +293,23 @@ def nmost(seqs, n: int, k: int, num_states: int = 4, labels=None) -> SummedRecor
     return nmost_concat(data, offs, n, k, num_states, labels)[0]
 
 
+def max_divergent_concat(data, offsets, min_size: int, max_size: int, k: int, num_states: int = 4,
+                         stat: str = "stdev", labels=None) -> SummedRecords:
+    """select_max_divergent over pre-concatenated sequences (genome-sized inputs: no second copy)"""
+    keep, lp = _lab(labels)
+    out = C.c_void_p()
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    _check(lib().orc_max(_p(data, C.c_uint8), _p(offsets, C.c_uint64), lp, offsets.size - 1,
+                         min_size, max_size, int(stat == "stdev"), k, num_states,
+                         C.byref(out)))
+    return SummedRecords(out.value)
+
+
 def max_divergent(seqs, min_size: int, max_size: int, k: int, num_states: int = 4,
                   stat: str = "stdev", labels=None) -> SummedRecords:
     """src/records.rs:390-454 select_max_divergent (stat != 'stdev' means cov, lib.rs:116-120)"""
     data, offs = concat(seqs)
-    keep, lp = _lab(labels)
-    out = C.c_void_p()
-    _check(lib().orc_max(_p(data, C.c_uint8), _p(offs, C.c_uint64), lp, len(seqs),
-                         min_size, max_size, int(stat == "stdev"), k, num_states,
-                         C.byref(out)))
-    return SummedRecords(out.value)
+    return max_divergent_concat(data, offs, min_size, max_size, k, num_states, stat, labels)
 
 
 def nmost_chunks_threads(data, offsets, bounds, n: int, k: int, num_states: int = 4):

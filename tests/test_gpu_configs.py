@@ -1,0 +1,334 @@
+"""Round-2 parity cases on the GPU: the BASELINE.json configurations at their stated workloads
+against the oracle, the drop-in module on the persistent engine, the engine's fall-back, and
+candidates built to sit inside the decision bands of the f32 tiers."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import synth_seqs
+from gpu_synth import synth_device
+from test_gpu_parity import RTOL, _assert_selection
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from diverseseq_amd import engine
+
+    return engine.default_context()
+
+
+# ---------------------------------------------------------------- drop-in module, fast engine
+def _store_of(seqs):
+    from diverseseq_amd import _dvs as dvs
+
+    st = dvs.make_zarr_store()
+    for i, s in enumerate(seqs):
+        st.write(f"s{i:06d}", s.tobytes())
+    return st
+
+
+def test_dvs_module_runs_the_persistent_engine():
+    """reference src/lib.rs:59-73,105-137 through the drop-in: the ids of a store are unique, so the
+    labels _dvs passes are all distinct and the selection runs on the persistent engine"""
+    from diverseseq_amd import _dvs as dvs
+
+    seqs = synth_seqs(1500, 1200, 77, invalid_frac=0.001)
+    st = _store_of(seqs)
+    ids = st.unique_seqids
+    assert len(ids) == len(seqs)
+    got = dvs.nmost_divergent(st, n=12, k=5)
+    assert got.stats["engine"] == 1
+    exp = oracle.nmost(seqs, 12, 5, 4)
+    elab, edelta, _, efreq = exp.members(with_freqs=True)
+    assert got.record_names == [ids[i] for i in elab]
+    np.testing.assert_allclose([r[2] for r in got.records], edelta, rtol=RTOL, atol=1e-13)
+    assert (np.array([r[1] for r in got.records]) == efreq).all()
+    assert abs(got.total_jsd - exp.total_jsd) <= RTOL * exp.total_jsd
+    # a caller-chosen order of the same ids: still distinct labels, still the persistent engine
+    perm = np.random.default_rng(5).permutation(len(ids))
+    got = dvs.nmost_divergent(st, n=7, k=4, seqids=[ids[i] for i in perm])
+    assert got.stats["engine"] == 1
+    exp = oracle.nmost([seqs[i] for i in perm], 7, 4, 4)
+    assert got.record_names == [ids[perm[i]] for i in exp.members()[0]]
+    for stat in ("stdev", "cov"):
+        got = dvs.max_divergent(st, min_size=5, max_size=40, k=5, stat=stat)
+        assert got.stats["engine"] == 1
+        exp = oracle.max_divergent(seqs, 5, 40, 5, 4, stat)
+        assert got.record_names == [ids[i] for i in exp.members()[0]]
+        assert abs(got.std_delta_jsd - exp.std_delta_jsd) <= RTOL * abs(exp.std_delta_jsd)
+    # the chunk merge: final_nmost over results whose ids are distinct
+    a = dvs.nmost_divergent(st, n=6, k=5, seqids=ids[:700])
+    b = dvs.nmost_divergent(st, n=6, k=5, seqids=ids[700:])
+    merged = dvs.final_nmost([a, b], n=6)
+    assert merged.stats["engine"] == 1
+    rows = np.array([r[1] for r in a.records] + [r[1] for r in b.records])
+    exp = oracle.final_nmost(rows, 6)
+    names = a.record_names + b.record_names
+    assert merged.record_names == [names[i] for i in exp.members()[0]]
+
+
+def test_repeated_ids_keep_the_label_aware_engine():
+    """an id listed twice (records.rs:71-73: a member's own id scores 0.0) needs the labels: the
+    multi-launch engine serves it, with the reference's answer"""
+    from diverseseq_amd import _dvs as dvs
+
+    seqs = synth_seqs(400, 900, 78)
+    st = _store_of(seqs)
+    ids = st.unique_seqids
+    order = list(range(400)) + list(range(0, 400, 7))
+    got = dvs.nmost_divergent(st, n=8, k=4, seqids=[ids[i] for i in order])
+    assert got.stats["engine"] == 0
+    exp = oracle.nmost([seqs[i] for i in order], 8, 4, 4, labels=np.array(order, dtype=np.uint32))
+    assert got.record_names == [ids[i] for i in exp.members()[0]]
+
+
+def test_caller_labels_come_back_from_the_label_free_engine(ctx):
+    """distinct but arbitrary labels: the engine runs without them, the caller gets them back"""
+    seqs = synth_seqs(600, 800, 79)
+    labels = (np.random.default_rng(1).permutation(600) * 7 + 3).astype(np.uint32)
+    m = ctx.build_matrix(seqs, 5, 4)
+    sel = m.nmost(9, labels=labels)
+    assert sel.summary().engine == 1
+    mem = sel.members(False)
+    exp = oracle.nmost(seqs, 9, 5, 4)
+    assert mem.positions.tolist() == exp.members()[0].tolist()
+    assert mem.labels.tolist() == labels[mem.positions.astype(np.int64)].tolist()
+    # delta_jsd against that selection speaks the caller's labels too: a member scores 0.0
+    q = ctx.build_matrix([seqs[int(mem.positions[0])], seqs[5]], 5, 4)
+    d = sel.delta_jsd(q, [int(mem.labels[0]), 0xFFFFFFF0])
+    assert d[0] == 0.0 and d[1] != 0.0
+
+
+def test_persistent_engine_falls_back_to_the_multi_launch_engine(ctx, monkeypatch):
+    """a persistent launch that gives up at a grid barrier (workgroups not co-resident) is not an
+    error: the selection starts over from its seeds on the multi-launch engine"""
+    seqs = synth_seqs(2500, 700, 80)
+    m = ctx.build_matrix(seqs, 5, 4)
+    exp = oracle.nmost(seqs, 11, 5, 4)
+    sel = m.nmost(11)
+    assert sel.summary().engine == 1
+    _assert_selection(sel, exp)
+    monkeypatch.setenv("DVS_PERSIST_FAKE_ERROR", "1")  # the first launch's outcome is read as SEL_ERROR
+    sel = m.nmost(11)
+    assert sel.summary().engine == 0
+    _assert_selection(sel, exp)
+    sel = m.max_divergent(4, 30, "stdev")
+    assert sel.summary().engine == 0
+    _assert_selection(sel, oracle.max_divergent(seqs, 4, 30, 5, 4, "stdev"))
+
+
+# ---------------------------------------------------------------- candidates inside the bands
+COARSE_BAND_K6 = 1.25 * 2.0**-24 * (9.0 * 12 + 7.4)  # select_dev.h coarse_band(4096)
+FAST_BAND = 4e-7                                       # select_dev.h
+
+
+def _craft(oset, start, target, k, rng, tol):
+    """substitutions of `start` (one to three bases at a time) until the oracle's score of the
+    sequence against `oset` sits at threshold + target (records.rs:70-92) within tol.  Equal-length
+    sequences give the score a grain of ~1e-8, so tol is a few of those (0.08 of the band), not zero."""
+    seq = start.copy()
+    thr = oset.total_jsd
+
+    def margin(s):
+        f, h = oracle.to_kfreqs(s, 4, k)
+        return oset.delta_jsd(f, h) - thr
+
+    cur = margin(seq)
+    for _ in range(60_000):
+        if abs(cur - target) <= tol:
+            return seq, cur
+        m = int(rng.integers(1, 4))
+        pos = rng.integers(0, seq.size, size=m)
+        old = seq[pos].copy()
+        seq[pos] = (old + rng.integers(1, 4, size=m)) % 4
+        d = margin(seq)
+        if abs(d - target) < abs(cur - target):
+            cur = d
+        else:
+            seq[pos] = old
+    raise AssertionError(f"no sequence found at margin {target}: stuck at {cur}")
+
+
+def _band_stream(k, n, length, nprefix, targets, seed):
+    """a random prefix, then for every target margin a near-copy of the set's lowest member whose exact
+    score is threshold + margin (each followed by a few ordinary rows), the oracle tracking the set"""
+    rng = np.random.default_rng(seed)
+    seqs = synth_seqs(nprefix, length, seed)
+    oset = oracle.nmost(seqs, n, k, 4)
+    margins = []
+    for t in targets:
+        labels = oset.members()[0]
+        low = seqs[int(labels[oset.lowest_index])]
+        cand, got = _craft(oset, low, t, k, rng, tol=0.08 * (FAST_BAND if abs(t) < 1e-6 else COARSE_BAND_K6))
+        f, h = oracle.to_kfreqs(cand, 4, k)
+        if oset.increases_jsd(f, h, len(seqs)):
+            oset.replace_lowest(f, h, len(seqs))
+        seqs.append(cand)
+        margins.append(got)
+        for s in synth_seqs(3, length, int(rng.integers(1 << 30))):
+            f, h = oracle.to_kfreqs(s, 4, k)
+            if oset.increases_jsd(f, h, len(seqs)):
+                oset.replace_lowest(f, h, len(seqs))
+            seqs.append(s)
+    return seqs, oset, margins
+
+
+MULTS = (-1.1, -0.9, -0.5, -0.1, 0.1, 0.5, 0.9, 1.1)
+
+
+@pytest.fixture(scope="module")
+def band_k6():
+    targets = [m * COARSE_BAND_K6 for m in MULTS] + [m * FAST_BAND for m in MULTS]
+    return _band_stream(6, 10, 5000, 700, targets, 91)
+
+
+@pytest.fixture(scope="module")
+def band_k7():
+    return _band_stream(7, 10, 5000, 300, [m * FAST_BAND for m in (-0.5, -0.1, 0.1, 0.5)], 92)  # (16384-bin scores: ~3 s each)
+
+
+@pytest.mark.parametrize("env", [{}, {"DVS_PERSIST_WG_ROUNDS": "0"}, {"DVS_PERSIST_WG_ROUNDS": "100000"},
+                                 {"DVS_NO_PERSIST": "1"}])
+def test_candidates_inside_the_f32_bands_k6(ctx, band_k6, env, monkeypatch):
+    """reference src/records.rs:86-92 (`jsd > total_jsd + EPSILON`) for candidates whose exact score is
+    the threshold +- {0.1, 0.5, 0.9, 1.1} x COARSE_BAND and x FAST_BAND: the f32 tiers may not decide
+    them, the f64 tier must, and the selected ids stay the oracle's.  Both row mappings of the
+    persistent engine and the multi-launch engine."""
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    seqs, oset, margins = band_k6
+    exp = oracle.nmost(seqs, 10, 6, 4)
+    assert exp.members()[0].tolist() == oset.members()[0].tolist()  # (the tracked set is the stream's)
+    nprefix = 700
+    m = ctx.build_matrix(seqs, 6, 4)
+    sel = m.nmost(10)
+    s = _assert_selection(sel, exp)
+    assert s.engine == (0 if "DVS_NO_PERSIST" in env else 1)
+    assert s.n_arbitrated == 0
+    # the same prefix without the crafted rows: what the bands cost on ordinary input
+    m0 = ctx.build_matrix(seqs[:nprefix], 6, 4)
+    s0 = m0.nmost(10).summary()
+    sure_fast = sum(1 for g in margins[len(MULTS):] if abs(g) <= 0.5 * FAST_BAND)
+    assert sure_fast >= 4
+    assert s.rows_rechecked >= s0.rows_rechecked + sure_fast, (s.rows_rechecked, s0.rows_rechecked)
+    if s.engine == 1:
+        sure_coarse = sum(1 for g in margins if abs(g) <= 0.5 * COARSE_BAND_K6)
+        assert sure_coarse >= 4 + len(MULTS)
+        assert s.rows_coarse_passed >= s0.rows_coarse_passed + sure_coarse, (s.rows_coarse_passed, s0.rows_coarse_passed)
+
+
+@pytest.mark.parametrize("env", [{}, {"DVS_NO_PERSIST": "1"}])
+def test_candidates_inside_the_fast_band_k7(ctx, band_k7, env, monkeypatch):
+    """the same at k=7 (16384 bins: no COARSE tier, the FAST tier decides or lists every row)"""
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    seqs, oset, margins = band_k7
+    exp = oracle.nmost(seqs, 10, 7, 4)
+    assert exp.members()[0].tolist() == oset.members()[0].tolist()
+    m = ctx.build_matrix(seqs, 7, 4)
+    s = _assert_selection(m.nmost(10), exp)
+    assert s.n_arbitrated == 0
+    s0 = ctx.build_matrix(seqs[:300], 7, 4).nmost(10).summary()
+    sure = sum(1 for g in margins if abs(g) <= 0.5 * FAST_BAND)
+    assert s.rows_rechecked >= s0.rows_rechecked + sure >= 4
+
+
+# ---------------------------------------------------------------- stated configurations
+def test_config_c3_scaled_1050_genomes_vs_oracle(ctx):
+    """C3 at N = 1050 (SURVEY 8d's CI variant): genomes of 2.5-3.5 Mb with their own base composition,
+    k=6, `max` min_size=100, max_size=N, stdev -- select_max_divergent (records.rs:390-454) in full
+    against the oracle (~10 s of CPU: 3.15 Gbases counted, ~1000 tentative pushes)"""
+    seqs, offs = synth_device(1050, 2_500_000, 3_500_000, 20260430, composition=True)
+    total = int(offs[-1])
+    m = ctx.build_matrix_device(seqs.data_ptr(), offs, 6, 4)
+    sel = m.max_divergent(100, 1050, "stdev")
+    host = seqs[:total].cpu().numpy()
+    exp = oracle.max_divergent_concat(host, offs, 100, 1050, 6, 4, "stdev")
+    s = _assert_selection(sel, exp)
+    assert s.size >= 100
+    tot = m.totals()
+    assert (tot.astype(np.int64) == np.diff(offs.astype(np.int64)) - 5).all()
+    for i in (0, 523, 1049):
+        c = oracle.count_kmers(host[int(offs[i]):int(offs[i + 1])], 4, 6)
+        assert (m.counts(i, 1)[0] == c).all()
+
+
+def test_config_c3_full_size_properties(ctx):
+    """C3 as stated: 10.5k genomes of ~3 Mb (31.5 Gbases resident in HBM), k=6, `max` min_size=100.
+    Too big for the oracle in seconds, so size-independent properties: row totals, spot rows against
+    the oracle's count_kmers, the same members from a different window partition and from the
+    multi-launch engine, and the prefix of the stream reproducing the oracle-checked scaled case's
+    kind of answer (members are stream positions in range, no duplicates, delta_jsd finite)."""
+    N = 10_500
+    seqs, offs = synth_device(N, 2_500_000, 3_500_000, 20260431, composition=True)
+    m = ctx.build_matrix_device(seqs.data_ptr(), offs, 6, 4)
+    tot = m.totals()
+    assert (tot.astype(np.int64) == np.diff(offs.astype(np.int64)) - 5).all()
+    for i in (0, 7777, N - 1):
+        a, b = int(offs[i]), int(offs[i + 1])
+        c = oracle.count_kmers(seqs[a:b].cpu().numpy(), 4, 6)
+        assert (m.counts(i, 1)[0] == c).all()
+    a = m.max_divergent(100, N, "stdev")
+    sa, ma = a.summary(), a.members(False)
+    assert sa.size >= 100 and len(set(ma.positions.tolist())) == sa.size
+    assert np.isfinite(ma.delta_jsd).all() and int(ma.positions.max()) < N
+    b = m.max_divergent(100, N, "stdev", window=777)  # another window partition: the same answer
+    mb = b.members(False)
+    assert ma.positions.tolist() == mb.positions.tolist()
+    np.testing.assert_allclose(ma.delta_jsd, mb.delta_jsd, rtol=1e-9)
+    os.environ["DVS_NO_PERSIST"] = "1"
+    try:
+        c = m.max_divergent(100, N, "stdev")  # the other engine: the same answer
+    finally:
+        del os.environ["DVS_NO_PERSIST"]
+    assert c.summary().engine == 0 and sa.engine == 1
+    mc = c.members(False)
+    assert ma.positions.tolist() == mc.positions.tolist()
+    np.testing.assert_allclose(ma.delta_jsd, mc.delta_jsd, rtol=1e-9)
+    # the members' own rows, taken alone, form a set with the same statistics (get_result is a
+    # function of the members only): make_summed_records over them in member order
+    rows = [seqs[int(offs[p]):int(offs[p + 1])].cpu().numpy() for p in ma.positions[:sa.size]]
+    oset = oracle.SummedRecords.from_seqs(rows, 6, 4)
+    assert abs(oset.total_jsd - sa.total_jsd) <= RTOL * oset.total_jsd
+    np.testing.assert_allclose(ma.delta_jsd, oset.members()[1], rtol=RTOL, atol=1e-13)
+
+
+def test_config_c4_full_input_k7_n100_vs_oracle(ctx):
+    """C4's input on one GPU: 100k x 5 kb, k=7 (16384 bins, a 6.55 GB count matrix), nmost n=100, in
+    full against the oracle (~30 s of CPU)"""
+    seqs, offs = synth_device(100_000, 5000, 5000, 20260432)
+    m = ctx.build_matrix_device(seqs.data_ptr(), offs, 7, 4)
+    sel = m.nmost(100)
+    host = seqs[:int(offs[-1])].cpu().numpy()
+    exp, acc = oracle.nmost_concat(host, offs, 100, 7, 4)
+    s = _assert_selection(sel, exp)
+    assert s.engine == 1 and s.n_arbitrated == 0
+    assert s.n_accepts == acc
+
+
+def test_config_c5_100_genomes_sketches_and_matrix_vs_oracle(ctx):
+    """C5 at N = 100: mash sketches (k=12, s=3000, plain and canonical) of ~3 Mb genomes bit-exact
+    against the oracle's mash_sketch (distance.rs:151-182), and the full N x N distance matrix against
+    the oracle's restatement of mash_distance (distance.py:230-291)"""
+    from diverseseq_amd import distance
+
+    N = 100
+    seqs, offs = synth_device(N, 2_900_000, 3_100_000, 20260433, composition=True)
+    host = seqs[:int(offs[-1])].cpu().numpy()
+    rows = [host[int(offs[i]):int(offs[i + 1])] for i in range(N)]
+    for canonical in (False, True):
+        sk, lens = distance.sketch_batch(rows, 12, 3000, 4, canonical, ctx=ctx)
+        with ThreadPoolExecutor(8) as ex:  # (the C oracle releases the GIL)
+            exp = list(ex.map(lambda r: oracle.mash_sketch(r, 12, 3000, 4, canonical), rows))
+        for i in range(N):
+            assert int(lens[i]) == exp[i].size
+            assert (sk[i, :lens[i]] == exp[i]).all(), f"sketch {i} differs (canonical={canonical})"
+        d = distance.distances_from_sketches(sk, lens, 12, 3000, ctx=ctx)
+        de = oracle.mash_distances(exp, 12, 3000)
+        np.testing.assert_allclose(d, de, rtol=RTOL, atol=0)
+        assert (d == d.T).all() and (np.diag(d) == 0).all()
