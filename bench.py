@@ -124,7 +124,7 @@ def main():
     torch.cuda.synchronize()
 
     stats = {"rows_scored": 0, "scan_ms": 0.0, "scan_launches": 0, "n_accepts": 0,
-             "n_windows": 0, "n_arbitrated": 0, "hist_ms": 0.0, "engine": 0}
+             "n_windows": 0, "n_arbitrated": 0, "hist_ms": 0.0, "engine": 0, "count_bytes": 4}
 
     def step(collect: bool):
         t0 = time.perf_counter()
@@ -146,6 +146,7 @@ def main():
                 stats[key] += getattr(s, key)
             stats["hist_ms"] += (t1 - t0) * 1e3
             stats["engine"] = s.engine
+            stats["count_bytes"] = m.count_bytes
         sel.close()
         m.close()
 
@@ -267,7 +268,8 @@ def main():
     if rank == 0:
         total_seqs = a.nseq * world * a.steps
         scan_s = stats["scan_ms"] / 1e3
-        alg_bytes = stats["rows_scored"] * B * 4  # rows scored x 4^k x sizeof(u32)
+        cb = stats["count_bytes"]  # sizeof(count) of the matrix the scan reads: 2 for whole-sequence rows, else 4
+        alg_bytes = stats["rows_scored"] * B * cb  # rows scored x 4^k x sizeof(count)
         achieved = alg_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
         peak = 8000.0  # GB/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
         out = {
@@ -306,9 +308,11 @@ def main():
                 "ms_per_step_with_offsets_cache": elapsed_cached / a.steps * 1e3,
             },
             "roofline": {
-                "kernel": ("persist_nmost_kernel<uint32> (one launch per selection: windowed delta-JSD scan + "
+                "kernel": (f"persist_nmost_kernel<uint{8 * cb}> (one launch per selection: windowed delta-JSD scan + "
                            "in-kernel set updates behind grid barriers)") if stats["engine"] == 1
-                          else "scan_kernel<uint32> (one launch per window)",
+                          else f"scan_kernel<uint{8 * cb}> (one launch per window)",
+                "count_bytes": cb,
+                "achieved_if_counts_were_u32": achieved * 4 / cb,  # comparable with round 1's lines (uint32 rows)
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": peak,
@@ -320,14 +324,14 @@ def main():
             },
         }
         if "scan_stream_ms" in stats:  # the scan arithmetic alone, streaming the whole matrix once
-            gbps = stats["scan_stream_rows"] * B * 4 / (stats["scan_stream_ms"] * 1e-3) / 1e9
+            gbps = stats["scan_stream_rows"] * B * cb / (stats["scan_stream_ms"] * 1e-3) / 1e9
             out["roofline"]["scan_streaming"] = {
                 "what": "one scan_kernel launch over all streamed rows, no events (dvs_select_bench_scan)",
                 "ms": stats["scan_stream_ms"], "rows": stats["scan_stream_rows"],
                 "achieved": gbps, "unit": "GB/s", "frac": gbps / peak,
             }
         if "persist_stream_ms" in stats:
-            gbps = stats["persist_stream_rows"] * B * 4 / (stats["persist_stream_ms"] * 1e-3) / 1e9
+            gbps = stats["persist_stream_rows"] * B * cb / (stats["persist_stream_ms"] * 1e-3) / 1e9
             out["roofline"]["persist_streaming"] = {
                 "what": "the persistent kernel with a threshold no row reaches (DVS_PERSIST_NO_EVENTS: no events, "
                         "four long windows): its scan arithmetic (coarse tier) as a pure stream, launch to exit",

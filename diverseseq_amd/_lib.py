@@ -28,7 +28,7 @@ ROW_REMOTE = 0xFFFFFFFF
 # every symbol include/dvs_hip.h declares (tests/test_boundary.py checks the .so exports them)
 EXPORTS = (
     "dvs_abi_version", "dvs_ctx_create", "dvs_ctx_destroy", "dvs_last_error", "dvs_ctx_sync",
-    "dvs_ctx_trim", "dvs_ctx_device_info", "dvs_ctx_set_timing", "dvs_matrix_build", "dvs_matrix_from_freqs", "dvs_matrix_from_device_freqs", "dvs_matrix_get_source_rows",
+    "dvs_ctx_trim", "dvs_ctx_device_info", "dvs_ctx_set_timing", "dvs_matrix_build", "dvs_matrix_from_freqs", "dvs_matrix_from_device_freqs", "dvs_matrix_get_source_rows", "dvs_matrix_count_bytes",
     "dvs_matrix_destroy", "dvs_matrix_nrows", "dvs_matrix_nbins", "dvs_matrix_dev_counts",
     "dvs_matrix_dev_totals", "dvs_matrix_dev_entropy", "dvs_matrix_get_counts",
     "dvs_matrix_get_totals", "dvs_matrix_get_entropy", "dvs_kmer_counts", "dvs_select_run",
@@ -137,6 +137,8 @@ def load() -> C.CDLL:
         L.dvs_matrix_get_totals.argtypes = [vp, vp, u32p]
         L.dvs_matrix_get_entropy.argtypes = [vp, vp, f64p]
         L.dvs_matrix_get_source_rows.argtypes = [vp, vp, u32p]
+        L.dvs_matrix_count_bytes.argtypes = [vp]
+        L.dvs_matrix_count_bytes.restype = C.c_uint32
         L.dvs_kmer_counts.argtypes = [vp, u8p, u64p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p,
                                       f64p]
         L.dvs_select_run.argtypes = [vp, vp, u32p, u32p, C.c_uint64, C.POINTER(SelectParams),
@@ -172,7 +174,7 @@ def load() -> C.CDLL:
         L.dvs_seqbatch_dev_codes.restype = vp
         L.dvs_seqbatch_get_codes.argtypes = [vp, vp, u8p]
         L.dvs_matrix_build_from_seqbatch.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
-        if L.dvs_abi_version() != 1:
+        if L.dvs_abi_version() != 2:
             raise RuntimeError("libdvs_hip.so ABI version mismatch")
         _lib = L
         return _lib

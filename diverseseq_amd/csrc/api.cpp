@@ -10,6 +10,8 @@ void dvs_matrix_free_fields(dvs_matrix *m);
 int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs, uint64_t nbytes,
                            const uint64_t *offsets, bool no_wait);
 int dvs_matrix_fill_freq_entropy(dvs_ctx *ctx, dvs_matrix *m);
+int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint32_t k, uint64_t nbytes, size_t *n_long_out);
+bool dvs_hist_rows_fit_u16(uint64_t B, size_t n_long);
 int dvs_matrix_fill_freq_totals(dvs_ctx *ctx, dvs_matrix *m, const double *d_meta);
 int dvs_matrix_fill_compacted(dvs_ctx *ctx, dvs_matrix *m, const double *d_in, const double *d_meta);
 
@@ -221,7 +223,7 @@ int dvs_ctx_device_info(dvs_ctx *ctx, char *name, size_t name_len, int *n_cu, ui
 
 static int matrix_alloc(dvs_ctx *ctx, dvs_matrix *m) {
     const size_t cells = size_t(m->nrows) * m->nbins;
-    const size_t bytes = cells * (m->kind == 0 ? 4 : 8);
+    const size_t bytes = cells * (m->kind == 0 ? 4 : m->kind == 2 ? 2 : 8);
     size_t free_b = 0, total_b = 0;
     const bool cached = ctx->pool.count(((bytes ? bytes : 4) + 4095) & ~size_t(4095)) > 0;
     if (!cached) DVS_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
@@ -234,6 +236,7 @@ static int matrix_alloc(dvs_ctx *ctx, dvs_matrix *m) {
     dvs_ctx_retain(ctx);
     int rc;
     if (m->kind == 0) rc = dvs_dev_alloc(ctx, (void **)&m->d_counts, bytes ? bytes : 4, "matrix counts");
+    else if (m->kind == 2) rc = dvs_dev_alloc(ctx, (void **)&m->d_counts16, bytes ? bytes : 4, "matrix counts (16-bit)");
     else rc = dvs_dev_alloc(ctx, (void **)&m->d_freqs, bytes ? bytes : 8, "matrix freqs");
     if (!rc) rc = dvs_dev_alloc(ctx, (void **)&m->d_totals, nr * 4, "matrix totals");
     if (!rc) rc = dvs_dev_alloc(ctx, (void **)&m->d_entropy, nr * 8, "matrix entropy");
@@ -255,8 +258,17 @@ int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, cons
         return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "%u^%u bins do not fit a dense count row",
                              num_states, k);
     DVS_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t nbytes = nseq ? offsets[nseq] : 0;
+    const uint64_t padded = ((nbytes + 15) & ~15ull) + 16;
+    uint64_t readable = seqs_on_device ? nbytes : padded;
+    // the offsets first: whether any sequence needs more than one tile decides the width of the rows
+    size_t n_long = 0;
+    if (nseq) {
+        const int prc = dvs_hist_prepare(ctx, offsets, nseq, k, readable, &n_long);
+        if (prc) return prc;
+    }
     dvs_matrix *m = new dvs_matrix();
-    m->kind = 0;
+    m->kind = (nseq && dvs_hist_rows_fit_u16(B, n_long)) ? 2 : 0;
     m->nrows = nseq;
     m->nbins = B;
     m->k = k;
@@ -268,12 +280,9 @@ int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, cons
         delete m;
         return rc;
     }
-    const uint64_t nbytes = nseq ? offsets[nseq] : 0;
     uint8_t *d_tmp = nullptr;
     const uint8_t *d_seqs = seqs;
-    uint64_t readable = nbytes;
     if (!seqs_on_device) {
-        const uint64_t padded = ((nbytes + 15) & ~15ull) + 16;
         rc = dvs_dev_alloc(ctx, (void **)&d_tmp, padded, "sequence upload buffer");
         if (rc) {
             dvs_matrix_free_fields(m);
@@ -290,7 +299,6 @@ int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, cons
             return dvs_hip_fail(ctx, ue, "sequence upload");
         }
         d_seqs = d_tmp;
-        readable = padded;
     } else if (reinterpret_cast<uintptr_t>(seqs) & 15) {
         dvs_matrix_free_fields(m);
         delete m;
@@ -298,7 +306,7 @@ int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, cons
     }
     // (a device-resident input needs no host wait: the kernels' completion is an event the consumers
     // of the matrix wait on when they need host-side data, dvs_matrix_settle)
-    rc = nseq ? dvs_matrix_fill_counts(ctx, m, d_seqs, seqs_on_device ? nbytes : readable, offsets,
+    rc = nseq ? dvs_matrix_fill_counts(ctx, m, d_seqs, readable, offsets,
                                        seqs_on_device != 0 && !getenv("DVS_BUILD_WAIT"))
               : DVS_OK;
     if (d_tmp) {
@@ -417,16 +425,28 @@ void dvs_matrix_destroy(dvs_matrix *m) {
 
 uint32_t dvs_matrix_nrows(const dvs_matrix *m) { return m ? m->nrows : 0; }
 uint64_t dvs_matrix_nbins(const dvs_matrix *m) { return m ? m->nbins : 0; }
-const void *dvs_matrix_dev_counts(const dvs_matrix *m) { return m ? m->d_counts : nullptr; }
+const void *dvs_matrix_dev_counts(const dvs_matrix *m) {
+    return !m ? nullptr : m->kind == 2 ? static_cast<const void *>(m->d_counts16) : static_cast<const void *>(m->d_counts);
+}
+uint32_t dvs_matrix_count_bytes(const dvs_matrix *m) { return !m ? 0u : m->kind == 0 ? 4u : m->kind == 2 ? 2u : 0u; }
 const void *dvs_matrix_dev_totals(const dvs_matrix *m) { return m ? m->d_totals : nullptr; }
 const void *dvs_matrix_dev_entropy(const dvs_matrix *m) { return m ? m->d_entropy : nullptr; }
 
 int dvs_matrix_get_counts(dvs_ctx *ctx, const dvs_matrix *m, uint32_t row0, uint32_t nrows,
                           uint32_t *out) {
     if (!ctx || !m || !out) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
-    if (m->kind != 0) return dvs_set_error(ctx, DVS_ERR_VALUE, "not a count matrix");
+    if (m->kind == 1) return dvs_set_error(ctx, DVS_ERR_VALUE, "not a count matrix");
     if (uint64_t(row0) + nrows > m->nrows) return dvs_set_error(ctx, DVS_ERR_VALUE, "row range out of bounds");
     if (!nrows) return DVS_OK;
+    if (m->kind == 2) {  // 16-bit rows: copied as they are, widened on the host
+        const size_t cells = size_t(nrows) * m->nbins;
+        std::vector<uint16_t> tmp(cells);
+        DVS_HIP(ctx, hipMemcpyAsync(tmp.data(), m->d_counts16 + uint64_t(row0) * m->nbins, cells * 2,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < cells; i++) out[i] = tmp[i];
+        return DVS_OK;
+    }
     DVS_HIP(ctx, hipMemcpyAsync(out, m->d_counts + uint64_t(row0) * m->nbins,
                                 size_t(nrows) * m->nbins * 4, hipMemcpyDeviceToHost, ctx->stream));
     DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -79,9 +79,12 @@ int dvs_hip_fail(dvs_ctx *ctx, hipError_t e, const char *what);
         if (e__ != hipSuccess) return dvs_hip_fail(ctx, e__, #call); \
     } while (0)
 
-// N x B matrix resident in HBM.  kind 0: uint32 counts; kind 1: f64 freqs.
+// N x B matrix resident in HBM.  kind 0: uint32 counts; kind 1: f64 freqs; kind 2: uint16 counts
+// (a build in which every sequence is a single tile of <= 32768 windows: no count can reach 2^16,
+// and both streaming phases -- the build's write, the scan's read -- move half the bytes).
 struct dvs_matrix {
     int kind = 0;
+    uint16_t *d_counts16 = nullptr;  // kind 2
     uint32_t nrows = 0;
     uint64_t nbins = 0;
     uint32_t k = 0, num_states = 0;
@@ -101,6 +104,14 @@ struct dvs_matrix {
     int device = 0;
     dvs_ctx *ctx = nullptr;  // owner of the allocations
 };
+
+// f(typed row pointer) for the matrix's element type
+template <typename F>
+auto dvs_mat_dispatch(const dvs_matrix *m, F &&f) {
+    if (m->kind == 0) return f(static_cast<const uint32_t *>(m->d_counts));
+    if (m->kind == 2) return f(static_cast<const uint16_t *>(m->d_counts16));
+    return f(static_cast<const double *>(m->d_freqs));
+}
 
 // ---- device helpers -------------------------------------------------------
 #ifdef __HIPCC__

@@ -211,10 +211,16 @@ int fetch_row(dvs_ctx *ctx, const dvs_select *s, uint64_t p, ExactSet &scratch, 
     out.pos = p;
     out.label = s->h_labels.empty() ? row : s->h_labels[p];
     out.f.resize(B);
-    if (m->kind == 0) {
+    if (m->kind != 1) {
         std::vector<uint32_t> c(B);
         uint32_t tot = 0;
-        DVS_HIP(ctx, hipMemcpy(c.data(), m->d_counts + uint64_t(row) * B, B * 4, hipMemcpyDeviceToHost));
+        if (m->kind == 2) {
+            std::vector<uint16_t> c16(B);
+            DVS_HIP(ctx, hipMemcpy(c16.data(), m->d_counts16 + uint64_t(row) * B, B * 2, hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < B; i++) c[i] = c16[i];
+        } else {
+            DVS_HIP(ctx, hipMemcpy(c.data(), m->d_counts + uint64_t(row) * B, B * 4, hipMemcpyDeviceToHost));
+        }
         DVS_HIP(ctx, hipMemcpy(&tot, m->d_totals + row, 4, hipMemcpyDeviceToHost));
         const double total = double(tot);  // record.rs:135-139
         for (uint64_t i = 0; i < B; i++) out.f[i] = double(c[i]) / total;

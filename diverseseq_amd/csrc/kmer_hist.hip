@@ -101,7 +101,8 @@ __device__ __forceinline__ double clog2c(uint32_t c, const double *tbl) {
 // PK16 (whole sequences only, 128 threads, 4 | B): the LDS histogram is packed (see bump) and the
 // flush emulates the 256-thread partition of the bins -- thread t stands for threads t and t + 128
 // -- so that the row entropy has the same bits as from the unpacked kernel.
-template <bool NS4, bool LDS_HIST, bool PK16 = false>
+// OUT16 (PK16 only): the row leaves as 16-bit counts, the packed LDS words as they are (matrix kind 2)
+template <bool NS4, bool LDS_HIST, bool PK16 = false, bool OUT16 = false>
 __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
     const uint8_t *__restrict__ seqs, uint64_t nbytes, const uint64_t *__restrict__ offsets,
     const KTile *__restrict__ tiles, uint32_t *__restrict__ counts, uint32_t *__restrict__ totals,
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
         if (s1 - s0 >= k && s1 - t.begin > TILE_LEN) return;  // multi-tile: other launch
         if (s1 - s0 < k) t.begin = t.end = s1;               // windows(k) empty: all-zero row
     }
-    uint32_t *row = counts + uint64_t(t.row) * B;
+    static_assert(!OUT16 || PK16, "16-bit rows come from the packed histogram");
+    uint32_t *row = OUT16 ? counts + uint64_t(t.row) * (B / 2) : counts + uint64_t(t.row) * B;
     uint32_t *hist = LDS_HIST ? reinterpret_cast<uint32_t *>(smem) : row;
     double *tbl = reinterpret_cast<double *>(smem + (LDS_HIST ? ((B * (PK16 ? 2 : 4) + 15) & ~15ull) : 0));
     double *scratch = tbl + CLOG_TBL;
@@ -204,7 +206,12 @@ __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
             for (uint64_t u = uint64_t(tid) + 128u * half; u < B / 4; u += HIST_THREADS) {
                 const uint2 w = h2[u];
                 const uint4 v = make_uint4(w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16);
-                if (t.row < hot_rows) r4[u] = v;
+                if constexpr (OUT16) {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    uint2 *r2 = reinterpret_cast<uint2 *>(row);
+                    if (t.row < hot_rows) r2[u] = w;
+                    else __builtin_nontemporal_store((u32x2){w.x, w.y}, reinterpret_cast<u32x2 *>(r2 + u));
+                } else if (t.row < hot_rows) r4[u] = v;
                 else __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4 *>(r4 + u));
                 sv[half] += clog2c(v.x, tbl) + clog2c(v.y, tbl) + clog2c(v.z, tbl) + clog2c(v.w, tbl);
                 tv[half] += double(v.x) + double(v.y) + double(v.z) + double(v.w);
@@ -400,6 +407,8 @@ void dvs_matrix_free_fields(dvs_matrix *m) {
     if (!m) return;
     (void)dvs_matrix_settle(m->ctx, m);  // the pinned block must not go back to the cache with a copy pending
     dvs_dev_free(m->ctx, m->d_counts);
+    dvs_dev_free(m->ctx, m->d_counts16);
+    m->d_counts16 = nullptr;
     dvs_dev_free(m->ctx, m->d_freqs);
     dvs_dev_free(m->ctx, m->d_totals);
     dvs_dev_free(m->ctx, m->d_entropy);
@@ -413,16 +422,11 @@ void dvs_matrix_free_fields(dvs_matrix *m) {
     m->ctx = nullptr;
 }
 
-// Launches the histogram build for sequences already in HBM (d_seqs, nbytes
-// readable) into an allocated matrix.  One launch gives every sequence that fits
-// a single tile its own workgroup (tile derived from the offsets on the device);
-// genome-length sequences get an explicit tile list and a second launch.
-int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
-                           uint64_t nbytes, const uint64_t *offsets, bool no_wait) {
-    const uint32_t nseq = m->nrows, k = m->k, ns = m->num_states;
-    const uint64_t B = m->nbins;
-    const bool lds_hist = B * 4 <= 64 * 1024;
-    const bool ns4 = ns == 4;
+// The offsets of a build: validated, the tile lists of genome-length sequences derived, everything
+// uploaded -- or found unchanged in the context's cache.  *n_long = sequences needing more than one
+// tile (none: every row's counts fit 16 bits and the matrix may be built as kind 2).
+int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint32_t k, uint64_t nbytes,
+                     size_t *n_long_out) {
     dvs_ctx::OffsetsCache &oc = ctx->off_cache;
     const bool hit = oc.d_off && oc.k == k && oc.nbytes == nbytes && oc.h_off.size() == size_t(nseq) + 1 &&
                      std::memcmp(oc.h_off.data(), offsets, (size_t(nseq) + 1) * 8) == 0 &&
@@ -483,6 +487,28 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
         oc.n_long = long_rows.size();
         oc.n_tiles = tiles.size();
     }
+    *n_long_out = oc.n_long;
+    return DVS_OK;
+}
+
+// a whole-sequence build may leave 16-bit rows (see dvs_matrix): the packed-histogram kernel serves it
+bool dvs_hist_rows_fit_u16(uint64_t B, size_t n_long) {
+    return n_long == 0 && B * 4 <= 64 * 1024 && (B & 3) == 0 && !getenv("DVS_COUNTS_U32") &&
+           !getenv("DVS_HIST_NO_PK16") && !getenv("DVS_HIST_THREADS");
+}
+
+// Launches the histogram build for sequences already in HBM (d_seqs, nbytes
+// readable) into an allocated matrix, after dvs_hist_prepare for the same offsets.  One launch gives
+// every sequence that fits a single tile its own workgroup (tile derived from the offsets on the
+// device); genome-length sequences get an explicit tile list and a second launch.
+int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
+                           uint64_t nbytes, const uint64_t *offsets, bool no_wait) {
+    const uint32_t nseq = m->nrows, k = m->k, ns = m->num_states;
+    const uint64_t B = m->nbins;
+    const bool lds_hist = B * 4 <= 64 * 1024;
+    const bool ns4 = ns == 4;
+    (void)offsets;
+    dvs_ctx::OffsetsCache &oc = ctx->off_cache;
     uint64_t *d_off = static_cast<uint64_t *>(oc.d_off);
     uint32_t *d_rows = static_cast<uint32_t *>(oc.d_rows);
     KTile *d_tiles = static_cast<KTile *>(oc.d_tiles);
@@ -529,11 +555,27 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
     // last and with ordinary stores, so that they are what the 256 MB memory-side cache still holds
     // when the selection starts; every other row is a streaming store.  Measured on 100k x 4^6:
     // streaming stores -0.04 ms per build + selection, the hot head another -0.01 ms.
-    uint32_t hot_rows = uint32_t(std::min<uint64_t>(nseq, (192ull << 20) / (B * 4)));
+    uint32_t hot_rows = uint32_t(std::min<uint64_t>(nseq, (192ull << 20) / (B * (m->kind == 2 ? 2 : 4))));
     if (const char *e = getenv("DVS_HIST_HOT_ROWS")) hot_rows = uint32_t(atoi(e));
     // whole sequences: the packed histogram at 128 threads when the row layout allows it
     const bool pk16 = lds_hist && (B & 3) == 0 && !getenv("DVS_HIST_NO_PK16") && !getenv("DVS_HIST_THREADS");
-    if (pk16) {
+    if (m->kind == 2) {  // 16-bit rows (dvs_hist_rows_fit_u16 held when the matrix was allocated)
+        const size_t lds16 = ((B * 2 + 15) & ~15ull) + (CLOG_TBL + 32) * sizeof(double);
+        uint32_t *out16 = reinterpret_cast<uint32_t *>(m->d_counts16);
+        if (ns4) {
+            rc = set_dyn_lds(ctx, kmer_hist_kernel<true, true, true, true>, lds16);
+            if (!rc)
+                hipLaunchKernelGGL((kmer_hist_kernel<true, true, true, true>), dim3(nseq), dim3(128), lds16, ctx->stream,
+                                   d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), out16,
+                                   m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_rows);
+        } else {
+            rc = set_dyn_lds(ctx, kmer_hist_kernel<false, true, true, true>, lds16);
+            if (!rc)
+                hipLaunchKernelGGL((kmer_hist_kernel<false, true, true, true>), dim3(nseq), dim3(128), lds16, ctx->stream,
+                                   d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), out16,
+                                   m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_rows);
+        }
+    } else if (pk16) {
         const size_t lds16 = ((B * 2 + 15) & ~15ull) + (CLOG_TBL + 32) * sizeof(double);
         if (ns4) {
             rc = set_dyn_lds(ctx, kmer_hist_kernel<true, true, true>, lds16);

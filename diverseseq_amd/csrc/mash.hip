@@ -25,6 +25,7 @@
 #include "dvs_internal.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 
 namespace {
@@ -697,12 +698,12 @@ extern "C" int dvs_euclidean_distances(dvs_ctx *ctx, const dvs_matrix *m, double
     hipError_t e = hipMemsetAsync(d_dist, 0, size_t(n) * n * 8, ctx->stream);  // the diagonal
     const dim3 grid(n, groups);
     if (e == hipSuccess) {
-        if (m->kind == 0)
-            hipLaunchKernelGGL((euclid_kernel<uint32_t>), grid, dim3(EUC_THREADS), 0, ctx->stream, m->d_counts,
-                               m->d_totals, m->nbins, n, d_dist);
-        else
-            hipLaunchKernelGGL((euclid_kernel<double>), grid, dim3(EUC_THREADS), 0, ctx->stream, m->d_freqs,
-                               m->d_totals, m->nbins, n, d_dist);
+        dvs_mat_dispatch(m, [&](auto *mp) {
+            using T = std::remove_cv_t<std::remove_pointer_t<decltype(mp)>>;
+            hipLaunchKernelGGL((euclid_kernel<T>), grid, dim3(EUC_THREADS), 0, ctx->stream, mp, m->d_totals, m->nbins,
+                               n, d_dist);
+            return 0;
+        });
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(dist, d_dist, size_t(n) * n * 8, hipMemcpyDeviceToHost, ctx->stream);

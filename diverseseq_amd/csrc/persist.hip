@@ -40,6 +40,7 @@
 #include "select_dev.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
@@ -201,10 +202,28 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                 const float rtn = float(rt * rn);
                 const dvs_f2 r2 = {rtn, rtn};
                 double c0 = 0.0, c1 = 0.0;
+                bool done16 = false;
+                if constexpr (sizeof(T) == 2) {
+                    // 16-bit rows of 4096 bins: eight 16-byte loads per lane (lane l owns bins
+                    // 512 j + 8 l .. + 7), the whole 8 KiB row requested at once
+                    if (B == 4096) {
+                        uint4 raw8[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) raw8[j] = *reinterpret_cast<const uint4 *>(rp + j * 512 + lane * 8);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            asm volatile("" : "+v"(raw8[j].x), "+v"(raw8[j].y), "+v"(raw8[j].z), "+v"(raw8[j].w));
+                            coarse8(raw8[j], slf + j * 512 + lane * 8, r2, c0, c1);
+                        }
+                        done16 = true;
+                    }
+                }
+                if (!done16) {
                 // Bursts of C_CH chunks: 4 KiB of a row requested at a time keep the memory pipe as full
                 // as 16 KiB do (scripts/micro/stream_read.hip), and a row that an earlier event has made
                 // pointless is dropped at the next burst with its other bytes never requested.
-                constexpr int C_CH = 8;
+                constexpr int C_CH = sizeof(T) == 2 ? 16 : 8;  // (16-bit rows: the same bytes per burst)
                 const uint64_t full = B - B % (256 * C_CH);
                 uint64_t i0 = 0;
                 bool dropped = false;
@@ -238,6 +257,7 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                     raw.load(rp + i);
                     c0 += double(coarse4(raw.c, *reinterpret_cast<const float4 *>(slf + i), r2));
                 }
+                }  // !done16
                 const double jf0 = -dvs_wave_sum_dpp(c0 + c1) - mean_entropy;
                 if (!(jf0 > thr_c_lo)) continue;  // (NaN: a negative bin, rejected as the reference does)
                 if (jf0 > thr_c_hi) {
@@ -476,8 +496,10 @@ __device__ __forceinline__ void p_scan_rows_wg_stream(const T *__restrict__ mat,
     const double dn = double(st.n), rn = 1.0 / dn;
     const double cband = coarse_band(B);
     const double thr_c_lo = st.thr - st.band - cband, thr_c_hi = st.thr + st.band + cband;
+    constexpr bool W16 = sizeof(T) == 2;  // 16-bit rows: ONE 16-byte load per thread (bins 8 tid .. + 7)
     struct Row {
         Raw4<T> r0, r1;
+        uint4 q;
         uint32_t tot;
         double hrow;
         unsigned long long ev;
@@ -485,8 +507,12 @@ __device__ __forceinline__ void p_scan_rows_wg_stream(const T *__restrict__ mat,
     auto issue = [&](Row &w, uint64_t r) {
         const uint64_t p = st.cursor + r;
         const T *rp = mat + p * B;
-        w.r0.load(rp + tid * 4);
-        w.r1.load(rp + 2048 + tid * 4);
+        if constexpr (W16) {
+            w.q = *reinterpret_cast<const uint4 *>(rp + tid * 8);
+        } else {
+            w.r0.load(rp + tid * 4);
+            w.r1.load(rp + 2048 + tid * 4);
+        }
         w.tot = totals[p];
         if (wave == 0) {  // the row's entropy and the event word travel through LDS with the partial sums
             w.hrow = rowH[p];
@@ -498,10 +524,18 @@ __device__ __forceinline__ void p_scan_rows_wg_stream(const T *__restrict__ mat,
         const uint64_t p = st.cursor + r;
         const float rtn = w.tot ? float(rn / double(w.tot)) : 0.0f;
         const dvs_f2 r2 = {rtn, rtn};
-        w.r0.pin();
-        w.r1.pin();
-        const double c = double(coarse4(w.r0.c, *reinterpret_cast<const float4 *>(slf + tid * 4), r2)) +
-                         double(coarse4(w.r1.c, *reinterpret_cast<const float4 *>(slf + 2048 + tid * 4), r2));
+        double c;
+        if constexpr (W16) {
+            asm volatile("" : "+v"(w.q.x), "+v"(w.q.y), "+v"(w.q.z), "+v"(w.q.w));
+            double ca = 0.0, cb = 0.0;
+            coarse8(w.q, slf + tid * 8, r2, ca, cb);
+            c = ca + cb;
+        } else {
+            w.r0.pin();
+            w.r1.pin();
+            c = double(coarse4(w.r0.c, *reinterpret_cast<const float4 *>(slf + tid * 4), r2)) +
+                double(coarse4(w.r1.c, *reinterpret_cast<const float4 *>(slf + 2048 + tid * 4), r2));
+        }
         const double cs = dvs_wave_sum_dpp(c);
         double *slot = red + 48 + par * 16;
         par ^= 1;
@@ -642,7 +676,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     const uint64_t B = B0;  // (the event loop below takes its own, laundered copy)
     double *sl = reinterpret_cast<double *>(smem);
     // f32 copy of sl / n for the COARSE tier (count matrices whose state fits the register cache)
-    constexpr bool COARSE = CACHED && sizeof(T) == 4;
+    constexpr bool COARSE = CACHED && sizeof(T) <= 4;  // (count matrices, 32- or 16-bit)
     float *slf = reinterpret_cast<float *>(sl + ((B + 1) & ~1ull));
     static_assert(!MAXM || CACHED, "the growth phase keeps the candidate's frequencies in registers");
     double *Sl = sl + ((B + 1) & ~1ull) + (COARSE ? ((B + 3) & ~3ull) / 2 : 0);  // S (MAXM only)
@@ -1658,19 +1692,17 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     s->persist_maxjobs = p_maxjobs(cached);
     // (MODE_MAX: max_size may be the whole stream; the kernel hands over when its LDS replica is full)
     if (!maxm && s->cap > s->persist_maxn) return DVS_OK;
-    const size_t lds = ((B + 1) & ~1ull) * 8 + (cached && s->mat_kind == 0 ? ((B + 3) & ~3ull) * 4 : 0) +
+    const size_t lds = ((B + 1) & ~1ull) * 8 + (cached && s->mat_kind != 1 ? ((B + 3) & ~3ull) * 4 : 0) +
                        (maxm ? ((B + 1) & ~1ull) * 8 : 0) + 128 * 8 + size_t(s->persist_maxn) * 52 + 8 + P_SOFT * 8 + 64 +
                        128 * 16;  // (+ log2_tab's table)
     if (lds > ctx->lds_per_block) return DVS_OK;
     s->persist_lds = lds;
-    const void *fn =
-        maxm ? (s->mat_kind == 0 ? reinterpret_cast<const void *>(persist_nmost_kernel<uint32_t, true, true>)
-                                 : reinterpret_cast<const void *>(persist_nmost_kernel<double, true, true>))
-        : s->mat_kind == 0
-            ? (cached ? reinterpret_cast<const void *>(persist_nmost_kernel<uint32_t, true>)
-                      : reinterpret_cast<const void *>(persist_nmost_kernel<uint32_t, false>))
-            : (cached ? reinterpret_cast<const void *>(persist_nmost_kernel<double, true>)
-                      : reinterpret_cast<const void *>(persist_nmost_kernel<double, false>));
+    const void *fn = dvs_mat_dispatch(s->mat, [&](auto *mp) -> const void * {
+        using T = std::remove_cv_t<std::remove_pointer_t<decltype(mp)>>;
+        return maxm     ? reinterpret_cast<const void *>(persist_nmost_kernel<T, true, true>)
+               : cached ? reinterpret_cast<const void *>(persist_nmost_kernel<T, true>)
+                        : reinterpret_cast<const void *>(persist_nmost_kernel<T, false>);
+    });
     int rc = dvs_raise_dyn_lds(ctx, fn, lds);
     if (rc) return rc;
     {   // one 512-thread workgroup with this much LDS must fit a CU, or the grid can never be resident
@@ -1693,6 +1725,5 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
 size_t dvs_persist_dbg_offset(void) { return offsetof(PSync, dbg2); }  // dbg2[16] then dbg[16]
 
 int dvs_persist_launch(dvs_ctx *ctx, dvs_select *s) {
-    return s->mat_kind == 0 ? persist_launch<uint32_t>(ctx, s, s->mat->d_counts)
-                            : persist_launch<double>(ctx, s, s->mat->d_freqs);
+    return dvs_mat_dispatch(s->mat, [&](auto *mp) { return persist_launch(ctx, s, mp); });
 }

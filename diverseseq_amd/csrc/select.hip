@@ -27,6 +27,7 @@
 #include "select_dev.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
@@ -1151,12 +1152,11 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     s->time_scan = ctx->timing;
     s->scan_hot = B % (256 * SCAN_CH) == 0 && !order && !labels && s->base_in_lds;
     if (s->scan_lds > 48 * 1024) {
-        const void *fn =
-            m->kind == 0
-                ? (s->scan_hot ? reinterpret_cast<const void *>(scan_kernel<uint32_t, true>)
-                               : reinterpret_cast<const void *>(scan_kernel<uint32_t, false>))
-                : (s->scan_hot ? reinterpret_cast<const void *>(scan_kernel<double, true>)
-                               : reinterpret_cast<const void *>(scan_kernel<double, false>));
+        const void *fn = dvs_mat_dispatch(m, [&](auto *mp) -> const void * {
+            using T = std::remove_cv_t<std::remove_pointer_t<decltype(mp)>>;
+            return s->scan_hot ? reinterpret_cast<const void *>(scan_kernel<T, true>)
+                               : reinterpret_cast<const void *>(scan_kernel<T, false>);
+        });
         const int lrc = dvs_raise_dyn_lds(ctx, fn, s->scan_lds);
         if (lrc) {
             sel_free(s);
@@ -1272,8 +1272,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     s->ctl0 = c;  // (sel_seed adds the window policy of the engine in charge and uploads it)
     s->seed_positions = seeds;
 
-    int rc = (m->kind == 0) ? sel_start<uint32_t>(ctx, s, m->d_counts)
-                            : sel_start<double>(ctx, s, m->d_freqs);
+    int rc = dvs_mat_dispatch(m, [&](auto *mp) { return sel_start(ctx, s, mp); });
     if (rc) {
         sel_free(s);
         return rc;
@@ -1373,12 +1372,12 @@ extern "C" int dvs_select_delta_jsd(dvs_ctx *ctx, const dvs_select *s, const dvs
         DVS_HIP(ctx, hipMemcpyAsync(d_lab, qlabels, size_t(q->nrows) * 4, hipMemcpyHostToDevice,
                                     ctx->stream));
     }
-    if (q->kind == 0)
-        hipLaunchKernelGGL((score_kernel<uint32_t>), dim3(q->nrows), dim3(LOO_THREADS), 0, ctx->stream,
-                           s->dev, q->d_counts, q->d_totals, q->d_entropy, d_lab, d_out);
-    else
-        hipLaunchKernelGGL((score_kernel<double>), dim3(q->nrows), dim3(LOO_THREADS), 0, ctx->stream,
-                           s->dev, q->d_freqs, q->d_totals, q->d_entropy, d_lab, d_out);
+    dvs_mat_dispatch(q, [&](auto *qp) {
+        using T = std::remove_cv_t<std::remove_pointer_t<decltype(qp)>>;
+        hipLaunchKernelGGL((score_kernel<T>), dim3(q->nrows), dim3(LOO_THREADS), 0, ctx->stream, s->dev, qp,
+                           q->d_totals, q->d_entropy, d_lab, d_out);
+        return 0;
+    });
     DVS_HIP(ctx, hipGetLastError());
     DVS_HIP(ctx, hipMemcpyAsync(out, d_out, size_t(q->nrows) * 8, hipMemcpyDeviceToHost, ctx->stream));
     DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1523,8 +1522,7 @@ static int step_scan(dvs_ctx *ctx, dvs_select *s, const T *mat) {
 
 extern "C" int dvs_select_step_scan(dvs_ctx *ctx, dvs_select *s, void *d_event_i64) {
     if (!ctx || !s || !d_event_i64) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
-    int rc = s->mat_kind == 0 ? step_scan<uint32_t>(ctx, s, s->mat->d_counts)
-                              : step_scan<double>(ctx, s, s->mat->d_freqs);
+    int rc = dvs_mat_dispatch(s->mat, [&](auto *mp) { return step_scan(ctx, s, mp); });
     if (rc) return rc;
     hipLaunchKernelGGL(export_event_kernel, dim3(1), dim3(1), 0, ctx->stream, s->dev.ctl,
                        static_cast<long long *>(d_event_i64));
@@ -1536,12 +1534,11 @@ extern "C" int dvs_select_step_fetch(dvs_ctx *ctx, dvs_select *s, const void *d_
     if (!ctx || !s || !d_event_i64 || !d_row) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
     hipLaunchKernelGGL(import_event_kernel, dim3(1), dim3(1), 0, ctx->stream, s->dev.ctl,
                        static_cast<const long long *>(d_event_i64));
-    if (s->mat_kind == 0)
-        hipLaunchKernelGGL((fetch_candidate_kernel<uint32_t>), dim3(1), dim3(LOO_THREADS), 0, ctx->stream,
-                           s->dev, s->mat->d_counts, d_row);
-    else
-        hipLaunchKernelGGL((fetch_candidate_kernel<double>), dim3(1), dim3(LOO_THREADS), 0, ctx->stream,
-                           s->dev, s->mat->d_freqs, d_row);
+    dvs_mat_dispatch(s->mat, [&](auto *mp) {
+        using T = std::remove_cv_t<std::remove_pointer_t<decltype(mp)>>;
+        hipLaunchKernelGGL((fetch_candidate_kernel<T>), dim3(1), dim3(LOO_THREADS), 0, ctx->stream, s->dev, mp, d_row);
+        return 0;
+    });
     DVS_HIP(ctx, hipGetLastError());
     return DVS_OK;
 }
@@ -1549,8 +1546,10 @@ extern "C" int dvs_select_step_fetch(dvs_ctx *ctx, dvs_select *s, const void *d_
 extern "C" int dvs_select_step_apply(dvs_ctx *ctx, dvs_select *s, const double *d_row) {
     if (!ctx || !s || !d_row) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
     s->dev.cand_ext = d_row;
-    if (s->mat_kind == 0) launch_iteration<uint32_t>(ctx, s, s->mat->d_counts, 1);
-    else launch_iteration<double>(ctx, s, s->mat->d_freqs, 1);
+    dvs_mat_dispatch(s->mat, [&](auto *mp) {
+        launch_iteration(ctx, s, mp, 1);
+        return 0;
+    });
     DVS_HIP(ctx, hipGetLastError());
     return DVS_OK;
 }
@@ -1598,20 +1597,18 @@ extern "C" int dvs_select_bench_scan(dvs_ctx *ctx, const dvs_select *s, int repe
     hipEvent_t e0 = dvs_event_get(ctx), e1 = dvs_event_get(ctx);
     const SelDev &d = s->dev;
     auto launch = [&]() {
-        if (s->mat_kind == 0) {
+        dvs_mat_dispatch(s->mat, [&](auto *mp) {
+            using T = std::remove_cv_t<std::remove_pointer_t<decltype(mp)>>;
             if (s->scan_hot)
-                hipLaunchKernelGGL((scan_kernel<uint32_t, true>), dim3(s->scan_grid), dim3(SCAN_THREADS),
-                                   s->scan_lds, ctx->stream, d_c, s->mat->d_counts, d.totals, d.rowH, d.order,
-                                   d.labels, d.inset, d.nlabels, d.base, d_rows, d.B, s->base_in_lds ? 1 : 0);
+                hipLaunchKernelGGL((scan_kernel<T, true>), dim3(s->scan_grid), dim3(SCAN_THREADS), s->scan_lds,
+                                   ctx->stream, d_c, mp, d.totals, d.rowH, d.order, d.labels, d.inset, d.nlabels,
+                                   d.base, d_rows, d.B, s->base_in_lds ? 1 : 0);
             else
-                hipLaunchKernelGGL((scan_kernel<uint32_t, false>), dim3(s->scan_grid), dim3(SCAN_THREADS),
-                                   s->scan_lds, ctx->stream, d_c, s->mat->d_counts, d.totals, d.rowH, d.order,
-                                   d.labels, d.inset, d.nlabels, d.base, d_rows, d.B, s->base_in_lds ? 1 : 0);
-        } else {
-            hipLaunchKernelGGL((scan_kernel<double, false>), dim3(s->scan_grid), dim3(SCAN_THREADS),
-                               s->scan_lds, ctx->stream, d_c, s->mat->d_freqs, d.totals, d.rowH, d.order,
-                               d.labels, d.inset, d.nlabels, d.base, d_rows, d.B, s->base_in_lds ? 1 : 0);
-        }
+                hipLaunchKernelGGL((scan_kernel<T, false>), dim3(s->scan_grid), dim3(SCAN_THREADS), s->scan_lds,
+                                   ctx->stream, d_c, mp, d.totals, d.rowH, d.order, d.labels, d.inset, d.nlabels,
+                                   d.base, d_rows, d.B, s->base_in_lds ? 1 : 0);
+            return 0;
+        });
     };
     hipError_t e = hipMemcpyAsync(d_c, &c, sizeof c, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_rows, 0, size_t(s->scan_grid) * 8, ctx->stream);

@@ -87,6 +87,7 @@ __device__ __forceinline__ double sel_band(double hmean, uint64_t B) {
 }
 
 __device__ __forceinline__ double row_value(const uint32_t *row, uint64_t i) { return double(row[i]); }
+__device__ __forceinline__ double row_value(const uint16_t *row, uint64_t i) { return double(row[i]); }
 __device__ __forceinline__ double row_value(const double *row, uint64_t i) { return row[i]; }
 
 // ---------------------------------------------------------------- scan kernel
@@ -148,6 +149,24 @@ __device__ __forceinline__ float coarse4(const uint4 c, const float4 b, const dv
     return s.x + s.y;
 }
 
+// the same for a row of 16-bit counts: four bins in two words
+__device__ __forceinline__ float coarse4(const uint2 c, const float4 b, const dvs_f2 r2) {
+    const dvs_f2 c01 = {float(c.x & 0xFFFFu), float(c.x >> 16)}, c23 = {float(c.y & 0xFFFFu), float(c.y >> 16)};
+    const dvs_f2 y01 = __builtin_elementwise_fma(c01, r2, (dvs_f2){b.x, b.y});
+    const dvs_f2 y23 = __builtin_elementwise_fma(c23, r2, (dvs_f2){b.z, b.w});
+    const dvs_f2 l01 = {__builtin_amdgcn_logf(y01.x), __builtin_amdgcn_logf(y01.y)};
+    const dvs_f2 l23 = {__builtin_amdgcn_logf(y23.x), __builtin_amdgcn_logf(y23.y)};
+    const dvs_f2 s = y01 * l01 + y23 * l23;
+    return s.x + s.y;
+}
+
+// eight consecutive 16-bit counts from ONE 16-byte load (a wave instruction reads 1 KiB of the row, as
+// it does for 32-bit counts): two groups of four, each folded in f32 and added in f64 like coarse4's
+__device__ __forceinline__ void coarse8(const uint4 c, const float *b, const dvs_f2 r2, double &a0, double &a1) {
+    a0 += double(coarse4(make_uint2(c.x, c.y), *reinterpret_cast<const float4 *>(b), r2));
+    a1 += double(coarse4(make_uint2(c.z, c.w), *reinterpret_cast<const float4 *>(b + 4), r2));
+}
+
 // 4 consecutive bins as they sit in memory (converted to f64 only when consumed, so a
 // batch of in-flight chunks costs 4 VGPRs each for a count matrix)
 template <typename T> struct Raw4;
@@ -158,6 +177,14 @@ template <> struct Raw4<uint32_t> {
     __device__ __forceinline__ void pin() { asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w)); }
     __device__ __forceinline__ void get(double &v0, double &v1, double &v2, double &v3) const {
         v0 = double(c.x); v1 = double(c.y); v2 = double(c.z); v3 = double(c.w);
+    }
+};
+template <> struct Raw4<uint16_t> {  // 16-bit counts (rows of whole sequences): 8 bytes per four bins
+    uint2 c;
+    __device__ __forceinline__ void load(const uint16_t *p) { c = *reinterpret_cast<const uint2 *>(p); }
+    __device__ __forceinline__ void pin() { asm volatile("" : "+v"(c.x), "+v"(c.y)); }
+    __device__ __forceinline__ void get(double &v0, double &v1, double &v2, double &v3) const {
+        v0 = double(c.x & 0xFFFFu); v1 = double(c.x >> 16); v2 = double(c.y & 0xFFFFu); v3 = double(c.y >> 16);
     }
 };
 template <> struct Raw4<double> {
@@ -178,6 +205,9 @@ __device__ __forceinline__ void load4(const T *rp, uint64_t i, double &v0, doubl
     if constexpr (sizeof(T) == 4) {
         const uint4 c = *reinterpret_cast<const uint4 *>(rp + i);
         v0 = double(c.x); v1 = double(c.y); v2 = double(c.z); v3 = double(c.w);
+    } else if constexpr (sizeof(T) == 2) {
+        const uint2 c = *reinterpret_cast<const uint2 *>(rp + i);
+        v0 = double(c.x & 0xFFFFu); v1 = double(c.x >> 16); v2 = double(c.y & 0xFFFFu); v3 = double(c.y >> 16);
     } else {
         const double2 a = *reinterpret_cast<const double2 *>(rp + i);
         const double2 b = *reinterpret_cast<const double2 *>(rp + i + 2);
@@ -228,6 +258,7 @@ __device__ __forceinline__ bool precise_row(const T *rp, const double *bvec, uin
 __device__ __forceinline__ double cand_freq(const uint32_t *row, uint64_t i, double tot) {
     return double(row[i]) / tot;  // record.rs:139, correctly rounded
 }
+__device__ __forceinline__ double cand_freq(const uint16_t *row, uint64_t i, double tot) { return double(row[i]) / tot; }
 __device__ __forceinline__ double cand_freq(const double *row, uint64_t i, double) { return row[i]; }
 
 // The same quotient without the ~35-instruction f64 division: with rt = RN(1 / tot) (one real
@@ -245,8 +276,12 @@ __device__ __forceinline__ double exact_div_u32(double c, double tot, double rt)
 __device__ __forceinline__ double cand_freq_x(const uint32_t *row, uint64_t i, double tot, double rt) {
     return exact_div_u32(double(row[i]), tot, rt);
 }
+__device__ __forceinline__ double cand_freq_x(const uint16_t *row, uint64_t i, double tot, double rt) {
+    return exact_div_u32(double(row[i]), tot, rt);
+}
 __device__ __forceinline__ double cand_freq_x(const double *row, uint64_t i, double, double) { return row[i]; }
 __device__ __forceinline__ double count_freq_x(uint32_t c, double tot, double rt) { return exact_div_u32(double(c), tot, rt); }
+__device__ __forceinline__ double count_freq_x(uint16_t c, double tot, double rt) { return exact_div_u32(double(c), tot, rt); }
 __device__ __forceinline__ double count_freq_x(double f, double, double) { return f; }
 
 // (sum, min, sum) over the block in ONE barrier pair; every thread gets the result.

@@ -299,6 +299,11 @@ class CountMatrix:
     def dev_counts(self) -> int:
         return int(self.ctx._L.dvs_matrix_dev_counts(self._h) or 0)
 
+    @property
+    def count_bytes(self) -> int:
+        """width of a count on the device: 4, or 2 when every sequence was a single tile (0: frequency rows)"""
+        return int(self.ctx._L.dvs_matrix_count_bytes(self._h))
+
     # ---- selection -----------------------------------------------------------
     def select(self, mode: int, n_seed: int, *, max_size: int = 0, stat: int = _lib.STAT_STDEV,
                order=None, labels=None, npos: int | None = None, window: int = 0,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DVS_ABI_VERSION 1
+#define DVS_ABI_VERSION 2
 
 #define DVS_OK 0
 #define DVS_ERR_VALUE 1       /* the reference would panic -> python ValueError */
@@ -97,10 +97,15 @@ void dvs_matrix_destroy(dvs_matrix *m);
 uint32_t dvs_matrix_nrows(const dvs_matrix *m);
 uint64_t dvs_matrix_nbins(const dvs_matrix *m);
 /* device pointers (for zero-copy hand-off to the host framework) */
-const void *dvs_matrix_dev_counts(const dvs_matrix *m);  /* uint32 [nrows x nbins] or NULL */
+/* counts [nrows x nbins], or NULL for a frequency matrix.  The elements are uint32, or uint16 when
+ * every sequence of the build was at most 32768 k-mer windows long (no count can reach 2^16; the
+ * build's write and the scan's read move half the bytes): dvs_matrix_count_bytes says which (4, 2;
+ * 0 for a frequency matrix).  DVS_COUNTS_U32=1 in the environment keeps every build at uint32. */
+const void *dvs_matrix_dev_counts(const dvs_matrix *m);
+uint32_t dvs_matrix_count_bytes(const dvs_matrix *m);
 const void *dvs_matrix_dev_totals(const dvs_matrix *m);  /* uint32 [nrows] */
 const void *dvs_matrix_dev_entropy(const dvs_matrix *m); /* double [nrows] */
-/* copies to host: counts rows [row0, row0+nrows) */
+/* copies to host: counts rows [row0, row0+nrows), widened to uint32 whatever the device width */
 int dvs_matrix_get_counts(dvs_ctx *ctx, const dvs_matrix *m, uint32_t row0,
                           uint32_t nrows, uint32_t *out);
 int dvs_matrix_get_totals(dvs_ctx *ctx, const dvs_matrix *m, uint32_t *out);

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(str(_lib.LIB_PATH))
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in dvs_hip.h but not exported"
-    assert _lib.load().dvs_abi_version() == 1
+    assert _lib.load().dvs_abi_version() == 2
 
 
 def test_product_never_imports_oracle():

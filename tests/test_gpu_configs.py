@@ -122,6 +122,56 @@ def test_persistent_engine_falls_back_to_the_multi_launch_engine(ctx, monkeypatc
     _assert_selection(sel, oracle.max_divergent(seqs, 4, 30, 5, 4, "stdev"))
 
 
+# ---------------------------------------------------------------- both count widths
+@pytest.mark.parametrize("u32", [False, True])
+def test_count_rows_in_both_widths(ctx, u32, monkeypatch):
+    """whole sequences (<= 32768 windows each) build 16-bit count rows, DVS_COUNTS_U32 keeps them at
+    32 bits: the same counts, entropies and selections either way (record.rs:41-84, records.rs:311-454),
+    on both engines and at 4^6 and 4^7 bins; a genome-length row keeps the matrix at 32 bits"""
+    if u32:
+        monkeypatch.setenv("DVS_COUNTS_U32", "1")
+    width = 4 if u32 else 2
+    seqs = synth_seqs(3000, 3000, 55, invalid_frac=0.001, ragged=True)
+    seqs[7] = np.full(32768 + 2, 1, dtype=np.uint8)  # a single tile for every k >= 3 below: one bin takes ~32768 counts
+    for k, n in ((6, 10), (6, 70), (7, 12), (3, 6), (5, 9)):
+        m = ctx.build_matrix(seqs, k, 4)
+        assert m.count_bytes == width
+        got = m.counts().astype(np.uint64)
+        for i in (0, 7, 1500, 2999):
+            assert (got[i] == oracle.count_kmers(seqs[i], 4, k)).all()
+        H = m.entropy()
+        for i in (0, 7, 2999):
+            assert abs(H[i] - oracle.to_kfreqs(seqs[i], 4, k)[1]) <= 1e-11 * max(1.0, H[i])
+        exp = oracle.nmost(seqs, n, k, 4)
+        sel = m.nmost(n)
+        assert sel.summary().engine == 1
+        _assert_selection(sel, exp)
+        monkeypatch.setenv("DVS_NO_PERSIST", "1")
+        sel = m.nmost(n)
+        assert sel.summary().engine == 0
+        _assert_selection(sel, exp)
+        monkeypatch.delenv("DVS_NO_PERSIST")
+        if k == 6:
+            _assert_selection(m.max_divergent(5, 60, "stdev"), oracle.max_divergent(seqs, 5, 60, k, 4, "stdev"))
+            from diverseseq_amd import distance
+
+            d = distance.euclidean_distances(seqs[:40], k, 4, ctx=ctx)  # (tiled kernel, either width)
+            fr = [oracle.to_kfreqs(s_, 4, k)[0] for s_ in seqs[:40]]
+            for i, j in ((1, 0), (7, 3), (39, 38), (20, 7)):
+                assert abs(d[i, j] - oracle.euclidean_distance(fr[i], fr[j])) <= 1e-9
+                assert d[i, j] == d[j, i]
+    # a sequence of more than one tile: 32-bit rows whatever the knob says
+    m = ctx.build_matrix(seqs[:20] + [np.zeros(40_000, dtype=np.uint8)], 6, 4)
+    assert m.count_bytes == 4
+    assert int(m.counts(20, 1)[0][0]) == 40_000 - 5
+    # other alphabets take the same path (20 states, k=2: 400 bins)
+    prot = [np.random.default_rng(i).integers(0, 21, size=900, dtype=np.uint8) for i in range(300)]
+    m = ctx.build_matrix(prot, 2, 20)
+    assert m.count_bytes == width
+    assert (m.counts(5, 1)[0] == oracle.count_kmers(prot[5], 20, 2)).all()
+    _assert_selection(m.nmost(7), oracle.nmost(prot, 7, 2, 20))
+
+
 # ---------------------------------------------------------------- candidates inside the bands
 COARSE_BAND_K6 = 1.25 * 2.0**-24 * (9.0 * 12 + 7.4)  # select_dev.h coarse_band(4096)
 FAST_BAND = 4e-7                                       # select_dev.h
@@ -213,11 +263,11 @@ def test_candidates_inside_the_f32_bands_k6(ctx, band_k6, env, monkeypatch):
     # the same prefix without the crafted rows: what the bands cost on ordinary input
     m0 = ctx.build_matrix(seqs[:nprefix], 6, 4)
     s0 = m0.nmost(10).summary()
-    sure_fast = sum(1 for g in margins[len(MULTS):] if abs(g) <= 0.5 * FAST_BAND)
+    sure_fast = sum(1 for g in margins[len(MULTS):] if abs(g) <= 0.6 * FAST_BAND)
     assert sure_fast >= 4
     assert s.rows_rechecked >= s0.rows_rechecked + sure_fast, (s.rows_rechecked, s0.rows_rechecked)
     if s.engine == 1:
-        sure_coarse = sum(1 for g in margins if abs(g) <= 0.5 * COARSE_BAND_K6)
+        sure_coarse = sum(1 for g in margins if abs(g) <= 0.6 * COARSE_BAND_K6)
         assert sure_coarse >= 4 + len(MULTS)
         assert s.rows_coarse_passed >= s0.rows_coarse_passed + sure_coarse, (s.rows_coarse_passed, s0.rows_coarse_passed)
 
@@ -234,7 +284,7 @@ def test_candidates_inside_the_fast_band_k7(ctx, band_k7, env, monkeypatch):
     s = _assert_selection(m.nmost(10), exp)
     assert s.n_arbitrated == 0
     s0 = ctx.build_matrix(seqs[:300], 7, 4).nmost(10).summary()
-    sure = sum(1 for g in margins if abs(g) <= 0.5 * FAST_BAND)
+    sure = sum(1 for g in margins if abs(g) <= 0.6 * FAST_BAND)
     assert s.rows_rechecked >= s0.rows_rechecked + sure >= 4
 
 

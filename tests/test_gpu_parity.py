@@ -938,6 +938,10 @@ def test_device_side_chunk_merge(ctx, brca1):
     gids = _global_ids(all_meta, [a for a, _ in bounds], cap)
     assert gids[gids >= 0].tolist() == eids.tolist()
     mm = ctx.matrix_from_device_freqs(all_rows.data_ptr(), 3 * cap, B, all_meta.data_ptr())
+    # the matrix keeps the real rows first, in their gathered order, and the padding behind them
+    src = mm.source_rows()
+    assert src.tolist() == [0, 1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 13, 14, 8, 9]
+    gids = _global_ids(all_meta, [a for a, _ in bounds], cap, src_rows=src)
     got = mm.nmost(n)
     exp = oracle.final_nmost(erows, n, labels=eids)
     gm = got.members()
@@ -946,6 +950,42 @@ def test_device_side_chunk_merge(ctx, brca1):
     np.testing.assert_allclose(got.summary().total_jsd, exp.total_jsd, rtol=RTOL)
     with pytest.raises(ValueError, match="buffer of"):
         sel.gather_members(all_rows.data_ptr(), all_meta.data_ptr(), 2)
+
+
+def test_device_side_chunk_merge_short_first_chunk(ctx, brca1):
+    """the FIRST chunk holds fewer than n sequences: the merge still seeds from the first n real
+    records of the concatenated results (get_kmerseqs_and_init_summed_records, records.rs:344-360),
+    not from the first n rows of the padded gather"""
+    import torch
+
+    from diverseseq_amd.parallel import _global_ids
+
+    seqs = list(brca1.values())
+    bounds = [(0, 3), (3, 30), (30, 55)]
+    n, cap, k = 5, 5, 4
+    B = 4 ** k
+    dev = torch.device("cuda:0")
+    all_rows = torch.zeros((3 * cap, B), dtype=torch.float64, device=dev)
+    all_meta = torch.zeros((3 * cap, 2), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    erows, eids = [], []
+    for r, (a, b) in enumerate(bounds):
+        m = ctx.build_matrix(seqs[a:b], k, 4)
+        sel = m.nmost(min(n, b - a))
+        sel.gather_members(all_rows[r * cap:].data_ptr(), all_meta[r * cap:].data_ptr(), cap)
+        ctx.sync()
+        l, _, _, f = oracle.nmost(seqs[a:b], min(n, b - a), k, 4).members(with_freqs=True)
+        erows.append(f)
+        eids.append(l + a)
+    erows, eids = np.vstack(erows), np.concatenate(eids)
+    mm = ctx.matrix_from_device_freqs(all_rows.data_ptr(), 3 * cap, B, all_meta.data_ptr())
+    gids = _global_ids(all_meta, [a for a, _ in bounds], cap, src_rows=mm.source_rows())
+    got = mm.nmost(n)
+    exp = oracle.final_nmost(erows, n, labels=eids)
+    assert got.summary().size == n == exp.size
+    gm = got.members()
+    assert [int(gids[p]) for p in gm.positions] == exp.members()[0].tolist()
+    np.testing.assert_allclose(gm.delta_jsd, exp.members()[1], rtol=RTOL, atol=1e-13)
 
 
 def test_merge_nmost_over_rccl_world1(ctx, brca1):
