@@ -169,6 +169,14 @@ int dvs_raise_dyn_lds(dvs_ctx *ctx, const void *fn, size_t bytes) {
     return DVS_OK;
 }
 
+hipStream_t dvs_ctx_stream2(dvs_ctx *ctx) {
+    if (!ctx->stream2 && hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->stream2 = nullptr;
+    }
+    return ctx->stream2;
+}
+
 void dvs_ctx_retain(dvs_ctx *ctx) {
     if (ctx) ctx->refs++;
 }
@@ -183,6 +191,7 @@ void dvs_ctx_release(dvs_ctx *ctx) {
     dvs_dev_trim(ctx);
     for (void *p : ctx->pinned_pool) (void)hipHostFree(p);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -13,11 +13,14 @@
 #include "../../include/dvs_hip.h"
 
 #define DVS_EPS 2.220446049250313e-16  // f64::EPSILON
+#define DVS_HEAD_ROWS 2048u            // rows of a split build's first launch (kmer_hist.hip, head.hip)
 
 struct dvs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t stream2 = nullptr;  // second stream (created on first use): a selection's set-up and head engine
+                                    // beside the histogram of the rest of the matrix
     int n_cu = 0;
     size_t lds_per_block = 0;  // max dynamic LDS a block may ask for
     double *d_clog_tbl = nullptr;  // c log2 c, c < 256 (kmer_hist.hip)
@@ -57,6 +60,7 @@ struct dvs_ctx {
 // hipFuncAttributeMaxDynamicSharedMemorySize >= bytes for kernel fn on this context's device
 int dvs_raise_dyn_lds(dvs_ctx *ctx, const void *fn, size_t bytes);
 void dvs_ctx_retain(dvs_ctx *ctx);
+hipStream_t dvs_ctx_stream2(dvs_ctx *ctx);  // NULL when it cannot be created
 void dvs_ctx_release(dvs_ctx *ctx);
 
 // waits for a build that is still in flight (no-op otherwise) and moves the head totals to the vector
@@ -101,6 +105,9 @@ struct dvs_matrix {
     uint32_t *h_head_pinned = nullptr;
     hipEvent_t ev_built = nullptr;
     uint32_t head_count = 0;
+    // rows [0, head_rows_built) were built by a launch of their own, finished when ev_built fires; the
+    // rest of the matrix may still be in flight on the context's stream after that (0: no such split)
+    uint32_t head_rows_built = 0;
     int device = 0;
     dvs_ctx *ctx = nullptr;  // owner of the allocations
 };

@@ -98,7 +98,7 @@ __device__ __forceinline__ void h_block_sums(double (&v)[NV], double *scratch) {
 template <typename T>
 __host__ __device__ constexpr size_t head_lds_bytes(uint64_t B, uint32_t n) {
     return B * 8 + B * 4 + size_t(n + 1) * B * sizeof(T) + (64 + 2 * H_MAXN * H_WAVES) * 8 + 4 * (H_MAXN + 1) * 8 +
-           (H_MAXN + 1) * 8 + 2 * (H_MAXN + 1) * 4 + 8 + 128 * 16;
+           (H_MAXN + 1) * 8 + 2 * (H_MAXN + 1) * 4 + 32 + 128 * 16;
 }
 
 template <typename T>
@@ -121,8 +121,7 @@ __global__ __launch_bounds__(H_THREADS) void head_nmost_kernel(SelDev d, const T
     uint64_t *s_pos = reinterpret_cast<uint64_t *>(s_res + (H_MAXN + 1));
     uint32_t *s_slot = reinterpret_cast<uint32_t *>(s_pos + (H_MAXN + 1));
     uint32_t *s_row = s_slot + (H_MAXN + 1);
-    double2 *s_ltab = reinterpret_cast<double2 *>(s_row + (H_MAXN + 1) + 2);
-    static_assert((H_MAXN + 1) % 2 == 1, "s_ltab offset below assumes an odd count of u32 pairs");
+    double2 *s_ltab = reinterpret_cast<double2 *>((reinterpret_cast<uintptr_t>(s_row + (H_MAXN + 1)) + 15) & ~uintptr_t(15));
 
     const int tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -195,35 +194,38 @@ __global__ __launch_bounds__(H_THREADS) void head_nmost_kernel(SelDev d, const T
     uint32_t par = 0;
     const double cband = coarse_band(B);
 
-    // one candidate (the row in w, stream position p): false = the head phase ends here (event unconsumed)
-    auto process = [&](Row &w) -> bool {
-        if (w.tot == 0) return true;  // "No valid k-mers": skipped (records.rs:332-335)
-        const double tot = double(w.tot), rt = 1.0 / tot;
-        const double he_base = sumH - s_mH[li];
-        const double mean_entropy = (he_base + w.hrow) / dn;
-        // ---- COARSE
-        {
-            const float rtn = float(rt * rn);
-            const dvs_f2 r2 = {rtn, rtn};
-            double c0 = 0.0, c1 = 0.0;
-            w.c.pin();
-            if (active) w.c.coarse(slf + i0, r2, c0, c1);
-            const double cs = dvs_wave_sum_dpp(c0 + c1);
-            double *slot = red + par * 16;
-            par ^= 1;
-            if (lane == 0) slot[wave] = cs;
-            __syncthreads();
-            double hc = 0.0;
+    // COARSE tier on one row: 0 = rejected (or no valid k-mers), 1 = the FAST tier must look, 2 = sure event.
+    // Small on purpose: it is the only code expanded once per ring slot.
+    auto coarse = [&](Row &w) -> int {
+        if (w.tot == 0) return 0;  // "No valid k-mers": skipped (records.rs:332-335)
+        const double rt = 1.0 / double(w.tot);
+        const float rtn = float(rt * rn);
+        const dvs_f2 r2 = {rtn, rtn};
+        double c0 = 0.0, c1 = 0.0;
+        w.c.pin();
+        if (active) w.c.coarse(slf + i0, r2, c0, c1);
+        const double cs = dvs_wave_sum_dpp(c0 + c1);
+        double *slot = red + par * 16;
+        par ^= 1;
+        if (lane == 0) slot[wave] = cs;
+        __syncthreads();
+        double hc = 0.0;
 #pragma unroll
-            for (int q = 0; q < H_WAVES; q++) hc += slot[q];
-            const double jf0 = -hc - mean_entropy;
-            if (tid == 0) nread++;
-            if (!(jf0 > thr - band - cband)) return true;  // (NaN: a negative bin, rejected as the reference does)
-            if (jf0 > thr + band + cband) goto accept;
+        for (int q = 0; q < H_WAVES; q++) hc += slot[q];
+        const double jf0 = -hc - ((sumH - s_mH[li]) + w.hrow) / dn;
+        if (tid == 0) nread++;
+        if (!(jf0 > thr - band - cband)) return 0;  // (NaN: a negative bin, rejected as the reference does)
+        return jf0 > thr + band + cband ? 2 : 1;
+    };
+
+    // Everything past the COARSE tier for the row in `w` at stream position p.  Returns false when the
+    // head phase must end here with the event unconsumed (a decision inside the rounding band).
+    auto heavy = [&](Row &w, int tier) -> bool {
+        const double tot = double(w.tot), rt = 1.0 / tot;
+        const double mean_entropy = ((sumH - s_mH[li]) + w.hrow) / dn;
+        bool sure = tier == 2;
+        if (!sure) {  // ---- FAST
             if (tid == 0) nmid++;
-        }
-        // ---- FAST
-        {
             double v[2] = {0.0, 0.0};  // (sum of -x log2 x, number of negative bins)
             if (active) {
 #pragma unroll
@@ -236,11 +238,10 @@ __global__ __launch_bounds__(H_THREADS) void head_nmost_kernel(SelDev d, const T
             h_block_sums<2>(v, scratch);
             const double jf = v[0] - mean_entropy;
             if (v[1] != 0.0 || !(jf > thr - band - FAST_BAND)) return true;
-            if (jf > thr + band + FAST_BAND) goto accept;
-            if (tid == 0) nprecise++;
+            sure = jf > thr + band + FAST_BAND;
         }
-        // ---- exact f64, the reference's per-bin order (records.rs:78-81)
-        {
+        if (!sure) {  // ---- exact f64, the reference's per-bin order (records.rs:78-81)
+            if (tid == 0) nprecise++;
             Ent e;
             if (active) {
 #pragma unroll
@@ -257,35 +258,37 @@ __global__ __launch_bounds__(H_THREADS) void head_nmost_kernel(SelDev d, const T
             if (!(jsd > thr)) return true;  // rejected (NaN included, records.rs:91)
             n_events--;
         }
-    accept:
         n_events++;
-        {
-            // ================= replace_lowest (records.rs:94-147), computed before anything is stored
-            double fr[H_NB], sn[H_NB];
-            const double sumH_n = (sumH - s_mH[li]) + w.hrow;
-            double tv[2] = {0.0, 0.0};  // whole set: entropy terms and sum of S' / n
-            if (active) {
+        // ================= replace_lowest (records.rs:94-147), computed before anything is stored
+        double fr[H_NB], sn[H_NB];
+        const double sumH_n = (sumH - s_mH[li]) + w.hrow;
+        double tv[2] = {0.0, 0.0};  // whole set: entropy terms and sum of S' / n
+        if (active) {
 #pragma unroll
-                for (int j = 0; j < H_NB; j++) {
-                    fr[j] = exact_div_u32(double(w.c.at(j)), tot, rt);
-                    double v = S[i0 + j] - mfreq(li, j);  // drop_lowest, with its clamp
-                    if (v <= DVS_EPS) v = 0.0;
-                    sn[j] = v + fr[j];                     // push
-                    const double u = sn[j] * rn;
-                    if (u > 0.0) tv[0] -= u * log2_tab(u, s_ltab);
-                    tv[1] += u;
-                }
+            for (int j = 0; j < H_NB; j++) {
+                fr[j] = exact_div_u32(double(w.c.at(j)), tot, rt);
+                double v = S[i0 + j] - mfreq(li, j);  // drop_lowest, with its clamp
+                if (v <= DVS_EPS) v = 0.0;
+                sn[j] = v + fr[j];                     // push
+                const double u = sn[j] * rn;
+                if (u > 0.0) tv[0] -= u * log2_tab(u, s_ltab);
+                tv[1] += u;
             }
-            h_block_sums<2>(tv, scratch);
-            const double tj = tv[0] - sumH_n / dn;
-            if (sum_risky(tv[1], B) || !(tv[0] == tv[0])) return false;
-            const double band_n = sel_band(tj + sumH_n / dn, B);
-            // ---- leave-one-out, FAST tier (get_lowest_record_index, records.rs:220-252): member r of the
-            // NEW order is member r of the old one before the lowest, r + 1 after it; the candidate is n - 1
-            double acc[2 * H_MAXN];
+        }
+        h_block_sums<2>(tv, scratch);
+        const double tj = tv[0] - sumH_n / dn;
+        if (sum_risky(tv[1], B) || !(tv[0] == tv[0])) return false;
+        const double band_n = sel_band(tj + sumH_n / dn, B);
+        // ---- leave-one-out, FAST tier (get_lowest_record_index, records.rs:220-252), four members at a
+        // time: member r of the NEW order is member r of the old one before the lowest, r + 1 after it;
+        // the candidate is member n - 1.  delta_jsd of member r -> s_res[r]; the sums are exact f64 adds.
+        bool risky = false;
+        for (uint32_t r0 = 0; r0 < n; r0 += 4) {
+            double acc[8];
 #pragma unroll
-            for (uint32_t r = 0; r < H_MAXN; r++) {
-                acc[2 * r] = acc[2 * r + 1] = 0.0;
+            for (int q = 0; q < 4; q++) {
+                const uint32_t r = r0 + q;
+                acc[2 * q] = acc[2 * q + 1] = 0.0;
                 if (r < n && active) {
                     const uint32_t old = r < li ? r : r + 1;
                     const bool is_new = r == n - 1;
@@ -293,140 +296,168 @@ __global__ __launch_bounds__(H_THREADS) void head_nmost_kernel(SelDev d, const T
                     for (int j = 0; j < H_NB; j++) {
                         double u = (sn[j] - (is_new ? fr[j] : mfreq(old, j))) * rdiv;  // updated_mean_freqs :276-286
                         if (u <= DVS_EPS) u = 0.0;
-                        acc[2 * r] += fast_neg_xlog2x(u);
-                        acc[2 * r + 1] += u;
+                        acc[2 * q] += fast_neg_xlog2x(u);
+                        acc[2 * q + 1] += u;
                     }
                 }
             }
-            h_block_sums<2 * H_MAXN>(acc, scratch);
-            // delta_jsd of every member from the FAST entropies; the sums are exact f64 adds
-            double dl[H_MAXN];
-            double best = 1e6;
-            bool risky = false;
+            h_block_sums<8>(acc, scratch);
 #pragma unroll
-            for (uint32_t r = 0; r < H_MAXN; r++) {
-                dl[r] = 1e6;
+            for (int q = 0; q < 4; q++) {
+                const uint32_t r = r0 + q;
                 if (r < n) {
                     const uint32_t old = r < li ? r : r + 1;
                     const double mh = r == n - 1 ? w.hrow : s_mH[old];
-                    dl[r] = tj - (acc[2 * r] - (sumH_n - mh) * rdiv);
-                    risky |= sum_risky(acc[2 * r + 1], B);
-                    if (dl[r] < best) best = dl[r];
+                    risky |= sum_risky(acc[2 * q + 1], B);
+                    if (tid == 0) s_res[r] = tj - (acc[2 * q] - (sumH_n - mh) * rdiv);
                 }
             }
-            if (risky) return false;
-            // members that could be the reference's argmin: within the FAST band (both ways) and the
-            // reference's own rounding band of the smallest FAST value
-            const double reach = best + 2.0 * FAST_BAND + band_n;
-            uint32_t ncand = 0, lowest = 0;
-#pragma unroll
-            for (uint32_t r = 0; r < H_MAXN; r++)
-                if (r < n && dl[r] <= reach) {
-                    if (ncand == 0) lowest = r;
-                    ncand++;
-                }
-            if (ncand > 1) {
-                // exact f64 for those members only; strict '<' from 1e6, first index (records.rs:231,246-249)
-                double dmin = 1e6, dsec = 1e6;
-                for (uint32_t r = 0; r < n; r++) {
-                    if (!(dl[r] <= reach)) continue;
-                    const uint32_t old = r < li ? r : r + 1;
-                    const bool is_new = r == n - 1;
-                    double ev[2] = {0.0, 0.0};
-                    if (active) {
-#pragma unroll
-                        for (int j = 0; j < H_NB; j++) {
-                            double u = (sn[j] - (is_new ? fr[j] : mfreq(old, j))) * rdiv;
-                            if (u <= DVS_EPS) u = 0.0;
-                            if (u > 0.0) ev[0] -= u * log2_tab(u, s_ltab);
-                            ev[1] += u;
-                        }
-                    }
-                    h_block_sums<2>(ev, scratch);
-                    const double mh = is_new ? w.hrow : s_mH[old];
-                    const double de = tj - (ev[0] - (sumH_n - mh) * rdiv);
-                    if (de < dmin) {
-                        dsec = dmin;
-                        dmin = de;
-                        lowest = r;
-                    } else if (de < dsec) {
-                        dsec = de;
-                    }
-                }
-                if (dsec - dmin <= band_n && dsec < 1e6) return false;  // argmin too close to call
-            }
-            // ================= commit
-            __syncthreads();  // every thread has read the old member arrays and rows
-            const uint32_t row_new = s_row[n], row_old = s_row[li], slot_low = s_slot[li];
-            const uint64_t old_pos = s_pos[li];
-            if (active) {
-                T *dst = Mc + uint64_t(row_new) * B + i0;
-#pragma unroll
-                for (int j = 0; j < H_NB; j++) {
-                    dst[j] = T(w.c.at(j));
-                    S[i0 + j] = sn[j];
-                }
-            }
-            if (wave == 0) {  // Vec::remove(li) + push by one wave (reads before the dependent writes)
-                const uint32_t i = li + lane;
-                const bool mv = i + 1 < n;
-                uint32_t a = 0, rw = 0;
-                uint64_t c = 0;
-                double b = 0.0, t = 1.0, r1 = 1.0;
-                if (mv) {
-                    a = s_slot[i + 1];
-                    rw = s_row[i + 1];
-                    b = s_mH[i + 1];
-                    c = s_pos[i + 1];
-                    t = s_tot[i + 1];
-                    r1 = s_rt[i + 1];
-                }
-                if (mv) {
-                    s_slot[i] = a;
-                    s_row[i] = rw;
-                    s_mH[i] = b;
-                    s_pos[i] = c;
-                    s_tot[i] = t;
-                    s_rt[i] = r1;
-                }
-                if (lane == 0) {
-                    s_slot[n - 1] = slot_low;
-                    s_row[n - 1] = row_new;
-                    s_row[n] = row_old;  // the dropped member's row is the spare now
-                    s_mH[n - 1] = w.hrow;
-                    s_pos[n - 1] = p;
-                    s_tot[n - 1] = tot;
-                    s_rt[n - 1] = rt;
-                    // identity order, unique ids: label = stream position
-                    if (old_pos < d.nlabels) d.inset[old_pos] = 0;
-                    if (p < d.nlabels) d.inset[p] = 1;
-                    d.evlog_pos[ctl->n_logged + n_accepts] = p;
-                    d.evlog_kind[ctl->n_logged + n_accepts] = 1;
-                }
-            }
-            __syncthreads();
-            n_accepts++;
-            li = lowest;
-            sumH = sumH_n;
-            total_jsd = tj;
-            band = band_n;
-            thr = tj + DVS_EPS;
-            refresh_slf();
-            __syncthreads();
         }
+        if (risky) return false;
+        __syncthreads();
+        // members that could be the reference's argmin: within the FAST band (both ways) and the
+        // reference's own rounding band of the smallest FAST value
+        double best = 1e6;
+        for (uint32_t r = 0; r < n; r++) best = fmin(best, s_res[r]);
+        const double reach = best + 2.0 * FAST_BAND + band_n;
+        uint32_t ncand = 0, lowest = 0;
+        for (uint32_t r = 0; r < n; r++)
+            if (s_res[r] <= reach) {
+                if (ncand == 0) lowest = r;
+                ncand++;
+            }
+        if (ncand > 1) {
+            // exact f64 for those members only; strict '<' from 1e6, first index (records.rs:231,246-249)
+            double dmin = 1e6, dsec = 1e6;
+            for (uint32_t r = 0; r < n; r++) {
+                if (!(s_res[r] <= reach)) continue;
+                const uint32_t old = r < li ? r : r + 1;
+                const bool is_new = r == n - 1;
+                double ev[2] = {0.0, 0.0};
+                if (active) {
+#pragma unroll
+                    for (int j = 0; j < H_NB; j++) {
+                        double u = (sn[j] - (is_new ? fr[j] : mfreq(old, j))) * rdiv;
+                        if (u <= DVS_EPS) u = 0.0;
+                        if (u > 0.0) ev[0] -= u * log2_tab(u, s_ltab);
+                        ev[1] += u;
+                    }
+                }
+                h_block_sums<2>(ev, scratch);
+                const double mh = is_new ? w.hrow : s_mH[old];
+                const double de = tj - (ev[0] - (sumH_n - mh) * rdiv);
+                if (de < dmin) {
+                    dsec = dmin;
+                    dmin = de;
+                    lowest = r;
+                } else if (de < dsec) {
+                    dsec = de;
+                }
+            }
+            if (dsec - dmin <= band_n && dsec < 1e6) return false;  // argmin too close to call
+        }
+        // ================= commit
+        __syncthreads();  // every thread has read the old member arrays and rows
+        const uint32_t row_new = s_row[n], row_old = s_row[li], slot_low = s_slot[li];
+        const uint64_t old_pos = s_pos[li];
+        __syncthreads();
+        if (active) {
+            T *dst = Mc + uint64_t(row_new) * B + i0;
+#pragma unroll
+            for (int j = 0; j < H_NB; j++) {
+                dst[j] = T(w.c.at(j));
+                S[i0 + j] = sn[j];
+            }
+        }
+        if (wave == 0) {  // Vec::remove(li) + push by one wave (reads before the dependent writes)
+            const uint32_t i = li + lane;
+            const bool mv = i + 1 < n;
+            uint32_t a = 0, rw = 0;
+            uint64_t c = 0;
+            double b = 0.0, t = 1.0, r1 = 1.0;
+            if (mv) {
+                a = s_slot[i + 1];
+                rw = s_row[i + 1];
+                b = s_mH[i + 1];
+                c = s_pos[i + 1];
+                t = s_tot[i + 1];
+                r1 = s_rt[i + 1];
+            }
+            if (mv) {
+                s_slot[i] = a;
+                s_row[i] = rw;
+                s_mH[i] = b;
+                s_pos[i] = c;
+                s_tot[i] = t;
+                s_rt[i] = r1;
+            }
+            if (lane == 0) {
+                s_slot[n - 1] = slot_low;
+                s_row[n - 1] = row_new;
+                s_row[n] = row_old;  // the dropped member's row is the spare now
+                s_mH[n - 1] = w.hrow;
+                s_pos[n - 1] = p;
+                s_tot[n - 1] = tot;
+                s_rt[n - 1] = rt;
+                // identity order, unique ids: label = stream position
+                if (old_pos < d.nlabels) d.inset[old_pos] = 0;
+                if (p < d.nlabels) d.inset[p] = 1;
+                d.evlog_pos[ctl->n_logged + n_accepts] = p;
+                d.evlog_kind[ctl->n_logged + n_accepts] = 1;
+            }
+        }
+        __syncthreads();
+        n_accepts++;
+        li = lowest;
+        sumH = sumH_n;
+        total_jsd = tj;
+        band = band_n;
+        thr = tj + DVS_EPS;
+        refresh_slf();
+        __syncthreads();
         return true;
     };
 
+    // Rows are consumed in stream order; slot k of the ring holds row p when (p - first) % H_D == k.  The
+    // unrolled pass runs the COARSE tier slot by slot; a row it cannot reject leaves the pass, is copied
+    // out of its slot by a (wave-uniform) branch, and takes the one expansion of `heavy`.
+    int start = 0;
+#pragma unroll 1
     while (p < stop && !bail) {
+        int hit = -1, tier = 0;
 #pragma unroll
         for (int k = 0; k < H_D; k++) {
-            if (p >= stop || bail) break;
-            if (!process(ring[k])) {
-                bail = true;
-                break;
+            if (k >= start && hit < 0 && p < stop) {
+                const int st_ = coarse(ring[k]);
+                if (st_ == 0) {
+                    if (p + uint64_t(H_D) < stop) issue(ring[k], p + uint64_t(H_D));
+                    p++;
+                } else {
+                    hit = k;
+                    tier = st_;
+                }
             }
-            if (p + uint64_t(H_D) < stop) issue(ring[k], p + uint64_t(H_D));
-            p++;
+        }
+        start = 0;
+        if (hit >= 0) {
+            Row cur;
+            if (hit == 0) cur = ring[0];
+            else if (hit == 1) cur = ring[1];
+            else if (hit == 2) cur = ring[2];
+            else cur = ring[3];
+            static_assert(H_D == 4, "the slot copies above and below list four slots");
+            if (!heavy(cur, tier)) {
+                bail = true;
+            } else {
+                if (p + uint64_t(H_D) < stop) {
+                    if (hit == 0) issue(ring[0], p + uint64_t(H_D));
+                    else if (hit == 1) issue(ring[1], p + uint64_t(H_D));
+                    else if (hit == 2) issue(ring[2], p + uint64_t(H_D));
+                    else issue(ring[3], p + uint64_t(H_D));
+                }
+                p++;
+                start = (hit + 1) % H_D;
+            }
         }
     }
 

@@ -107,14 +107,15 @@ __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
     const uint8_t *__restrict__ seqs, uint64_t nbytes, const uint64_t *__restrict__ offsets,
     const KTile *__restrict__ tiles, uint32_t *__restrict__ counts, uint32_t *__restrict__ totals,
     double *__restrict__ entropy, const double *__restrict__ clog_tbl, uint32_t k, uint32_t ns,
-    uint64_t B, uint32_t hot_rows) {
+    uint64_t B, uint32_t hot_rows, uint32_t row0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KTile t;
     if (tiles) {
         t = tiles[blockIdx.x];
     } else {
-        // hot_rows: the first rows of the matrix are built LAST and with ordinary stores
-        const uint32_t r = hot_rows ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+        // this launch builds rows row0 .. row0 + gridDim.x - 1; rows below hot_rows are built LAST and
+        // with ordinary stores (the next reader comes soon)
+        const uint32_t r = row0 + (hot_rows ? gridDim.x - 1 - blockIdx.x : blockIdx.x);
         const uint64_t s0 = offsets[r], s1 = offsets[r + 1];
         t.row = r;
         t.single = 1;
@@ -542,7 +543,7 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
         if (!rc)                                                                                 \
             hipLaunchKernelGGL((kmer_hist_kernel<NS4, LH, false>), dim3(GRID), dim3(NTHR), lds,  \
                                ctx->stream, d_seqs, nbytes, d_off, TILES, m->d_counts,           \
-                               m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, HOT);       \
+                               m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, HOT, 0u);   \
     } while (0)
 #define DVS_LAUNCH_HIST_ANY(GRID, TILES, NTHR, HOT)                            \
     do {                                                                  \
@@ -559,21 +560,55 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
     if (const char *e = getenv("DVS_HIST_HOT_ROWS")) hot_rows = uint32_t(atoi(e));
     // whole sequences: the packed histogram at 128 threads when the row layout allows it
     const bool pk16 = lds_hist && (B & 3) == 0 && !getenv("DVS_HIST_NO_PK16") && !getenv("DVS_HIST_THREADS");
+    // A build that does not wait for its kernels is cut in two launches: the head of the matrix first
+    // (what a selection reads first -- its seeds, and the stretch of the stream its one-workgroup head
+    // engine covers, head.hip), the totals of those rows on their way to the host right behind it, then
+    // everything else.  The selection's set-up and head engine run beside the second launch.
+    uint32_t head_rows = 0;
+    if (m->kind == 2 && no_wait && !getenv("DVS_HIST_NO_SPLIT")) head_rows = std::min<uint32_t>(nseq, DVS_HEAD_ROWS);
+    if (head_rows == nseq) head_rows = 0;  // (nothing left to run beside)
+    bool head_event_done = false;
     if (m->kind == 2) {  // 16-bit rows (dvs_hist_rows_fit_u16 held when the matrix was allocated)
         const size_t lds16 = ((B * 2 + 15) & ~15ull) + (CLOG_TBL + 32) * sizeof(double);
         uint32_t *out16 = reinterpret_cast<uint32_t *>(m->d_counts16);
-        if (ns4) {
-            rc = set_dyn_lds(ctx, kmer_hist_kernel<true, true, true, true>, lds16);
-            if (!rc)
-                hipLaunchKernelGGL((kmer_hist_kernel<true, true, true, true>), dim3(nseq), dim3(128), lds16, ctx->stream,
-                                   d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), out16,
-                                   m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_rows);
+        auto launch16 = [&](uint32_t row0, uint32_t count, uint32_t hot_end) {
+            if (ns4) {
+                rc = set_dyn_lds(ctx, kmer_hist_kernel<true, true, true, true>, lds16);
+                if (!rc)
+                    hipLaunchKernelGGL((kmer_hist_kernel<true, true, true, true>), dim3(count), dim3(128), lds16, ctx->stream,
+                                       d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), out16,
+                                       m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_end, row0);
+            } else {
+                rc = set_dyn_lds(ctx, kmer_hist_kernel<false, true, true, true>, lds16);
+                if (!rc)
+                    hipLaunchKernelGGL((kmer_hist_kernel<false, true, true, true>), dim3(count), dim3(128), lds16, ctx->stream,
+                                       d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), out16,
+                                       m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_end, row0);
+            }
+        };
+        if (head_rows) {
+            launch16(0, head_rows, head_rows);
+            void *pin = nullptr;
+            if (!rc && dvs_pinned_get(ctx, &pin) == DVS_OK) {
+                m->head_count = uint32_t(std::min<size_t>(head_rows, 4096 / sizeof(uint32_t)));
+                m->h_head_pinned = static_cast<uint32_t *>(pin);
+                m->ev_built = dvs_event_get(ctx);
+                if (m->ev_built &&
+                    hipMemcpyAsync(m->h_head_pinned, m->d_totals, size_t(m->head_count) * 4, hipMemcpyDeviceToHost,
+                                   ctx->stream) == hipSuccess &&
+                    hipEventRecord(m->ev_built, ctx->stream) == hipSuccess) {
+                    head_event_done = true;
+                    m->head_rows_built = head_rows;
+                } else {
+                    if (m->ev_built) dvs_event_put(ctx, m->ev_built);
+                    dvs_pinned_put(ctx, pin);
+                    m->ev_built = nullptr;
+                    m->h_head_pinned = nullptr;
+                }
+            }
+            if (!rc) launch16(head_rows, nseq - head_rows, std::min<uint64_t>(nseq, uint64_t(head_rows) + hot_rows));
         } else {
-            rc = set_dyn_lds(ctx, kmer_hist_kernel<false, true, true, true>, lds16);
-            if (!rc)
-                hipLaunchKernelGGL((kmer_hist_kernel<false, true, true, true>), dim3(nseq), dim3(128), lds16, ctx->stream,
-                                   d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), out16,
-                                   m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_rows);
+            launch16(0, nseq, hot_rows);
         }
     } else if (pk16) {
         const size_t lds16 = ((B * 2 + 15) & ~15ull) + (CLOG_TBL + 32) * sizeof(double);
@@ -582,13 +617,13 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
             if (!rc)
                 hipLaunchKernelGGL((kmer_hist_kernel<true, true, true>), dim3(nseq), dim3(128), lds16, ctx->stream,
                                    d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), m->d_counts,
-                                   m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_rows);
+                                   m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_rows, 0u);
         } else {
             rc = set_dyn_lds(ctx, kmer_hist_kernel<false, true, true>, lds16);
             if (!rc)
                 hipLaunchKernelGGL((kmer_hist_kernel<false, true, true>), dim3(nseq), dim3(128), lds16, ctx->stream,
                                    d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), m->d_counts,
-                                   m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_rows);
+                                   m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_rows, 0u);
         }
     } else
         DVS_LAUNCH_HIST_ANY(nseq, static_cast<const KTile *>(nullptr), nthreads, hot_rows);
@@ -601,6 +636,7 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
 #undef DVS_LAUNCH_HIST_ANY
 #undef DVS_LAUNCH_HIST
     if (!rc && (e = hipGetLastError()) != hipSuccess) rc = dvs_hip_fail(ctx, e, "histogram launch");
+    if (!rc && no_wait && head_event_done) return DVS_OK;  // (the head's totals are already on their way)
     if (!rc && no_wait) {
         // Device-resident input: nothing here needs the host to wait.  The first rows' totals are
         // copied to a pinned block behind the kernels and an event marks their arrival; whoever

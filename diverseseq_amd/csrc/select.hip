@@ -839,6 +839,9 @@ static void sel_free(dvs_select *s) {
     for (hipEvent_t e : s->ev_pool) dvs_event_put(s->ctx, e);
     dvs_dev_free(s->ctx, s->psync);
     dvs_dev_free(s->ctx, s->ppart);
+    dvs_dev_free(s->ctx, s->d_seed_list);
+    if (s->ev_head_done) dvs_event_put(s->ctx, s->ev_head_done);
+    for (hipEvent_t e : s->head_ev) dvs_event_put(s->ctx, e);
     dvs_select_arbiter_free(s);
     dvs_ctx_release(s->ctx);
     delete s;
@@ -846,13 +849,15 @@ static void sel_free(dvs_select *s) {
 
 // stage 0: scan + resolve + loo + finalize; 1: resolve + loo + finalize; 2: loo + finalize
 template <typename T>
-static void launch_iteration(dvs_ctx *ctx, dvs_select *s, const T *mat, int stage) {
+static void launch_iteration(dvs_ctx *ctx_, dvs_select *s, const T *mat, int stage, hipStream_t on = nullptr) {
     const SelDev &d = s->dev;
+    struct { hipStream_t stream; } ctx_l{on ? on : ctx_->stream}, *ctx = &ctx_l;  // (the launches below name ctx->stream)
+    auto dvs_event_get_ = [&]() { return dvs_event_get(ctx_); };
     if (stage == 0) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (s->time_scan) {
             if (s->ev_used + 2 > s->ev_pool.size()) {
-                hipEvent_t a = dvs_event_get(ctx), b = dvs_event_get(ctx);
+                hipEvent_t a = dvs_event_get_(), b = dvs_event_get_();
                 s->ev_pool.push_back(a);
                 s->ev_pool.push_back(b);
             }
@@ -892,7 +897,7 @@ static int sel_poll(dvs_ctx *ctx, dvs_select *s) {
 }
 
 template <typename T>
-static int sel_seed(dvs_ctx *ctx, dvs_select *s, const T *mat);
+static int sel_seed(dvs_ctx *ctx, dvs_select *s, const T *mat, hipStream_t st);
 
 template <typename T>
 static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_unpolled = false) {
@@ -928,6 +933,11 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
             }
             s->ev_used = 0;
         }
+        if (s->head_ev.size() == 2 && s->head_ms == 0.0 && s->head_stop) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s->head_ev[0], s->head_ev[1]) == hipSuccess) s->head_ms = ms;
+            else (void)hipGetLastError();
+        }
         if (s->persist && s->psync && getenv("DVS_PERSIST_DEBUG")) {
             unsigned long long dbg[32];
             if (hipMemcpy(dbg, static_cast<char *>(s->psync) + dvs_persist_dbg_offset(), sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -952,7 +962,7 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
             s->persist = false;
             s->persist_fell_back = true;
             dvs_select_arbiter_free(s);  // (its replay of the event log belongs to the abandoned run)
-            rc = sel_seed<T>(ctx, s, mat);
+            rc = sel_seed<T>(ctx, s, mat, ctx->stream);
             if (rc) return rc;
             persist_launches = 0;
             continue;
@@ -1003,17 +1013,47 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
 
 template <typename T>
 static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat) {
-    int rc = sel_seed<T>(ctx, s, mat);
+    // The head of the stream on one workgroup (head.hip), when the selection qualifies.  If the rest of
+    // the matrix is still being built on the context's stream (a split build, kmer_hist.hip), the
+    // set-up kernels and the head engine go to the second stream and run beside it; the grid engine
+    // is launched on the first stream behind both.
+    hipStream_t side = nullptr;
+    if (s->head_stop) {
+        if (s->mat->head_rows_built) {
+            if (s->head_stop > s->mat->head_rows_built) s->head_stop = s->mat->head_rows_built;
+            side = dvs_ctx_stream2(ctx);
+            if (!side || s->head_stop <= s->params.n_seed + 8) s->head_stop = 0;
+        }
+    }
+    if (!s->head_stop) side = nullptr;
+    hipStream_t st = side ? side : ctx->stream;
+    int rc = sel_seed<T>(ctx, s, mat, st);
     if (rc) return rc;
+    if (s->head_stop) {
+        if (s->time_scan) {
+            while (s->head_ev.size() < 2) s->head_ev.push_back(dvs_event_get(ctx));
+            (void)hipEventRecord(s->head_ev[0], st);
+        }
+        rc = dvs_head_launch(ctx, s, st);
+        if (rc) return rc;
+        if (s->time_scan) (void)hipEventRecord(s->head_ev[1], st);
+        launch_iteration<T>(ctx, s, mat, 2, st);  // exact leave-one-out + finalize of the set the head leaves
+        DVS_HIP(ctx, hipGetLastError());
+        if (side) {
+            if (!s->ev_head_done) s->ev_head_done = dvs_event_get(ctx);
+            DVS_HIP(ctx, hipEventRecord(s->ev_head_done, side));
+            DVS_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev_head_done, 0));
+        }
+    }
     if (s->params.flags & DVS_SELECT_STEPWISE) return sel_poll(ctx, s);
     return sel_run_loop<T>(ctx, s, mat, true);
 }
 
 // control block of a fresh selection + the initial set from the seed positions (SummedRecords::new
-// over the first n usable records, records.rs:288-308); also the way back to a clean state when
-// the persistent engine has to be abandoned
+// over the first n usable records, records.rs:288-308), enqueued on `st`; also the way back to a clean
+// state when the persistent engine has to be abandoned
 template <typename T>
-static int sel_seed(dvs_ctx *ctx, dvs_select *s, const T *mat) {
+static int sel_seed(dvs_ctx *ctx, dvs_select *s, const T *mat, hipStream_t st) {
     const std::vector<uint64_t> &seeds = s->seed_positions;
     SelDev &d = s->dev;
     SelCtl c = s->ctl0;
@@ -1026,19 +1066,20 @@ static int sel_seed(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     // (the control block travels through the pinned mirror: a pageable source would have to stay
     // alive until the copy has been performed)
     *s->h_ctl = c;
-    DVS_HIP(ctx, hipMemsetAsync(d.inset, 0, std::max<size_t>(d.nlabels, 1), ctx->stream));
-    DVS_HIP(ctx, hipMemcpyAsync(d.ctl, s->h_ctl, sizeof c, hipMemcpyHostToDevice, ctx->stream));
-    uint64_t *d_seed = nullptr;
-    int rc0 = dvs_dev_alloc(ctx, (void **)&d_seed, seeds.size() * sizeof(uint64_t), "seed list");
-    if (rc0) return rc0;
+    DVS_HIP(ctx, hipMemsetAsync(d.inset, 0, std::max<size_t>(d.nlabels, 1), st));
+    DVS_HIP(ctx, hipMemcpyAsync(d.ctl, s->h_ctl, sizeof c, hipMemcpyHostToDevice, st));
+    if (!s->d_seed_list) {
+        int rc0 = dvs_dev_alloc(ctx, &s->d_seed_list, seeds.size() * sizeof(uint64_t), "seed list");
+        if (rc0) return rc0;
+    }
+    uint64_t *d_seed = static_cast<uint64_t *>(s->d_seed_list);
     DVS_HIP(ctx, hipMemcpyAsync(d_seed, seeds.data(), seeds.size() * sizeof(uint64_t),
-                                hipMemcpyHostToDevice, ctx->stream));
+                                hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL((seed_kernel<T>), dim3(uint32_t(seeds.size())), dim3(LOO_THREADS), 0,
-                       ctx->stream, s->dev, mat, d_seed);
-    hipLaunchKernelGGL(rebuild_kernel, dim3(1), dim3(WIDE_THREADS), 0, ctx->stream, s->dev);
-    launch_iteration<T>(ctx, s, mat, 2);  // loo + finalize of the initial set
+                       st, s->dev, mat, d_seed);
+    hipLaunchKernelGGL(rebuild_kernel, dim3(1), dim3(WIDE_THREADS), 0, st, s->dev);
+    launch_iteration<T>(ctx, s, mat, 2, st);  // loo + finalize of the initial set
     DVS_HIP(ctx, hipGetLastError());
-    dvs_dev_free(ctx, d_seed);  // (back to the ctx cache: any later user is ordered behind seed_kernel on this stream)
     return DVS_OK;
 }
 
@@ -1212,6 +1253,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
 
     {
         int prc = dvs_persist_setup(ctx, s);
+        if (!prc && s->persist) prc = dvs_head_setup(ctx, s);
         if (prc) {
             sel_free(s);
             return prc;
@@ -1305,6 +1347,10 @@ extern "C" int dvs_select_get_summary(dvs_ctx *ctx, const dvs_select *s, dvs_sel
     out->scan_launches = s->scan_launches;
     out->engine = s->persist ? 1u : 0u;
     out->rows_coarse_passed = uint32_t(std::min<unsigned long long>(c.rows_coarse_passed, 0xFFFFFFFFull));
+    out->head_rows = c.head_rows;
+    out->head_accepts = c.head_accepts;
+    out->head_bailed = c.head_bailed;
+    out->head_ms = s->head_ms;
     return DVS_OK;
 }
 
