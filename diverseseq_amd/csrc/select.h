@@ -19,7 +19,8 @@ struct SelCtl {
     unsigned long long rows_scored, rows_rechecked;
     unsigned long long rows_coarse_passed;
     unsigned long long head_rows;  // rows scored / accepts made by the one-workgroup head engine (head.hip)
-    uint32_t head_accepts, head_bailed;  // rows the persistent engine's COARSE tier handed to the FAST tier
+    uint32_t head_accepts, head_bailed;
+    unsigned long long head_dbg[12];  // -DDVS_HEAD_STAMPS: 100 MHz ticks per phase of the head kernel  // rows the persistent engine's COARSE tier handed to the FAST tier
     uint32_t window, window_min, window_max;
     uint32_t status, arb_stage, forced, forced_lowest;
     uint32_t size, lowest, mode, max_size, stat;

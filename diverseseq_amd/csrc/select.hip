@@ -938,6 +938,12 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
             if (hipEventElapsedTime(&ms, s->head_ev[0], s->head_ev[1]) == hipSuccess) s->head_ms = ms;
             else (void)hipGetLastError();
         }
+        if (s->head_stop && getenv("DVS_PERSIST_DEBUG")) {
+            const unsigned long long *g = c.head_dbg;
+            fprintf(stderr, "[dvs head] us: set-up %.1f scan (coarse rows) %.1f fast+exact %.1f S'+total %.1f loo %.1f argmin/refine %.1f "
+                    "commit %.1f mirror %.1f | rows %llu accepts %u bailed %u\n", g[0] / 100.0, g[1] / 100.0, g[2] / 100.0, g[3] / 100.0,
+                    g[4] / 100.0, g[5] / 100.0, g[6] / 100.0, g[7] / 100.0, c.head_rows, c.head_accepts, c.head_bailed);
+        }
         if (s->persist && s->psync && getenv("DVS_PERSIST_DEBUG")) {
             unsigned long long dbg[32];
             if (hipMemcpy(dbg, static_cast<char *>(s->psync) + dvs_persist_dbg_offset(), sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
