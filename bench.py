@@ -124,8 +124,7 @@ def main():
     torch.cuda.synchronize()
 
     stats = {"rows_scored": 0, "scan_ms": 0.0, "scan_launches": 0, "n_accepts": 0,
-             "n_windows": 0, "n_arbitrated": 0, "hist_ms": 0.0, "engine": 0, "count_bytes": 4,
-             "head_rows": 0, "head_accepts": 0, "head_ms": 0.0}
+             "n_windows": 0, "n_arbitrated": 0, "hist_ms": 0.0, "engine": 0, "count_bytes": 4}
 
     def step(collect: bool):
         t0 = time.perf_counter()
@@ -143,7 +142,7 @@ def main():
         if collect:
             s = sel.summary()
             for key in ("rows_scored", "scan_ms", "scan_launches", "n_accepts", "n_windows",
-                        "n_arbitrated", "head_rows", "head_accepts", "head_ms"):
+                        "n_arbitrated"):
                 stats[key] += getattr(s, key)
             stats["hist_ms"] += (t1 - t0) * 1e3
             stats["engine"] = s.engine
@@ -270,9 +269,7 @@ def main():
         total_seqs = a.nseq * world * a.steps
         scan_s = stats["scan_ms"] / 1e3
         cb = stats["count_bytes"]  # sizeof(count) of the matrix the scan reads: 2 for whole-sequence rows, else 4
-        # rows scored x 4^k x sizeof(count) -- the rows the timed kernel itself scored (the
-        # head of the stream is scored by the one-workgroup head engine, beside the histogram)
-        alg_bytes = (stats["rows_scored"] - stats["head_rows"]) * B * cb
+        alg_bytes = stats["rows_scored"] * B * cb  # rows scored x 4^k x sizeof(count)
         achieved = alg_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
         peak = 8000.0  # GB/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
         out = {
@@ -305,11 +302,6 @@ def main():
                 "hist_host_ms_per_step": stats["hist_ms"] / a.steps,  # host time of the build call (it does not wait for its kernel)
                 "scan_ms_per_step": stats["scan_ms"] / a.steps,
                 "tie_arbitrations": stats["n_arbitrated"],
-                "head_engine": {"what": "stream positions below head_stop on ONE workgroup (csrc/head.hip), on a second "
-                                        "stream beside the histogram of the rest of the matrix",
-                                "rows_per_step": stats["head_rows"] / a.steps,
-                                "accepts_per_step": stats["head_accepts"] / a.steps,
-                                "kernel_ms_per_step": stats["head_ms"] / a.steps},
                 "offsets_cache": "off in the timed steps (every step validates + uploads its offsets, as a first "
                                  "build does)",
                 "value_with_offsets_cache": total_seqs / elapsed_cached,

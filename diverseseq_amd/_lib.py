@@ -56,9 +56,7 @@ class SelectSummary(C.Structure):
                 ("n_windows", C.c_uint32), ("n_events", C.c_uint32),
                 ("n_accepts", C.c_uint32), ("n_arbitrated", C.c_uint32),
                 ("scan_ms", C.c_double), ("scan_launches", C.c_uint64),
-                ("engine", C.c_uint32), ("rows_coarse_passed", C.c_uint32),
-                ("head_rows", C.c_uint64), ("head_accepts", C.c_uint32), ("head_bailed", C.c_uint32),
-                ("head_ms", C.c_double)]
+                ("engine", C.c_uint32), ("rows_coarse_passed", C.c_uint32)]
 
 
 class DvsLibraryMissing(RuntimeError):

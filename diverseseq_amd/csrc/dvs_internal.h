@@ -13,14 +13,14 @@
 #include "../../include/dvs_hip.h"
 
 #define DVS_EPS 2.220446049250313e-16  // f64::EPSILON
-#define DVS_HEAD_ROWS 2048u            // rows of a split build's first launch (kmer_hist.hip, head.hip)
+#define DVS_HEAD_ROWS 1024u            // rows of a split build's first launch (kmer_hist.hip)
 
 struct dvs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipStream_t stream2 = nullptr;  // second stream (created on first use): a selection's set-up and head engine
-                                    // beside the histogram of the rest of the matrix
+    hipStream_t stream2 = nullptr;  // second stream (created on first use): a selection's set-up kernels beside
+                                    // the histogram of the rest of the matrix
     int n_cu = 0;
     size_t lds_per_block = 0;  // max dynamic LDS a block may ask for
     double *d_clog_tbl = nullptr;  // c log2 c, c < 256 (kmer_hist.hip)

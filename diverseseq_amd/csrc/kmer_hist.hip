@@ -561,9 +561,9 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
     // whole sequences: the packed histogram at 128 threads when the row layout allows it
     const bool pk16 = lds_hist && (B & 3) == 0 && !getenv("DVS_HIST_NO_PK16") && !getenv("DVS_HIST_THREADS");
     // A build that does not wait for its kernels is cut in two launches: the head of the matrix first
-    // (what a selection reads first -- its seeds, and the stretch of the stream its one-workgroup head
-    // engine covers, head.hip), the totals of those rows on their way to the host right behind it, then
-    // everything else.  The selection's set-up and head engine run beside the second launch.
+    // (what a selection reads first: its seeds), the totals of those rows on their way to the host right
+    // behind it, then everything else.  The selection's set-up kernels run on the context's second
+    // stream beside the second launch (select.hip sel_start).
     uint32_t head_rows = 0;
     if (m->kind == 2 && no_wait && !getenv("DVS_HIST_NO_SPLIT")) head_rows = std::min<uint32_t>(nseq, DVS_HEAD_ROWS);
     if (head_rows == nseq) head_rows = 0;  // (nothing left to run beside)

@@ -17,10 +17,7 @@ struct SelCtl {
     unsigned long long event_pos;  // first position of the window whose score clears thr - band
     unsigned long long arb_pos;
     unsigned long long rows_scored, rows_rechecked;
-    unsigned long long rows_coarse_passed;
-    unsigned long long head_rows;  // rows scored / accepts made by the one-workgroup head engine (head.hip)
-    uint32_t head_accepts, head_bailed;
-    unsigned long long head_dbg[12];  // -DDVS_HEAD_STAMPS: 100 MHz ticks per phase of the head kernel  // rows the persistent engine's COARSE tier handed to the FAST tier
+    unsigned long long rows_coarse_passed;  // rows the persistent engine's COARSE tier handed to the FAST tier
     uint32_t window, window_min, window_max;
     uint32_t status, arb_stage, forced, forced_lowest;
     uint32_t size, lowest, mode, max_size, stat;
@@ -101,12 +98,7 @@ struct dvs_select {
     void *psync = nullptr;
     std::vector<unsigned char> h_psync;  // host image of the sync block (source of its upload)
     void *ppart = nullptr;
-    // one-workgroup head of the stream (head.hip): positions below head_stop, on the context's second stream
-    uint64_t head_stop = 0;
-    size_t head_lds = 0;
-    hipEvent_t ev_head_done = nullptr;
-    std::vector<hipEvent_t> head_ev;  // (start, stop) around the head kernel when timing is on
-    double head_ms = 0.0;
+    hipEvent_t ev_side_done = nullptr;  // the set-up kernels on the context's second stream have run
     void *d_seed_list = nullptr;  // the seed positions on the device (kept until the selection goes: two streams read it)
     int batch = 16;
     // timing
@@ -128,7 +120,3 @@ void dvs_select_arbiter_free(dvs_select *s);
 int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s);
 int dvs_persist_launch(dvs_ctx *ctx, dvs_select *s);
 size_t dvs_persist_dbg_offset(void);
-
-// head.hip
-int dvs_head_setup(dvs_ctx *ctx, dvs_select *s);
-int dvs_head_launch(dvs_ctx *ctx, dvs_select *s, hipStream_t stream);

@@ -840,8 +840,7 @@ static void sel_free(dvs_select *s) {
     dvs_dev_free(s->ctx, s->psync);
     dvs_dev_free(s->ctx, s->ppart);
     dvs_dev_free(s->ctx, s->d_seed_list);
-    if (s->ev_head_done) dvs_event_put(s->ctx, s->ev_head_done);
-    for (hipEvent_t e : s->head_ev) dvs_event_put(s->ctx, e);
+    if (s->ev_side_done) dvs_event_put(s->ctx, s->ev_side_done);
     dvs_select_arbiter_free(s);
     dvs_ctx_release(s->ctx);
     delete s;
@@ -933,17 +932,6 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
             }
             s->ev_used = 0;
         }
-        if (s->head_ev.size() == 2 && s->head_ms == 0.0 && s->head_stop) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, s->head_ev[0], s->head_ev[1]) == hipSuccess) s->head_ms = ms;
-            else (void)hipGetLastError();
-        }
-        if (s->head_stop && getenv("DVS_PERSIST_DEBUG")) {
-            const unsigned long long *g = c.head_dbg;
-            fprintf(stderr, "[dvs head] us: set-up %.1f scan (coarse rows) %.1f fast+exact %.1f S'+total %.1f loo %.1f argmin/refine %.1f "
-                    "commit %.1f mirror %.1f | rows %llu accepts %u bailed %u\n", g[0] / 100.0, g[1] / 100.0, g[2] / 100.0, g[3] / 100.0,
-                    g[4] / 100.0, g[5] / 100.0, g[6] / 100.0, g[7] / 100.0, c.head_rows, c.head_accepts, c.head_bailed);
-        }
         if (s->persist && s->psync && getenv("DVS_PERSIST_DEBUG")) {
             unsigned long long dbg[32];
             if (hipMemcpy(dbg, static_cast<char *>(s->psync) + dvs_persist_dbg_offset(), sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1019,37 +1007,21 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
 
 template <typename T>
 static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat) {
-    // The head of the stream on one workgroup (head.hip), when the selection qualifies.  If the rest of
-    // the matrix is still being built on the context's stream (a split build, kmer_hist.hip), the
-    // set-up kernels and the head engine go to the second stream and run beside it; the grid engine
-    // is launched on the first stream behind both.
+    // When the rest of the matrix is still being built on the context's stream (a split build,
+    // kmer_hist.hip: the head rows are finished, the host has their totals), the set-up kernels of the
+    // selection -- which read only the seed rows -- go to the second stream and run beside that launch
+    // instead of queueing behind it; the engine itself is launched on the first stream behind both.
     hipStream_t side = nullptr;
-    if (s->head_stop) {
-        if (s->mat->head_rows_built) {
-            if (s->head_stop > s->mat->head_rows_built) s->head_stop = s->mat->head_rows_built;
-            side = dvs_ctx_stream2(ctx);
-            if (!side || s->head_stop <= s->params.n_seed + 8) s->head_stop = 0;
-        }
-    }
-    if (!s->head_stop) side = nullptr;
+    if (s->mat->head_rows_built && s->params.n_seed <= s->mat->head_rows_built && s->h_order.empty() &&
+        !(s->params.flags & DVS_SELECT_STEPWISE) && !getenv("DVS_NO_SIDE_STREAM"))
+        side = dvs_ctx_stream2(ctx);
     hipStream_t st = side ? side : ctx->stream;
     int rc = sel_seed<T>(ctx, s, mat, st);
     if (rc) return rc;
-    if (s->head_stop) {
-        if (s->time_scan) {
-            while (s->head_ev.size() < 2) s->head_ev.push_back(dvs_event_get(ctx));
-            (void)hipEventRecord(s->head_ev[0], st);
-        }
-        rc = dvs_head_launch(ctx, s, st);
-        if (rc) return rc;
-        if (s->time_scan) (void)hipEventRecord(s->head_ev[1], st);
-        launch_iteration<T>(ctx, s, mat, 2, st);  // exact leave-one-out + finalize of the set the head leaves
-        DVS_HIP(ctx, hipGetLastError());
-        if (side) {
-            if (!s->ev_head_done) s->ev_head_done = dvs_event_get(ctx);
-            DVS_HIP(ctx, hipEventRecord(s->ev_head_done, side));
-            DVS_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev_head_done, 0));
-        }
+    if (side) {
+        if (!s->ev_side_done) s->ev_side_done = dvs_event_get(ctx);
+        DVS_HIP(ctx, hipEventRecord(s->ev_side_done, side));
+        DVS_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev_side_done, 0));
     }
     if (s->params.flags & DVS_SELECT_STEPWISE) return sel_poll(ctx, s);
     return sel_run_loop<T>(ctx, s, mat, true);
@@ -1259,7 +1231,6 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
 
     {
         int prc = dvs_persist_setup(ctx, s);
-        if (!prc && s->persist) prc = dvs_head_setup(ctx, s);
         if (prc) {
             sel_free(s);
             return prc;
@@ -1353,10 +1324,6 @@ extern "C" int dvs_select_get_summary(dvs_ctx *ctx, const dvs_select *s, dvs_sel
     out->scan_launches = s->scan_launches;
     out->engine = s->persist ? 1u : 0u;
     out->rows_coarse_passed = uint32_t(std::min<unsigned long long>(c.rows_coarse_passed, 0xFFFFFFFFull));
-    out->head_rows = c.head_rows;
-    out->head_accepts = c.head_accepts;
-    out->head_bailed = c.head_bailed;
-    out->head_ms = s->head_ms;
     return DVS_OK;
 }
 

@@ -183,11 +183,6 @@ typedef struct dvs_select_summary {
     uint64_t scan_launches;  /* scan-kernel launches the events bracket (no-op launches included) */
     uint32_t engine;         /* 0: one scan launch per window + state kernels; 1: persistent single launch */
     uint32_t rows_coarse_passed; /* persistent engine: rows its all-f32 tier could not decide (scored again by the f32-log tier) */
-    /* the head of the stream as one workgroup scored it (csrc/head.hip; included in the counts above):
-     * rows, accepts, and the kernel's duration (HIP events, when timing is on) */
-    uint64_t head_rows;
-    uint32_t head_accepts, head_bailed;
-    double head_ms;
 } dvs_select_summary;
 
 int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t *order,

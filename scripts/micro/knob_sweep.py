@@ -21,7 +21,7 @@ for spec in sys.argv[1:]:
         dt = time.perf_counter() - t0
         s = sel.summary()
         if it and (best is None or dt < best[0]):
-            best = (dt, s.scan_ms, s.rows_scored, s.n_windows, s.n_accepts, s.head_ms, s.head_rows)
+            best = (dt, s.scan_ms, s.rows_scored, s.n_windows, s.n_accepts)
         sel.close(); m.close()
-    print(f"{spec:50s} step {best[0]*1e3:.3f} ms persist {best[1]:.3f} rows {best[2]} windows {best[3]} accepts {best[4]} head {best[5]:.3f}/{best[6]}", flush=True)
+    print(f"{spec:50s} step {best[0]*1e3:.3f} ms persist {best[1]:.3f} rows {best[2]} windows {best[3]} accepts {best[4]}", flush=True)
     for k_ in env: os.environ.pop(k_, None)
