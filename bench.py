@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--mode", choices=("chunk", "exact"), default="chunk",
                     help="multi-GPU scheme: 'chunk' = the reference's -np G (independent greedy per GPU + "
                          "one all_gather + final_nmost); 'exact' = rows sharded block-cyclically, set state "
-                         "replicated, one MIN + one SUM all-reduce per greedy step (same answer as 1 GPU)")
+                         "replicated, ONE all_gather per greedy step: every rank's first event + its candidate row "
+                         "(same answer as 1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-runs", action="store_true",
                     help="only the timed steps: no streaming passes, no configs[1] side number (profiling runs: "
@@ -126,12 +127,14 @@ def main():
     stats = {"rows_scored": 0, "scan_ms": 0.0, "scan_launches": 0, "n_accepts": 0,
              "n_windows": 0, "n_arbitrated": 0, "hist_ms": 0.0, "engine": 0, "count_bytes": 4}
 
+    exact_timing = {} if exact else None
+
     def step(collect: bool):
         t0 = time.perf_counter()
         m = ctx.build_matrix_device(seqs.data_ptr(), offsets, a.k, 4)
         t1 = time.perf_counter()
         if exact:
-            sel = nmost_exact(ctx, m, order, a.n, dev, world, window=a.window)
+            sel = nmost_exact(ctx, m, order, a.n, dev, world, window=a.window, timing=exact_timing)
         else:
             sel = m.nmost(a.n, window=a.window)
         if (world > 1 or force_dist) and not exact:
@@ -292,8 +295,9 @@ def main():
                              "inputs resident in HBM (north-star shape)"),
                 "nseq_per_gpu": a.nseq, "length": a.length, "k": a.k, "n": a.n,
                 "parallelism": ("single GPU" if world == 1 and not exact else
-                                (f"{world} ranks, rows sharded block-cyclically, replicated set state, one MIN + one "
-                                 "SUM RCCL all-reduce per greedy step (same answer as 1 GPU)") if exact else
+                                (f"{world} ranks, rows sharded block-cyclically, replicated set state, ONE RCCL all_gather "
+                                 f"per greedy step ({world} x {B + 2} f64: every rank's first event + its candidate row; "
+                                 "same answer as 1 GPU)") if exact else
                                 (f"{world} shards, independent greedy per GPU + one RCCL all_gather "
                                  "+ final_nmost merge (reference -np semantics)")),
                 "accepts_per_step": stats["n_accepts"] / a.steps,
@@ -338,6 +342,12 @@ def main():
                 "ms": stats["persist_stream_ms"], "rows": stats["persist_stream_rows"],
                 "achieved": gbps, "unit": "GB/s", "frac": gbps / peak,
             }
+        if exact_timing and exact_timing.get("collective_ms"):
+            cm = exact_timing["collective_ms"]
+            out["config"]["exact_mode_collective"] = {
+                "what": "duration of the per-step all_gather (device events around it, first 64 steps of every "
+                        "selection), rank 0", "mean_us": 1e3 * sum(cm) / len(cm), "max_us": 1e3 * max(cm),
+                "samples": len(cm), "bytes_per_rank": (B + 2) * 8}
         if "c2" in stats:
             out["config"]["also_configs_1"] = stats["c2"]
         if "dvs_module" in stats:

@@ -794,34 +794,56 @@ __global__ __launch_bounds__(LOO_THREADS) void gather_members_kernel(SelDev d, d
     }
 }
 
-// ---- stepwise (distributed) helpers: the event word as int64 for a MIN all-reduce and the
-// candidate row for a SUM all-reduce (the owner contributes the row, everyone else zeros)
-__global__ void export_event_kernel(const SelCtl *ctl, long long *dst) {
-    const unsigned long long v = ctl->event_pos;
-    *dst = (v == SEL_NONE) ? 0x7FFFFFFFFFFFFFFFll : (long long)v;
-}
-__global__ void import_event_kernel(SelCtl *ctl, const long long *src) {
-    const long long v = *src;
-    ctl->event_pos = (v == 0x7FFFFFFFFFFFFFFFll) ? SEL_NONE : (unsigned long long)v;
-}
+// ---- stepwise (distributed) helpers.  One exchange per greedy step: every rank packs its own first
+// event of the window -- position, row entropy and the candidate's 4^k frequency row -- into its slot
+// of an all_gather; afterwards every rank holds all the slots, takes the smallest position (a stream
+// position is scored by exactly one rank) and resolves that candidate against its replica of the set.
+// slot: [0] event position as a double (< 0: none), [1] H(row), [2 ..] the frequency row.
 template <typename T>
-__global__ __launch_bounds__(LOO_THREADS) void fetch_candidate_kernel(SelDev d, const T *__restrict__ mat,
-                                                                     double *__restrict__ out) {
+__global__ __launch_bounds__(LOO_THREADS) void pack_event_kernel(SelDev d, const T *__restrict__ mat,
+                                                                double *__restrict__ slot) {
     const SelCtl *ctl = d.ctl;
     const unsigned long long p = ctl->event_pos;
     uint32_t row = DVS_ROW_REMOTE;
     if (ctl->status == SEL_RUN && p != SEL_NONE) row = d.order ? d.order[p] : uint32_t(p);
     if (row == DVS_ROW_REMOTE) {
-        for (uint64_t i = threadIdx.x; i < d.B + 2; i += LOO_THREADS) out[i] = 0.0;
+        if (threadIdx.x == 0) slot[0] = -1.0;  // (the rest of the slot is not read)
         return;
     }
     const double tot = double(d.totals[row]);
     const T *rp = mat + uint64_t(row) * d.B;
-    for (uint64_t i = threadIdx.x; i < d.B; i += LOO_THREADS) out[i] = cand_freq(rp, i, tot);
+    for (uint64_t i = threadIdx.x; i < d.B; i += LOO_THREADS) slot[2 + i] = cand_freq(rp, i, tot);
     if (threadIdx.x == 0) {
-        out[d.B] = d.rowH[row];
-        out[d.B + 1] = 1.0;  // exactly one rank owns the position
+        slot[0] = double(p);  // (exact below 2^53)
+        slot[1] = d.rowH[row];
     }
+}
+// the earliest event among the gathered slots -> the control block and the candidate buffer
+// (B frequencies, then the entropy: what resolve_body reads through cand_ext)
+__global__ __launch_bounds__(LOO_THREADS) void pick_event_kernel(SelDev d, const double *__restrict__ all,
+                                                                uint32_t world, uint64_t stride,
+                                                                double *__restrict__ pick) {
+    __shared__ int s_best;
+    SelCtl *ctl = d.ctl;
+    if (threadIdx.x == 0) {
+        int best = -1;
+        double bp = 0.0;
+        for (uint32_t r = 0; r < world; r++) {
+            const double q = all[uint64_t(r) * stride];
+            if (q >= 0.0 && (best < 0 || q < bp)) {
+                best = int(r);
+                bp = q;
+            }
+        }
+        s_best = best;
+        if (ctl->status == SEL_RUN) ctl->event_pos = best < 0 ? SEL_NONE : (unsigned long long)bp;
+    }
+    __syncthreads();
+    const int best = s_best;
+    if (best < 0) return;
+    const double *src = all + uint64_t(best) * stride;
+    for (uint64_t i = threadIdx.x; i < d.B; i += LOO_THREADS) pick[i] = src[2 + i];
+    if (threadIdx.x == 0) pick[d.B] = src[1];
 }
 
 }  // namespace
@@ -1527,8 +1549,8 @@ extern "C" int dvs_selftest_fast_log2(dvs_ctx *ctx, double *max_abs_err) {
     return DVS_OK;
 }
 
-// ---- stepwise driving (one process per GPU; the collectives between the steps are the
-// host framework's: an int64 MIN all-reduce of the event word, a SUM all-reduce of the row)
+// ---- stepwise driving (one process per GPU; the exchange between the steps is the host
+// framework's: ONE all_gather of every rank's slot per greedy step)
 template <typename T>
 static int step_scan(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     const SelDev &d = s->dev;
@@ -1539,25 +1561,24 @@ static int step_scan(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     return DVS_OK;
 }
 
-extern "C" int dvs_select_step_scan(dvs_ctx *ctx, dvs_select *s, void *d_event_i64) {
-    if (!ctx || !s || !d_event_i64) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+extern "C" int dvs_select_step_pack(dvs_ctx *ctx, dvs_select *s, double *d_slot) {
+    if (!ctx || !s || !d_slot) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
     int rc = dvs_mat_dispatch(s->mat, [&](auto *mp) { return step_scan(ctx, s, mp); });
     if (rc) return rc;
-    hipLaunchKernelGGL(export_event_kernel, dim3(1), dim3(1), 0, ctx->stream, s->dev.ctl,
-                       static_cast<long long *>(d_event_i64));
+    dvs_mat_dispatch(s->mat, [&](auto *mp) {
+        using T = std::remove_cv_t<std::remove_pointer_t<decltype(mp)>>;
+        hipLaunchKernelGGL((pack_event_kernel<T>), dim3(1), dim3(LOO_THREADS), 0, ctx->stream, s->dev, mp, d_slot);
+        return 0;
+    });
     DVS_HIP(ctx, hipGetLastError());
     return DVS_OK;
 }
 
-extern "C" int dvs_select_step_fetch(dvs_ctx *ctx, dvs_select *s, const void *d_event_i64, double *d_row) {
-    if (!ctx || !s || !d_event_i64 || !d_row) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
-    hipLaunchKernelGGL(import_event_kernel, dim3(1), dim3(1), 0, ctx->stream, s->dev.ctl,
-                       static_cast<const long long *>(d_event_i64));
-    dvs_mat_dispatch(s->mat, [&](auto *mp) {
-        using T = std::remove_cv_t<std::remove_pointer_t<decltype(mp)>>;
-        hipLaunchKernelGGL((fetch_candidate_kernel<T>), dim3(1), dim3(LOO_THREADS), 0, ctx->stream, s->dev, mp, d_row);
-        return 0;
-    });
+extern "C" int dvs_select_step_pick(dvs_ctx *ctx, dvs_select *s, const double *d_all, uint32_t world,
+                                    double *d_row) {
+    if (!ctx || !s || !d_all || !d_row || !world) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    hipLaunchKernelGGL(pick_event_kernel, dim3(1), dim3(LOO_THREADS), 0, ctx->stream, s->dev, d_all, world,
+                       s->dev.B + 2, d_row);
     DVS_HIP(ctx, hipGetLastError());
     return DVS_OK;
 }

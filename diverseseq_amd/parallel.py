@@ -161,9 +161,11 @@ def merge_max(ctx, sel, min_size: int, max_size: int, stat: str, chunk_start: in
 # ---------------------------------------------------------------------------------------
 # Exact multi-GPU selection (same answer as one GPU / the reference's `-np 1`): rows are
 # sharded block-cyclically by global candidate order, the set state is replicated, and each
-# greedy step costs two small collectives:
-#   MIN all-reduce of the first event position, SUM all-reduce of that candidate's 4^k
-#   frequency row (the owner contributes the row, everyone else zeros).
+# greedy step costs ONE small collective (BASELINE north_star): every rank packs
+# its own first event of the window -- position, row entropy, the candidate's 4^k frequency
+# row -- into its slot of an all_gather (world x (4^k + 2) f64: 8 x 32 KB at k=6); every rank
+# then takes the earliest position among the slots and resolves that candidate against its
+# replica of the set (identical arithmetic, so the replicas stay bit-identical).
 ROW_REMOTE = 0xFFFFFFFF
 
 
@@ -180,41 +182,117 @@ def shard_order(npos: int, n_seed: int, rank: int, world: int, block: int = 256)
     return owned, order
 
 
-def nmost_exact(ctx, matrix, order: np.ndarray, n: int, device, world: int, *, window: int = 0,
-                poll_every: int = 8):
-    """Greedy nmost over a row-sharded stream.  `ctx` must have been created on the torch stream
-    that is current here (Context(device, stream=torch.cuda.current_stream().cuda_stream)), so the
-    library's kernels and the collectives are ordered on one stream with no host syncs in between.
-    Returns the Selection; its member positions are global stream positions."""
-    import ctypes as C
+class HipStepper:
+    """the library's stepwise entry points (include/dvs_hip.h) behind the driver below"""
 
+    def __init__(self, ctx, sel, nbins: int, device):
+        import torch
+
+        self.ctx, self.sel, self.nbins = ctx, sel, nbins
+        self.slot = torch.zeros(nbins + 2, dtype=torch.float64, device=device)
+        self.row = torch.zeros(nbins + 2, dtype=torch.float64, device=device)
+
+    def pack(self):
+        import ctypes as C
+
+        self.ctx.check(self.ctx._L.dvs_select_step_pack(self.ctx._h, self.sel._h, C.c_void_p(self.slot.data_ptr())))
+        return self.slot
+
+    def apply(self, all_slots, world: int):
+        import ctypes as C
+
+        L = self.ctx._L
+        self.ctx.check(L.dvs_select_step_pick(self.ctx._h, self.sel._h, C.c_void_p(all_slots.data_ptr()), world,
+                                              C.c_void_p(self.row.data_ptr())))
+        self.ctx.check(L.dvs_select_step_apply(self.ctx._h, self.sel._h, C.c_void_p(self.row.data_ptr())))
+
+    def done(self) -> bool:
+        import ctypes as C
+
+        status, cursor = C.c_uint32(), C.c_uint64()
+        self.ctx.check(self.ctx._L.dvs_select_step_poll(self.ctx._h, self.sel._h, C.byref(status), C.byref(cursor)))
+        if status.value not in (0, 1):
+            raise RuntimeError(f"selection engine in state {status.value}")
+        return status.value == 1
+
+
+def drive_exact(stepper, world: int, device, *, poll_every: int = 8, timing: dict | None = None):
+    """The greedy loop of the exact mode: `poll_every` steps are enqueued between two looks at the
+    engine's status (a finished selection turns the remaining steps into no-ops).  One all_gather per
+    step.  `stepper` is HipStepper on GPUs; the CPU tests drive the oracle through the same loop.
+    timing: {"collective_ms": [...]} gets the duration of the first steps' all_gather (device events)."""
     import torch
     import torch.distributed as dist
 
+    all_slots = None
+    on_gpu = getattr(device, "type", str(device)) == "cuda"
+
+    flat_ok = [True]
+
+    def gather(dst, src):
+        if flat_ok[0]:
+            try:
+                dist.all_gather_into_tensor(dst, src)
+                return
+            except RuntimeError:  # (a backend without the flat form for this device: per-rank views)
+                flat_ok[0] = False
+        dist.all_gather(list(dst.view(world, -1).unbind(0)), src)
+    events = []
+    while not stepper.done():
+        for _ in range(poll_every):
+            slot = stepper.pack()
+            if world > 1:
+                if all_slots is None:
+                    all_slots = torch.empty(world * slot.numel(), dtype=slot.dtype, device=slot.device)  # (flat: gloo wants it so)
+                if timing is not None and on_gpu and len(events) < 64:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    gather(all_slots, slot)
+                    e1.record()
+                    events.append((e0, e1))
+                else:
+                    gather(all_slots, slot)
+                stepper.apply(all_slots, world)
+            else:
+                stepper.apply(slot, 1)
+    if timing is not None and events:
+        torch.cuda.synchronize()
+        timing.setdefault("collective_ms", []).extend(a.elapsed_time(b) for a, b in events)
+
+
+def _select_exact(ctx, matrix, order, mode, n_seed, device, world, *, max_size=0, stat=0, window=0,
+                  poll_every=8, timing=None):
     from . import _lib
 
-    L = ctx._L
-    B = matrix.nbins
-    ev = torch.full((1,), 2**63 - 1, dtype=torch.int64, device=device)
-    row = torch.zeros(B + 2, dtype=torch.float64, device=device)
-    sel = matrix.select(_lib.MODE_NMOST, n, order=order, window=window or 4096 * world,
+    sel = matrix.select(mode, n_seed, max_size=max_size, stat=stat, order=order, window=window or 4096 * world,
                         flags=_lib.SELECT_STEPWISE)
-    status, cursor = C.c_uint32(), C.c_uint64()
-    while True:
-        ctx.check(L.dvs_select_step_poll(ctx._h, sel._h, C.byref(status), C.byref(cursor)))
-        if status.value == 1:
-            return sel
-        if status.value != 0:
-            raise RuntimeError(f"selection engine in state {status.value}")
-        for _ in range(poll_every):
-            ctx.check(L.dvs_select_step_scan(ctx._h, sel._h, C.c_void_p(ev.data_ptr())))
-            if world > 1:
-                dist.all_reduce(ev, op=dist.ReduceOp.MIN)
-            ctx.check(L.dvs_select_step_fetch(ctx._h, sel._h, C.c_void_p(ev.data_ptr()),
-                                              C.c_void_p(row.data_ptr())))
-            if world > 1:
-                dist.all_reduce(row, op=dist.ReduceOp.SUM)
-            ctx.check(L.dvs_select_step_apply(ctx._h, sel._h, C.c_void_p(row.data_ptr())))
+    drive_exact(HipStepper(ctx, sel, matrix.nbins, device), world, device, poll_every=poll_every, timing=timing)
+    return sel
+
+
+def nmost_exact(ctx, matrix, order: np.ndarray, n: int, device, world: int, *, window: int = 0,
+                poll_every: int = 8, timing: dict | None = None):
+    """Greedy nmost over a row-sharded stream (select_nmost_divergent, src/records.rs:311-342).
+    `ctx` must have been created on the torch stream that is current here
+    (Context(device, stream=torch.cuda.current_stream().cuda_stream)), so the library's kernels and
+    the collective are ordered on one stream with no host syncs in between.  Returns the Selection;
+    its member positions are global stream positions."""
+    from . import _lib
+
+    return _select_exact(ctx, matrix, order, _lib.MODE_NMOST, n, device, world, window=window,
+                         poll_every=poll_every, timing=timing)
+
+
+def max_exact(ctx, matrix, order: np.ndarray, min_size: int, max_size: int, stat: str, device, world: int, *,
+              window: int = 0, poll_every: int = 8, timing: dict | None = None):
+    """The same for select_max_divergent (src/records.rs:390-454): the set grows while the standard
+    deviation (or coefficient of variation) of the members' delta_jsd rises; every rank takes the
+    commit-or-rollback decision from the same numbers."""
+    from . import _lib
+
+    st = _lib.STAT_STDEV if stat == "stdev" else _lib.STAT_COV
+    return _select_exact(ctx, matrix, order, _lib.MODE_MAX, min_size, device, world, max_size=max_size, stat=st,
+                         window=window, poll_every=poll_every, timing=timing)
 
 
 # ---------------------------------------------------------------------------------------

@@ -207,20 +207,21 @@ int dvs_select_gather_members(dvs_ctx *ctx, const dvs_select *s, double *d_rows,
 int dvs_select_delta_jsd(dvs_ctx *ctx, const dvs_select *s, const dvs_matrix *queries,
                          const uint32_t *qlabels, double *out);
 /* ---- stepwise driving: rows sharded over ranks, set state replicated -------- *
- * The exact multi-GPU form of select_nmost_divergent: every rank
- * holds the rows of its share of the stream (order[p] = DVS_ROW_REMOTE for the
- * others; the first n_seed rows replicated everywhere) and an identical copy of
- * the set.  Per greedy step, all enqueued on the ctx stream with no host sync:
- *   dvs_select_step_scan   scan this rank's rows of the current window; the first
- *                          local event position goes to *d_event_i64 (INT64_MAX: none)
- *   [host framework: MIN all-reduce of d_event_i64 -- RCCL]
- *   dvs_select_step_fetch  the owner of that position writes its frequency row,
- *                          entropy and a 1.0 marker to d_row[nbins + 2], others zeros
- *   [host framework: SUM all-reduce of d_row -- the row reaches every rank]
- *   dvs_select_step_apply  resolve + leave-one-out + finalize with that candidate
+ * The exact multi-GPU form of select_nmost_divergent / select_max_divergent: every
+ * rank holds the rows of its share of the stream (order[p] = DVS_ROW_REMOTE for the others; the
+ * first n_seed rows replicated everywhere) and an identical copy of the set.  ONE collective per
+ * greedy step, everything enqueued on the ctx stream with no host sync:
+ *   dvs_select_step_pack   scan this rank's rows of the current window and pack its first local
+ *                          event into d_slot[nbins + 2]: position (as a double; < 0: none), the
+ *                          row's entropy, the candidate's frequency row
+ *   [host framework: all_gather of the slots -- RCCL; world x (nbins + 2) doubles, 8 x 32 KB at k=6]
+ *   dvs_select_step_pick   the earliest event among the gathered slots becomes the window's event
+ *                          and its row goes to d_row[nbins + 1] (a position is scored by one rank only)
+ *   dvs_select_step_apply  resolve + leave-one-out + finalize with that candidate (identical
+ *                          arithmetic on every rank: the replicas stay bit-identical)
  * dvs_select_step_poll syncs and returns the status (0 running, 1 done) / cursor. */
-int dvs_select_step_scan(dvs_ctx *ctx, dvs_select *s, void *d_event_i64);
-int dvs_select_step_fetch(dvs_ctx *ctx, dvs_select *s, const void *d_event_i64, double *d_row);
+int dvs_select_step_pack(dvs_ctx *ctx, dvs_select *s, double *d_slot);
+int dvs_select_step_pick(dvs_ctx *ctx, dvs_select *s, const double *d_all, uint32_t world, double *d_row);
 int dvs_select_step_apply(dvs_ctx *ctx, dvs_select *s, const double *d_row);
 int dvs_select_step_poll(dvs_ctx *ctx, dvs_select *s, uint32_t *status, uint64_t *cursor);
 

@@ -807,18 +807,26 @@ def _exact_worker(rank, world, port, q):
         owned, order = parallel.shard_order(len(seqs), n, rank, world, block=32)
         local = seqs[:n] + [seqs[int(p)] for p in owned]
         m = ctx.build_matrix(local, k, 4)
+        out = [rank]
         sel = parallel.nmost_exact(ctx, m, order, n, dev, world, window=256 * world, poll_every=4)
         mem = sel.members(with_freqs=False)
         s = sel.summary()
-        q.put((rank, mem.positions.tolist(), mem.delta_jsd.tolist(), s.total_jsd))
+        out.append((mem.positions.tolist(), mem.delta_jsd.tolist(), s.total_jsd))
+        for stat in ("stdev", "cov"):  # the same rows, select_max_divergent: the set grows from n
+            sel = parallel.max_exact(ctx, m, order, n, 40, stat, dev, world, window=256 * world, poll_every=4)
+            mem = sel.members(with_freqs=False)
+            s = sel.summary()
+            out.append((mem.positions.tolist(), mem.delta_jsd.tolist(), s.total_jsd))
+        q.put(tuple(out))
     if world > 1:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [1, 2])
 def test_exact_row_sharded_mode(world):
-    """rows sharded over ranks + replicated set state + one MIN and one SUM all-reduce per greedy
-    step must give the single-process answer (ids bit-exact)"""
+    """rows sharded over ranks + replicated set state + ONE all_gather per greedy step (every rank's
+    first event and its candidate row) must give the single-process answer (ids bit-exact), for
+    select_nmost_divergent and select_max_divergent (records.rs:311-454)"""
     import socket
 
     import torch.multiprocessing as mp
@@ -836,12 +844,14 @@ def test_exact_row_sharded_mode(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     seqs = synth_seqs(1500, 600, 123, invalid_frac=0.001, ragged=True)
-    exp = oracle.nmost(seqs, 12, 5, 4)
-    elab, edelta, _, _ = exp.members()
-    for rank, pos, delta, total in res:
-        assert pos == elab.tolist()
-        np.testing.assert_allclose(delta, edelta, rtol=RTOL, atol=1e-13)
-        np.testing.assert_allclose(total, exp.total_jsd, rtol=RTOL)
+    exps = [oracle.nmost(seqs, 12, 5, 4), oracle.max_divergent(seqs, 12, 40, 5, 4, "stdev"),
+            oracle.max_divergent(seqs, 12, 40, 5, 4, "cov")]
+    for r in res:
+        for (pos, delta, total), exp in zip(r[1:], exps):
+            elab, edelta, _, _ = exp.members()
+            assert pos == elab.tolist()
+            np.testing.assert_allclose(delta, edelta, rtol=RTOL, atol=1e-13)
+            np.testing.assert_allclose(total, exp.total_jsd, rtol=RTOL)
     assert res[0][1:] == res[-1][1:]  # replicas are bit-identical
 
 

@@ -1,7 +1,9 @@
-"""world_size-2 gloo test of the N>1 path's exchange step (no GPU): each rank
-selects on its chunk with the oracle, the winners are all_gathered exactly as
-bench.py / diverseseq_amd.parallel do on RCCL, and the merged result must equal
-the reference's chunk-and-merge (`-np 2`) semantics computed in one process."""
+"""gloo tests of the N>1 paths' exchange steps (no GPU), world sizes 2, 4 and 8.  Chunk mode: each rank
+selects on its chunk with the oracle, the winners are all_gathered exactly as bench.py /
+diverseseq_amd.parallel do on RCCL, and the merged result must equal the reference's chunk-and-merge
+(`-np G`, chunks in order) computed in one process.  Exact mode: the driver of the row-sharded
+selection (parallel.drive_exact: one all_gather per greedy step) with the oracle as each rank's
+compute must give the one-process answer of select_nmost_divergent / select_max_divergent."""
 import os
 import socket
 import sys
@@ -16,6 +18,22 @@ def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def _run_world(target, world, timeout=240):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=timeout) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
 
 
 def _worker(rank, world, port, q):
@@ -47,26 +65,16 @@ def test_chunk_sizes_match_reference():
     assert parallel.chunk_bounds(10, 3) == [(0, 4), (4, 7), (7, 10)]
 
 
-def test_gather_and_merge_world2():
-    import torch.multiprocessing as mp
-
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_gather_and_merge(world):
     import oracle
     from diverseseq_amd import parallel
 
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=90) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    # single-process statement of the same `-np 2` semantics
+    res = _run_world(_worker, world)
+    # single-process statement of the same `-np G` semantics (chunks in order)
     seqs = synth_seqs(301, 300, 99, ragged=True)
     rows, ids = [], []
-    for lo, hi in parallel.chunk_bounds(len(seqs), 2):
+    for lo, hi in parallel.chunk_bounds(len(seqs), world):
         r = oracle.nmost(seqs[lo:hi], 6, 3, 4)
         lab, _, _, f = r.members(with_freqs=True)
         rows.append(f)
@@ -137,3 +145,96 @@ def test_sharded_mash_distances_world2():
     exp = oracle.mash_distances([oracle.mash_sketch(x, 8, 64) for x in seqs], 8, 64)
     for _, d in res:
         np.testing.assert_array_equal(d, exp)
+
+
+# ----------------------------------------------------------------------------- exact mode
+class _OracleStepper:
+    """the per-rank compute of the exact mode stated with the oracle: scan this rank's rows of the
+    window against the replicated set, pack the first local event, apply the gathered winner"""
+
+    def __init__(self, seqs, owned, mode, n_seed, k, window, max_size=0, stat="stdev"):
+        import oracle
+
+        self.o, self.seqs, self.k, self.window = oracle, seqs, k, window
+        self.mode, self.max_size, self.stat = mode, min(max_size, len(seqs)), stat
+        self.owned = set(int(p) for p in owned)
+        self.set = oracle.SummedRecords.from_seqs(seqs[:n_seed], k, 4, labels=np.arange(n_seed, dtype=np.uint32))
+        self.cursor, self.npos, self.B = n_seed, len(seqs), 4 ** k
+
+    def pack(self):
+        import torch
+
+        slot = np.zeros(self.B + 2)
+        slot[0] = -1.0
+        for p in range(self.cursor, min(self.cursor + self.window, self.npos)):
+            if p not in self.owned or self.seqs[p].size < self.k:
+                continue
+            f, h = self.o.to_kfreqs(self.seqs[p], 4, self.k)
+            if self.set.increases_jsd(f, h, p):
+                slot[0], slot[1], slot[2:] = p, h, f
+                break
+        return torch.from_numpy(slot)
+
+    def _stat(self, s):
+        return s.std_delta_jsd if self.stat == "stdev" else s.cov_delta_jsd
+
+    def apply(self, all_slots, world):
+        a = all_slots.numpy().reshape(world, -1)
+        live = [r for r in range(world) if a[r, 0] >= 0]
+        if not live:
+            self.cursor = min(self.cursor + self.window, self.npos)
+            return
+        r = min(live, key=lambda i: a[i, 0])
+        p, h, f = int(a[r, 0]), float(a[r, 1]), a[r, 2:].copy()
+        if self.mode == "nmost" or self.set.size >= self.max_size:
+            self.set.replace_lowest(f, h, p)
+        else:  # records.rs:427-451: clone + push, kept iff the statistic rose
+            lab, _, ent, fr = self.set.members(with_freqs=True)
+            grown = self.o.SummedRecords.new(np.vstack([fr, f[None]]), np.append(ent, h),
+                                             np.append(lab, p).astype(np.uint32))
+            if self._stat(grown) > self._stat(self.set):
+                self.set = grown
+        self.cursor = p + 1
+
+    def done(self):
+        return self.cursor >= self.npos
+
+
+def _exact_cpu_worker(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+
+    from diverseseq_amd import parallel
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seqs = synth_seqs(400, 300, 7, invalid_frac=0.002, ragged=True)
+    out = [rank]
+    for mode, n_seed, kw in (("nmost", 6, {}), ("max", 4, {"max_size": 12, "stat": "stdev"}),
+                             ("max", 4, {"max_size": 400, "stat": "cov"})):
+        owned, _ = parallel.shard_order(len(seqs), n_seed, rank, world, block=16)
+        st = _OracleStepper(seqs, owned, mode, n_seed, 3, window=24 * world, **kw)
+        parallel.drive_exact(st, world, torch.device("cpu"), poll_every=3)
+        lab, delta, _, _ = st.set.members()
+        out.append((lab.tolist(), delta.tolist(), st.set.total_jsd))
+    q.put(tuple(out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_exact_mode_driver(world):
+    """rows dealt block-cyclically over 2 / 4 / 8 ranks, ONE all_gather per greedy step: every rank ends
+    with the one-process selection, nmost and max (stdev, cov), bit for bit"""
+    import oracle
+
+    res = _run_world(_exact_cpu_worker, world)
+    seqs = synth_seqs(400, 300, 7, invalid_frac=0.002, ragged=True)
+    exp = [oracle.nmost(seqs, 6, 3, 4), oracle.max_divergent(seqs, 4, 12, 3, 4, "stdev"),
+           oracle.max_divergent(seqs, 4, 400, 3, 4, "cov")]
+    for r in res:
+        for got, e in zip(r[1:], exp):
+            lab, delta, _, _ = e.members()
+            assert got[0] == lab.tolist()
+            assert got[1] == delta.tolist()
+            assert got[2] == e.total_jsd
