@@ -17,11 +17,20 @@
 // redoes the block locally on top of its carry.  The file is read three times at HBM speed; the
 // bases are written once.
 //
+// A file handed over in HOST memory is streamed: chunks of 32 MiB travel through a ring of pinned staging
+// buffers (filled by a few host threads, sent by asynchronous copies on a stream of their own) and
+// all five passes run chunk by chunk behind their copy -- every scan carries its running state from
+// chunk to chunk in a device word -- so the kernels of chunk c overlap the upload of chunk c + 1 and the
+// ingest ends a fraction of a millisecond after the last byte has arrived.
+//
 // join_records != 0 restates io.py:100: the records of the file become ONE sequence, a gap symbol
 // ('-' = index 4 for DNA, an invalid state, so no k-mer spans two records) between adjacent records.
 #include "dvs_internal.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace {
 
@@ -125,28 +134,31 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
 }
 
 // pass 1: aggregate of every block
+// (block0: the first block of the chunk this launch covers; n: the whole file)
 __global__ __launch_bounds__(ING_THREADS) void ing_agg_kernel(const uint8_t *__restrict__ raw, uint64_t n,
-                                                              Agg *__restrict__ blocks) {
+                                                              Agg *__restrict__ blocks, uint64_t block0) {
     __shared__ Agg lds[ING_THREADS];
     Agg run{-1, -1, 0};
+    const uint64_t blk = block0 + blockIdx.x;
     for (int tile = 0; tile < ING_TILES; tile++) {
-        const uint64_t base = uint64_t(blockIdx.x) * ING_BLOCK + uint64_t(tile) * ING_TILE +
-                              uint64_t(threadIdx.x) * ING_CHUNK;
-        if (uint64_t(blockIdx.x) * ING_BLOCK + uint64_t(tile) * ING_TILE >= n) break;  // (block-uniform)
+        const uint64_t base = blk * ING_BLOCK + uint64_t(tile) * ING_TILE + uint64_t(threadIdx.x) * ING_CHUNK;
+        if (blk * ING_BLOCK + uint64_t(tile) * ING_TILE >= n) break;  // (block-uniform)
         uint8_t c[ING_CHUNK], prev;
         load_chunk(raw, n, base, c, prev);
         Agg total;
         (void)block_scan_agg(chunk_agg(c, prev, base, n), lds, total);
         run = agg_join(run, total);
     }
-    if (threadIdx.x == 0) blocks[blockIdx.x] = run;
+    if (threadIdx.x == 0) blocks[blk] = run;
 }
 
-// pass 2: one block turns the block aggregates into exclusive prefixes (carry of every block);
-// blocks[nb] receives the grand total
-__global__ __launch_bounds__(ING_THREADS) void ing_scan_agg_kernel(Agg *__restrict__ blocks, uint64_t nb) {
+// pass 2: one block turns the aggregates of nb blocks into exclusive prefixes (carry of every block),
+// starting from the running state *running (what precedes them in the file) and leaving the state behind
+// them there
+__global__ __launch_bounds__(ING_THREADS) void ing_scan_agg_kernel(Agg *__restrict__ blocks, uint64_t nb,
+                                                                   Agg *__restrict__ running) {
     __shared__ Agg lds[ING_THREADS];
-    Agg carry{-1, -1, 0};
+    Agg carry = *running;
     for (uint64_t b0 = 0; b0 < nb; b0 += ING_THREADS) {
         const uint64_t b = b0 + threadIdx.x;
         const Agg mine = b < nb ? blocks[b] : Agg{-1, -1, 0};
@@ -155,12 +167,14 @@ __global__ __launch_bounds__(ING_THREADS) void ing_scan_agg_kernel(Agg *__restri
         if (b < nb) blocks[b] = agg_join(carry, ex);
         carry = agg_join(carry, total);
     }
-    if (threadIdx.x == 0) blocks[nb] = carry;
+    __syncthreads();  // (every thread has read *running)
+    if (threadIdx.x == 0) *running = carry;
 }
 
-__global__ __launch_bounds__(ING_THREADS) void ing_scan_u64_kernel(unsigned long long *__restrict__ blocks, uint64_t nb) {
+__global__ __launch_bounds__(ING_THREADS) void ing_scan_u64_kernel(unsigned long long *__restrict__ blocks, uint64_t nb,
+                                                                   unsigned long long *__restrict__ running) {
     __shared__ unsigned long long lds[ING_THREADS];
-    unsigned long long carry = 0;
+    unsigned long long carry = *running;
     for (uint64_t b0 = 0; b0 < nb; b0 += ING_THREADS) {
         const uint64_t b = b0 + threadIdx.x;
         const unsigned long long mine = b < nb ? blocks[b] : 0ull;
@@ -169,7 +183,8 @@ __global__ __launch_bounds__(ING_THREADS) void ing_scan_u64_kernel(unsigned long
         if (b < nb) blocks[b] = carry + ex;
         carry += total;
     }
-    if (threadIdx.x == 0) blocks[nb] = carry;
+    __syncthreads();
+    if (threadIdx.x == 0) *running = carry;
 }
 
 // what a byte becomes: 0 dropped, 1 a base, 2 the gap symbol that joins two records
@@ -194,15 +209,18 @@ __global__ __launch_bounds__(ING_THREADS) void ing_emit_kernel(const uint8_t *__
                                                                const uint8_t *__restrict__ lut, int join,
                                                                uint8_t gap_code, uint8_t *__restrict__ codes,
                                                                unsigned long long *__restrict__ rec_start,
-                                                               unsigned long long *__restrict__ hdr_pos) {
+                                                               unsigned long long *__restrict__ hdr_pos,
+                                                               uint64_t block0, unsigned long long rec_cap,
+                                                               unsigned int *__restrict__ rec_overflow) {
     __shared__ Agg lds[ING_THREADS];
     __shared__ unsigned long long ldk[ING_THREADS];
     __shared__ uint8_t s_lut[256];
     if (WRITE) s_lut[threadIdx.x] = lut[threadIdx.x];
-    Agg run_block = carry_agg[blockIdx.x];  // state in front of the tile being processed
-    unsigned long long kept_block = WRITE ? keep_blocks[blockIdx.x] : 0ull;
+    const uint64_t blk = block0 + blockIdx.x;
+    Agg run_block = carry_agg[blk];  // state in front of the tile being processed
+    unsigned long long kept_block = WRITE ? keep_blocks[blk] : 0ull;
     for (int tile = 0; tile < ING_TILES; tile++) {
-        const uint64_t tile_base = uint64_t(blockIdx.x) * ING_BLOCK + uint64_t(tile) * ING_TILE;
+        const uint64_t tile_base = blk * ING_BLOCK + uint64_t(tile) * ING_TILE;
         if (tile_base >= n) break;  // (block-uniform)
         const uint64_t base = tile_base + uint64_t(threadIdx.x) * ING_CHUNK;
         uint8_t c[ING_CHUNK], prev;
@@ -231,8 +249,12 @@ __global__ __launch_bounds__(ING_THREADS) void ing_emit_kernel(const uint8_t *__
                 const uint8_t p = i ? c[i - 1] : prev;
                 const uint32_t k = (cls >> (2 * i)) & 3u;
                 if (c[i] == '>' && p == '\n') {  // record ng starts here; its bases follow the joining gap, if any
-                    rec_start[ng] = out + (k == 2 ? 1 : 0);
-                    hdr_pos[ng] = base + i;
+                    if ((unsigned long long)ng < rec_cap) {
+                        rec_start[ng] = out + (k == 2 ? 1 : 0);
+                        hdr_pos[ng] = base + i;
+                    } else {
+                        atomicOr(rec_overflow, 1u);  // more records than the arrays hold: the caller sizes them again
+                    }
                     ng++;
                 }
                 if (k == 1) codes[out++] = s_lut[c[i]];
@@ -242,7 +264,7 @@ __global__ __launch_bounds__(ING_THREADS) void ing_emit_kernel(const uint8_t *__
         run_block = agg_join(run_block, total);
         kept_block += btotal;
     }
-    if (!WRITE && threadIdx.x == 0) keep_blocks[blockIdx.x] = kept_block;
+    if (!WRITE && threadIdx.x == 0) keep_blocks[blk] = kept_block;
 }
 
 }  // namespace
@@ -277,6 +299,22 @@ extern "C" void dvs_default_alphabet_lut(int rna, uint8_t lut[256]) {
     lut[(unsigned char)(rna ? 't' : 'u')] = 0;
 }
 
+// host bytes -> a pinned staging block, by a few threads (one thread moves ~10 GB/s; PCIe wants ~60)
+static void ing_stage(uint8_t *dst, const uint8_t *src, size_t n, unsigned nthreads) {
+    if (nthreads <= 1 || n < (4u << 20)) {
+        memcpy(dst, src, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t part = (n / nthreads + 4095) & ~size_t(4095);
+    for (unsigned t = 0; t < nthreads; t++) {
+        const size_t lo = size_t(t) * part, hi = std::min(n, lo + part);
+        if (lo >= hi) break;
+        th.emplace_back([=]() { memcpy(dst + lo, src + lo, hi - lo); });
+    }
+    for (auto &t : th) t.join();
+}
+
 extern "C" int dvs_seqbatch_from_fasta(dvs_ctx *ctx, const uint8_t *raw, int raw_on_device, uint64_t nbytes,
                                        const uint8_t *lut256, int join_records, dvs_seqbatch **out) {
     if (!ctx || !out || (!raw && nbytes)) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
@@ -293,7 +331,15 @@ extern "C" int dvs_seqbatch_from_fasta(dvs_ctx *ctx, const uint8_t *raw, int raw
     uint8_t *d_raw = nullptr, *d_lut = nullptr;
     Agg *d_agg = nullptr;
     unsigned long long *d_keep = nullptr, *d_rec = nullptr, *d_hdr = nullptr;
+    struct Running {  // the scans' running state behind the chunks processed so far, and the overflow flag
+        Agg agg;
+        unsigned long long kept;
+        unsigned int overflow, pad;
+    } *d_run = nullptr;
     bool own_raw = false;
+    hipStream_t scopy = nullptr;
+    std::vector<hipEvent_t> ev_copied, ev_free;
+    uint8_t *pinned = nullptr;
     int rc = DVS_OK;
     auto cleanup = [&]() {
         if (own_raw && d_raw) dvs_dev_free(ctx, d_raw);
@@ -302,12 +348,18 @@ extern "C" int dvs_seqbatch_from_fasta(dvs_ctx *ctx, const uint8_t *raw, int raw
         if (d_keep) dvs_dev_free(ctx, d_keep);
         if (d_rec) dvs_dev_free(ctx, d_rec);
         if (d_hdr) dvs_dev_free(ctx, d_hdr);
+        if (d_run) dvs_dev_free(ctx, d_run);
+        for (hipEvent_t e : ev_copied) dvs_event_put(ctx, e);
+        for (hipEvent_t e : ev_free) dvs_event_put(ctx, e);
+        if (scopy) (void)hipStreamDestroy(scopy);
+        if (pinned) (void)hipHostFree(pinned);
     };
 #define ING_TRY(expr)                                              \
     do {                                                           \
         hipError_t e__ = (expr);                                   \
         if (e__ != hipSuccess) {                                   \
             rc = dvs_hip_fail(ctx, e__, #expr);                    \
+            (void)hipDeviceSynchronize();                          \
             cleanup();                                             \
             dvs_seqbatch_destroy(b);                               \
             return rc;                                             \
@@ -317,61 +369,115 @@ extern "C" int dvs_seqbatch_from_fasta(dvs_ctx *ctx, const uint8_t *raw, int raw
     do {                                  \
         rc = (expr);                      \
         if (rc) {                         \
+            (void)hipDeviceSynchronize(); \
             cleanup();                    \
             dvs_seqbatch_destroy(b);      \
             return rc;                    \
         }                                 \
     } while (0)
+    // chunks: the whole file at once when it is already in HBM (or small), else 32 MiB pieces
+    uint64_t chunk_blocks = nb ? nb : 1;
+    const uint64_t CH_BLOCKS = (32ull << 20) / ING_BLOCK;
+    const bool streamed = !raw_on_device && nb >= 3 * CH_BLOCKS && !getenv("DVS_INGEST_NO_STREAM");
+    constexpr int NSLOT = 3;
+    unsigned nthreads = 1;
     if (raw_on_device) {
         d_raw = const_cast<uint8_t *>(raw);
     } else {
         own_raw = true;
         ING_RC(dvs_dev_alloc(ctx, (void **)&d_raw, nbytes + 16, "raw FASTA bytes"));
-        ING_TRY(hipMemcpyAsync(d_raw, raw, nbytes, hipMemcpyHostToDevice, ctx->stream));
+        if (streamed) {
+            chunk_blocks = CH_BLOCKS;
+            ING_TRY(hipStreamCreateWithFlags(&scopy, hipStreamNonBlocking));
+            ING_TRY(hipHostMalloc((void **)&pinned, size_t(NSLOT) * chunk_blocks * ING_BLOCK, hipHostMallocDefault));
+            for (int i = 0; i < NSLOT; i++) {
+                ev_copied.push_back(dvs_event_get(ctx));
+                ev_free.push_back(dvs_event_get(ctx));
+            }
+            nthreads = std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
+            if (const char *e = getenv("DVS_INGEST_THREADS")) nthreads = std::max(1, atoi(e));
+        } else {
+            ING_TRY(hipMemcpyAsync(d_raw, raw, nbytes, hipMemcpyHostToDevice, ctx->stream));
+        }
     }
     ING_RC(dvs_dev_alloc(ctx, (void **)&d_lut, 256, "alphabet table"));
     ING_TRY(hipMemcpyAsync(d_lut, lut, 256, hipMemcpyHostToDevice, ctx->stream));
     ING_RC(dvs_dev_alloc(ctx, (void **)&d_agg, (nb + 1) * sizeof(Agg), "ingest block aggregates"));
     ING_RC(dvs_dev_alloc(ctx, (void **)&d_keep, (nb + 1) * sizeof(unsigned long long), "ingest block counts"));
-    Agg tot_agg{-1, -1, 0};
-    unsigned long long total = 0;
-    if (nb) {
-        hipLaunchKernelGGL(ing_agg_kernel, dim3(uint32_t(nb)), dim3(ING_THREADS), 0, ctx->stream, d_raw, nbytes, d_agg);
-        hipLaunchKernelGGL(ing_scan_agg_kernel, dim3(1), dim3(ING_THREADS), 0, ctx->stream, d_agg, nb);
-        hipLaunchKernelGGL((ing_emit_kernel<false>), dim3(uint32_t(nb)), dim3(ING_THREADS), 0, ctx->stream, d_raw,
-                           nbytes, d_agg, d_keep, d_lut, join_records, gap, (uint8_t *)nullptr,
-                           (unsigned long long *)nullptr, (unsigned long long *)nullptr);
-        hipLaunchKernelGGL(ing_scan_u64_kernel, dim3(1), dim3(ING_THREADS), 0, ctx->stream, d_keep, nb);
+    ING_RC(dvs_dev_alloc(ctx, (void **)&d_run, sizeof(Running), "ingest running state"));
+    const Running run0{Agg{-1, -1, 0}, 0ull, 0u, 0u};
+    ING_TRY(hipMemcpyAsync(d_run, &run0, sizeof run0, hipMemcpyHostToDevice, ctx->stream));  // (run0 is const: staged)
+    // The number of records is known only at the end; the arrays are sized for records of >= 256 bytes on
+    // average (+ 1 M) and the kernel raises a flag instead of writing beyond them -- then the last pass is
+    // repeated over the whole file with arrays of the right size.
+    unsigned long long rec_cap = nbytes / 256 + (1ull << 20);
+    ING_RC(dvs_dev_alloc(ctx, (void **)&d_rec, rec_cap * 8, "record starts"));
+    ING_RC(dvs_dev_alloc(ctx, (void **)&d_hdr, rec_cap * 8, "header positions"));
+    // the encoded bases: never more than the file's bytes
+    ING_RC(dvs_dev_alloc(ctx, (void **)&b->d_codes, nbytes + 16, "encoded sequences"));
+    auto passes = [&](uint64_t block0, uint64_t nblk, bool all_five) {
+        const dim3 grid{uint32_t(nblk)}, blk{ING_THREADS};
+        hipLaunchKernelGGL(ing_agg_kernel, grid, blk, 0, ctx->stream, d_raw, nbytes, d_agg, block0);
+        hipLaunchKernelGGL(ing_scan_agg_kernel, dim3(1), blk, 0, ctx->stream, d_agg + block0, nblk, &d_run->agg);
+        hipLaunchKernelGGL((ing_emit_kernel<false>), grid, blk, 0, ctx->stream, d_raw, nbytes, d_agg, d_keep, d_lut,
+                           join_records, gap, (uint8_t *)nullptr, (unsigned long long *)nullptr,
+                           (unsigned long long *)nullptr, block0, 0ull, (unsigned int *)nullptr);
+        hipLaunchKernelGGL(ing_scan_u64_kernel, dim3(1), blk, 0, ctx->stream, d_keep + block0, nblk, &d_run->kept);
+        if (all_five)
+            hipLaunchKernelGGL((ing_emit_kernel<true>), grid, blk, 0, ctx->stream, d_raw, nbytes, d_agg, d_keep, d_lut,
+                               join_records, gap, b->d_codes, d_rec, d_hdr, block0, rec_cap, &d_run->overflow);
+    };
+    if (streamed) {
+        const uint64_t cbytes = chunk_blocks * ING_BLOCK;
+        uint64_t c = 0;
+        for (uint64_t block0 = 0; block0 < nb; block0 += chunk_blocks, c++) {
+            const int slot = int(c % NSLOT);
+            const uint64_t off = block0 * ING_BLOCK, len = std::min<uint64_t>(cbytes, nbytes - off);
+            if (c >= uint64_t(NSLOT)) ING_TRY(hipEventSynchronize(ev_free[slot]));  // its last copy has left the block
+            ing_stage(pinned + size_t(slot) * cbytes, raw + off, len, nthreads);
+            ING_TRY(hipMemcpyAsync(d_raw + off, pinned + size_t(slot) * cbytes, len, hipMemcpyHostToDevice, scopy));
+            ING_TRY(hipEventRecord(ev_free[slot], scopy));
+            ING_TRY(hipEventRecord(ev_copied[slot], scopy));
+            ING_TRY(hipStreamWaitEvent(ctx->stream, ev_copied[slot], 0));
+            passes(block0, std::min<uint64_t>(chunk_blocks, nb - block0), true);
+            ING_TRY(hipGetLastError());
+        }
+    } else if (nb) {
+        passes(0, nb, true);
         ING_TRY(hipGetLastError());
-        ING_TRY(hipMemcpyAsync(&tot_agg, d_agg + nb, sizeof(Agg), hipMemcpyDeviceToHost, ctx->stream));
-        ING_TRY(hipMemcpyAsync(&total, d_keep + nb, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    Running fin = run0;
+    if (nb) {
+        ING_TRY(hipMemcpyAsync(&fin, d_run, sizeof fin, hipMemcpyDeviceToHost, ctx->stream));
         ING_TRY(hipStreamSynchronize(ctx->stream));
     }
-    const uint64_t nrec = uint64_t(tot_agg.ng);
+    const uint64_t nrec = uint64_t(fin.agg.ng), total = fin.kept;
     if (nrec > 0xFFFFFFFFull) {
         cleanup();
         dvs_seqbatch_destroy(b);
         return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "more than 2^32 - 1 records in one file");
     }
+    if (fin.overflow) {  // more (shorter) records than the arrays were sized for: the last pass again, over everything
+        dvs_dev_free(ctx, d_rec);
+        dvs_dev_free(ctx, d_hdr);
+        d_rec = d_hdr = nullptr;
+        rec_cap = nrec;
+        ING_RC(dvs_dev_alloc(ctx, (void **)&d_rec, rec_cap * 8, "record starts"));
+        ING_RC(dvs_dev_alloc(ctx, (void **)&d_hdr, rec_cap * 8, "header positions"));
+        hipLaunchKernelGGL((ing_emit_kernel<true>), dim3(uint32_t(nb)), dim3(ING_THREADS), 0, ctx->stream, d_raw, nbytes,
+                           d_agg, d_keep, d_lut, join_records, gap, b->d_codes, d_rec, d_hdr, 0ull, rec_cap,
+                           &d_run->overflow);
+        ING_TRY(hipGetLastError());
+    }
     b->total = total;
-    ING_RC(dvs_dev_alloc(ctx, (void **)&b->d_codes, total + 16, "encoded sequences"));
     ING_TRY(hipMemsetAsync(b->d_codes + total, 0xFF, 16, ctx->stream));  // invalid filler behind the last base
     std::vector<uint64_t> starts(nrec);
     b->header_pos.resize(nrec);
-    if (nb && nrec) {
-        ING_RC(dvs_dev_alloc(ctx, (void **)&d_rec, nrec * 8, "record starts"));
-        ING_RC(dvs_dev_alloc(ctx, (void **)&d_hdr, nrec * 8, "header positions"));
+    if (nrec) {
+        ING_TRY(hipMemcpyAsync(starts.data(), d_rec, nrec * 8, hipMemcpyDeviceToHost, ctx->stream));
+        ING_TRY(hipMemcpyAsync(b->header_pos.data(), d_hdr, nrec * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (nb) {
-        hipLaunchKernelGGL((ing_emit_kernel<true>), dim3(uint32_t(nb)), dim3(ING_THREADS), 0, ctx->stream, d_raw,
-                           nbytes, d_agg, d_keep, d_lut, join_records, gap, b->d_codes, d_rec, d_hdr);
-        ING_TRY(hipGetLastError());
-        if (nrec) {
-            ING_TRY(hipMemcpyAsync(starts.data(), d_rec, nrec * 8, hipMemcpyDeviceToHost, ctx->stream));
-            ING_TRY(hipMemcpyAsync(b->header_pos.data(), d_hdr, nrec * 8, hipMemcpyDeviceToHost, ctx->stream));
-        }
-        ING_TRY(hipStreamSynchronize(ctx->stream));
-    }
+    ING_TRY(hipStreamSynchronize(ctx->stream));
 #undef ING_TRY
 #undef ING_RC
     if (join_records) {

@@ -479,21 +479,23 @@ struct DevBuf {
     T *as() { return static_cast<T *>(p); }
 };
 
+struct PooledBuf {  // a block of the context's cache, handed back on scope exit
+    dvs_ctx *ctx;
+    void *p = nullptr;
+    ~PooledBuf() { dvs_dev_free(ctx, p); }
+    template <typename T>
+    T *as() { return static_cast<T *>(p); }
+};
+
 }  // namespace
 
-extern "C" int dvs_mash_sketch(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device,
-                               const uint64_t *offsets, uint32_t nseq, uint32_t k,
-                               uint32_t sketch_size, uint32_t num_states, int mash_canonical,
-                               uint32_t *sketches_out, uint32_t *lens_out) {
-    if (!ctx || !offsets || !sketches_out || !lens_out)
-        return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
-    if (k == 0 || k > MAX_K)
-        return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "mash k = %u outside 1..%d", k, MAX_K);
-    if (sketch_size == 0) {
-        for (uint32_t i = 0; i < nseq; i++) lens_out[i] = 0;
-        return DVS_OK;
-    }
-    if (nseq == 0) return DVS_OK;
+// sketches of a batch, left in HBM: nseq x sketch_size uint32 (ascending, first d_lens[i] valid) in
+// blocks of the context's cache (the caller hands them back with dvs_dev_free)
+static int mash_sketch_core(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, const uint64_t *offsets,
+                            uint32_t nseq, uint32_t k, uint32_t sketch_size, uint32_t num_states,
+                            int mash_canonical, uint32_t **d_sk_out, uint32_t **d_lens_out) {
+    *d_sk_out = nullptr;
+    *d_lens_out = nullptr;
     DVS_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t s = sketch_size;
     const uint64_t nbytes = offsets[nseq];
@@ -537,7 +539,8 @@ extern "C" int dvs_mash_sketch(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_de
             tiles.push_back(t);
         }
     }
-    DevBuf d_tiles, d_lo, d_hi, d_cap, d_coff, d_cnt, d_active, d_cand, d_list, d_sk, d_lens, d_status;
+    DevBuf d_tiles, d_lo, d_hi, d_cap, d_coff, d_cnt, d_active, d_cand, d_list, d_status;
+    PooledBuf d_sk{ctx}, d_lens{ctx};  // (the two results live in the context's cache; released here unless handed over)
     const size_t ntile = std::max<size_t>(tiles.size(), 1);
     DVS_HIP(ctx, hipMalloc(&d_tiles.p, ntile * sizeof(MTile)));
     DVS_HIP(ctx, hipMalloc(&d_lo.p, nseq * 8));
@@ -548,8 +551,11 @@ extern "C" int dvs_mash_sketch(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_de
     DVS_HIP(ctx, hipMalloc(&d_active.p, nseq));
     DVS_HIP(ctx, hipMalloc(&d_cand.p, std::max<uint64_t>(coff[nseq], 1) * 4));
     DVS_HIP(ctx, hipMalloc(&d_list.p, nseq * 4));
-    DVS_HIP(ctx, hipMalloc(&d_sk.p, size_t(nseq) * s * 4));
-    DVS_HIP(ctx, hipMalloc(&d_lens.p, nseq * 4));
+    {
+        int arc = dvs_dev_alloc(ctx, &d_sk.p, size_t(nseq) * s * 4, "sketches");
+        if (!arc) arc = dvs_dev_alloc(ctx, &d_lens.p, size_t(nseq) * 4, "sketch lengths");
+        if (arc) return arc;
+    }
     DVS_HIP(ctx, hipMalloc(&d_status.p, nseq * 4));
     if (!tiles.empty())
         DVS_HIP(ctx, hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(MTile),
@@ -635,10 +641,145 @@ extern "C" int dvs_mash_sketch(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_de
             }
         }
     }
-    DVS_HIP(ctx, hipMemcpyAsync(sketches_out, d_sk.p, size_t(nseq) * s * 4, hipMemcpyDeviceToHost, ctx->stream));
-    DVS_HIP(ctx, hipMemcpyAsync(lens_out, d_lens.p, nseq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    *d_sk_out = d_sk.as<uint32_t>();
+    *d_lens_out = d_lens.as<uint32_t>();
+    d_sk.p = d_lens.p = nullptr;  // handed over
+    return DVS_OK;
+}
+
+static int mash_check_args(dvs_ctx *ctx, const uint64_t *offsets, uint32_t k) {
+    if (!ctx || !offsets) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (k == 0 || k > MAX_K)
+        return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "mash k = %u outside 1..%d", k, MAX_K);
+    return DVS_OK;
+}
+
+extern "C" int dvs_mash_sketch(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device,
+                               const uint64_t *offsets, uint32_t nseq, uint32_t k,
+                               uint32_t sketch_size, uint32_t num_states, int mash_canonical,
+                               uint32_t *sketches_out, uint32_t *lens_out) {
+    if (!sketches_out || !lens_out) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    int rc = mash_check_args(ctx, offsets, k);
+    if (rc) return rc;
+    if (sketch_size == 0) {
+        for (uint32_t i = 0; i < nseq; i++) lens_out[i] = 0;
+        return DVS_OK;
+    }
+    if (nseq == 0) return DVS_OK;
+    uint32_t *d_sk = nullptr, *d_lens = nullptr;
+    rc = mash_sketch_core(ctx, seqs, seqs_on_device, offsets, nseq, k, sketch_size, num_states, mash_canonical,
+                          &d_sk, &d_lens);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(sketches_out, d_sk, size_t(nseq) * sketch_size * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(lens_out, d_lens, size_t(nseq) * 4, hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t se = hipStreamSynchronize(ctx->stream);
+    dvs_dev_free(ctx, d_sk);
+    dvs_dev_free(ctx, d_lens);
+    if (e != hipSuccess) return dvs_hip_fail(ctx, e, "sketch copy");
+    if (se != hipSuccess) return dvs_hip_fail(ctx, se, "sketch copy");
+    return DVS_OK;
+}
+
+// ---- sketches that stay in HBM between the two stages of ctree (sketch, then N x N distances)
+struct dvs_sketches {
+    dvs_ctx *ctx = nullptr;
+    uint32_t nseq = 0, stride = 0;
+    uint32_t *d_sk = nullptr, *d_lens = nullptr;
+};
+
+extern "C" int dvs_sketches_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, const uint64_t *offsets,
+                                  uint32_t nseq, uint32_t k, uint32_t sketch_size, uint32_t num_states,
+                                  int mash_canonical, dvs_sketches **out) {
+    if (!out) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    *out = nullptr;
+    int rc = mash_check_args(ctx, offsets, k);
+    if (rc) return rc;
+    dvs_sketches *sk = new dvs_sketches();
+    sk->ctx = ctx;
+    sk->nseq = nseq;
+    sk->stride = sketch_size;
+    dvs_ctx_retain(ctx);
+    if (nseq && sketch_size) {
+        rc = mash_sketch_core(ctx, seqs, seqs_on_device, offsets, nseq, k, sketch_size, num_states, mash_canonical,
+                              &sk->d_sk, &sk->d_lens);
+        if (rc) {
+            dvs_ctx_release(ctx);
+            delete sk;
+            return rc;
+        }
+    }
+    *out = sk;
+    return DVS_OK;
+}
+
+extern "C" void dvs_sketches_destroy(dvs_sketches *sk) {
+    if (!sk) return;
+    dvs_dev_free(sk->ctx, sk->d_sk);
+    dvs_dev_free(sk->ctx, sk->d_lens);
+    dvs_ctx_release(sk->ctx);
+    delete sk;
+}
+
+extern "C" int dvs_sketches_get(dvs_ctx *ctx, const dvs_sketches *sk, uint32_t *sketches_out, uint32_t *lens_out) {
+    if (!ctx || !sk || !lens_out) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (!sk->d_sk) {
+        for (uint32_t i = 0; i < sk->nseq; i++) lens_out[i] = 0;
+        return DVS_OK;
+    }
+    if (sketches_out)
+        DVS_HIP(ctx, hipMemcpyAsync(sketches_out, sk->d_sk, size_t(sk->nseq) * sk->stride * 4, hipMemcpyDeviceToHost,
+                                    ctx->stream));
+    DVS_HIP(ctx, hipMemcpyAsync(lens_out, sk->d_lens, size_t(sk->nseq) * 4, hipMemcpyDeviceToHost, ctx->stream));
     DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return DVS_OK;
+}
+extern "C" const void *dvs_sketches_dev(const dvs_sketches *sk) { return sk ? sk->d_sk : nullptr; }
+extern "C" const void *dvs_sketches_dev_lens(const dvs_sketches *sk) { return sk ? sk->d_lens : nullptr; }
+
+// the pair kernel over sketches in HBM; dist (host, nseq x nseq) receives the visited cells
+static int mash_pairs_device(dvs_ctx *ctx, const uint32_t *d_sk, const uint32_t *d_lens, uint32_t nseq, uint32_t stride,
+                             uint32_t k, uint32_t sketch_size, uint32_t row_start, uint32_t row_stride, int symmetric,
+                             double *dist) {
+    double *d_dist = nullptr;
+    uint32_t *d_flag = nullptr;
+    int rc = dvs_dev_alloc(ctx, (void **)&d_dist, size_t(nseq) * nseq * 8, "distance matrix");
+    if (!rc) rc = dvs_dev_alloc(ctx, (void **)&d_flag, 4, "flag");
+    if (rc) {
+        dvs_dev_free(ctx, d_dist);
+        return rc;
+    }
+    // (cells this call does not visit keep the caller's values: the matrix starts as its copy)
+    hipError_t e = hipMemcpyAsync(d_dist, dist, size_t(nseq) * nseq * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, 4, ctx->stream);
+    const uint32_t nrows = (nseq - 1 - row_start) / row_stride + 1;
+    uint32_t flag = 0;
+    if (e == hipSuccess) {
+        const dim3 grid((nseq + 255) / 256, nrows);
+        hipLaunchKernelGGL(mash_pairs_kernel, grid, dim3(256), MASH_PAIR_LDS * 4, ctx->stream, d_sk, d_lens, nseq, k,
+                           sketch_size, stride, row_start, row_stride, symmetric, d_dist, d_flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(dist, d_dist, size_t(nseq) * nseq * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t se = hipStreamSynchronize(ctx->stream);
+    dvs_dev_free(ctx, d_dist);
+    dvs_dev_free(ctx, d_flag);
+    if (e != hipSuccess) return dvs_hip_fail(ctx, e, "mash distances");
+    if (se != hipSuccess) return dvs_hip_fail(ctx, se, "mash distances");
+    if (flag) return dvs_set_error(ctx, DVS_ERR_ZERODIV, "division by zero");  // 0 / 0, distance.py:283
+    return DVS_OK;
+}
+
+extern "C" int dvs_sketches_distances(dvs_ctx *ctx, const dvs_sketches *sk, uint32_t k, uint32_t sketch_size,
+                                      uint32_t row_start, uint32_t row_stride, int symmetric, double *dist) {
+    if (!ctx || !sk || !dist) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (sk->nseq < 2 || row_start >= sk->nseq) return DVS_OK;
+    if (row_stride == 0) row_stride = 1;
+    if (k == 0) return dvs_set_error(ctx, DVS_ERR_ZERODIV, "float division by zero");
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    if (!sk->d_sk) return dvs_set_error(ctx, DVS_ERR_ZERODIV, "division by zero");  // every sketch empty
+    return mash_pairs_device(ctx, sk->d_sk, sk->d_lens, sk->nseq, sk->stride, k, sketch_size, row_start, row_stride,
+                             symmetric, dist);
 }
 
 extern "C" int dvs_mash_distances(dvs_ctx *ctx, const uint32_t *sketches, uint32_t sketch_stride,
@@ -656,28 +797,19 @@ extern "C" int dvs_mash_distances(dvs_ctx *ctx, const uint32_t *sketches, uint32
     if (k == 0) return dvs_set_error(ctx, DVS_ERR_ZERODIV, "float division by zero");
     DVS_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t s = std::max<uint32_t>(sketch_stride, 1);
-    DevBuf d_sk, d_lens, d_dist, d_flag;
-    DVS_HIP(ctx, hipMalloc(&d_sk.p, size_t(nseq) * s * 4));
-    DVS_HIP(ctx, hipMalloc(&d_lens.p, nseq * 4));
-    DVS_HIP(ctx, hipMalloc(&d_dist.p, size_t(nseq) * nseq * 8));
-    DVS_HIP(ctx, hipMalloc(&d_flag.p, 4));
-    if (sketch_stride)
-        DVS_HIP(ctx, hipMemcpyAsync(d_sk.p, sketches, size_t(nseq) * s * 4, hipMemcpyHostToDevice, ctx->stream));
-    DVS_HIP(ctx, hipMemcpyAsync(d_lens.p, lens, nseq * 4, hipMemcpyHostToDevice, ctx->stream));
-    DVS_HIP(ctx, hipMemcpyAsync(d_dist.p, dist, size_t(nseq) * nseq * 8, hipMemcpyHostToDevice, ctx->stream));
-    DVS_HIP(ctx, hipMemsetAsync(d_flag.p, 0, 4, ctx->stream));
-    const uint32_t nrows = (nseq - 1 - row_start) / row_stride + 1;
-    const dim3 grid((nseq + 255) / 256, nrows);
-    hipLaunchKernelGGL(mash_pairs_kernel, grid, dim3(256), MASH_PAIR_LDS * 4, ctx->stream, d_sk.as<uint32_t>(),
-                       d_lens.as<uint32_t>(), nseq, k, sketch_size, s, row_start, row_stride, symmetric,
-                       d_dist.as<double>(), d_flag.as<uint32_t>());
-    DVS_HIP(ctx, hipGetLastError());
-    uint32_t flag = 0;
-    DVS_HIP(ctx, hipMemcpyAsync(dist, d_dist.p, size_t(nseq) * nseq * 8, hipMemcpyDeviceToHost, ctx->stream));
-    DVS_HIP(ctx, hipMemcpyAsync(&flag, d_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (flag) return dvs_set_error(ctx, DVS_ERR_ZERODIV, "division by zero");  // 0 / 0, distance.py:283
-    return DVS_OK;
+    uint32_t *d_sk = nullptr, *d_lens = nullptr;
+    int rc = dvs_dev_alloc(ctx, (void **)&d_sk, size_t(nseq) * s * 4, "sketches");
+    if (!rc) rc = dvs_dev_alloc(ctx, (void **)&d_lens, size_t(nseq) * 4, "sketch lengths");
+    hipError_t e = hipSuccess;
+    if (!rc && sketch_stride)
+        e = hipMemcpyAsync(d_sk, sketches, size_t(nseq) * s * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (!rc && e == hipSuccess) e = hipMemcpyAsync(d_lens, lens, size_t(nseq) * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (!rc && e != hipSuccess) rc = dvs_hip_fail(ctx, e, "sketch upload");
+    if (!rc) rc = mash_pairs_device(ctx, d_sk, d_lens, nseq, s, k, sketch_size, row_start, row_stride, symmetric, dist);
+    else (void)hipStreamSynchronize(ctx->stream);
+    dvs_dev_free(ctx, d_sk);
+    dvs_dev_free(ctx, d_lens);
+    return rc;
 }
 
 extern "C" int dvs_euclidean_distances(dvs_ctx *ctx, const dvs_matrix *m, double *dist) {

@@ -72,11 +72,65 @@ def mash_distance(left_sketch, right_sketch, k: int, sketch_size: int) -> float:
     return float(d[1, 0])
 
 
+class Sketches:
+    """bottom-s sketches of a batch resident in HBM (dvs_sketches): the hand-over between the two
+    stages of ctree (diverse_seq/cluster.py:241-297) without a trip through the host"""
+
+    def __init__(self, seqs, k: int, sketch_size: int, num_states: int = 4, mash_canonical: bool = False,
+                 ctx: engine.Context | None = None, dev_ptr: int | None = None, offsets=None):
+        self.ctx = ctx or engine.default_context()
+        if dev_ptr is None:
+            data, offsets = engine.concat(seqs)
+            src, on_dev = data.ctypes.data_as(C.c_void_p), 0
+        else:  # sequences already in HBM
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+            src, on_dev = C.c_void_p(dev_ptr), 1
+        self.n = offsets.size - 1
+        lens_in = np.diff(offsets.astype(np.int64)) if self.n else np.zeros(0, dtype=np.int64)
+        longest = int(max(0, (lens_in.max() if self.n else 0) - k + 1))
+        if sketch_size < 0 or sketch_size > _U32_MAX:
+            raise OverflowError("sketch_size out of range for u32")
+        self.k, self.sketch_size = k, int(sketch_size)
+        self.stride = max(1, min(int(sketch_size), longest)) if sketch_size else 0
+        h = C.c_void_p()
+        self.ctx.check(self.ctx._L.dvs_sketches_build(self.ctx._h, src, on_dev, _lib.ptr(offsets, C.c_uint64), self.n, k,
+                                                      self.stride, num_states, int(bool(mash_canonical)), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._L.dvs_sketches_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def to_host(self):
+        """(uint32 [n, stride], lens uint32 [n])"""
+        sk = np.zeros((self.n, max(self.stride, 1)), dtype=np.uint32)
+        lens = np.zeros(self.n, dtype=np.uint32)
+        self.ctx.check(self.ctx._L.dvs_sketches_get(self.ctx._h, self._h, _lib.ptr(sk, C.c_uint32), _lib.ptr(lens, C.c_uint32)))
+        return sk, lens
+
+    def distances(self, *, row_start: int = 0, row_stride: int = 1, symmetric: bool = True) -> np.ndarray:
+        dist = np.zeros((self.n, self.n), dtype=np.float64)
+        self.ctx.check(self.ctx._L.dvs_sketches_distances(self.ctx._h, self._h, self.k, min(self.sketch_size, _U32_MAX),
+                                                          row_start, row_stride, int(symmetric), _lib.ptr(dist, C.c_double)))
+        return dist
+
+
 def mash_distances(seqs, k: int, sketch_size: int, num_states: int = 4,
-                   mash_canonical: bool = False) -> np.ndarray:
-    """diverse_seq/distance.py:119-175: sketches, then the symmetric N x N matrix"""
-    sk, lens = sketch_batch(seqs, k, sketch_size, num_states, mash_canonical)
-    return distances_from_sketches(sk, lens, k, sketch_size)
+                   mash_canonical: bool = False, ctx: engine.Context | None = None) -> np.ndarray:
+    """diverse_seq/distance.py:119-175: sketches, then the symmetric N x N matrix; the sketches stay in
+    HBM between the two stages"""
+    sk = Sketches(seqs, k, sketch_size, num_states, mash_canonical, ctx=ctx)
+    try:
+        return sk.distances()
+    finally:
+        sk.close()
 
 
 def euclidean_distances(seqs, k: int, num_states: int = 4,

@@ -266,6 +266,20 @@ int dvs_mash_distances(dvs_ctx *ctx, const uint32_t *sketches, uint32_t sketch_s
                        const uint32_t *lens, uint32_t nseq, uint32_t k, uint32_t sketch_size,
                        uint32_t row_start, uint32_t row_stride, int symmetric,
                        double *dist);
+/* The two stages of ctree (diverse_seq/cluster.py:241-297: sketches, then the N x N distances) with
+ * the sketches left in HBM between them: dvs_sketches_build = dvs_mash_sketch without the copy to
+ * the host, dvs_sketches_distances = dvs_mash_distances on that handle, dvs_sketches_get copies
+ * sketches (may be NULL) and lengths out (what _dvs.mash_sketch returns). */
+typedef struct dvs_sketches dvs_sketches;
+int dvs_sketches_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, const uint64_t *offsets,
+                       uint32_t nseq, uint32_t k, uint32_t sketch_size, uint32_t num_states,
+                       int mash_canonical, dvs_sketches **out);
+void dvs_sketches_destroy(dvs_sketches *sk);
+int dvs_sketches_get(dvs_ctx *ctx, const dvs_sketches *sk, uint32_t *sketches_out, uint32_t *lens_out);
+const void *dvs_sketches_dev(const dvs_sketches *sk);      /* uint32 [nseq x sketch_size] in HBM */
+const void *dvs_sketches_dev_lens(const dvs_sketches *sk); /* uint32 [nseq] */
+int dvs_sketches_distances(dvs_ctx *ctx, const dvs_sketches *sk, uint32_t k, uint32_t sketch_size,
+                           uint32_t row_start, uint32_t row_stride, int symmetric, double *dist);
 /* euclidean_distances (diverse_seq/distance.py:294-336): ||f_i - f_j||_2 over
  * the rows of m, full symmetric nrows x nrows matrix */
 int dvs_euclidean_distances(dvs_ctx *ctx, const dvs_matrix *m, double *dist);

@@ -201,3 +201,54 @@ def test_device_ingest_of_genbank_files(ctx):
         assert np.array_equal(joined.sequences()[0], exp[0])
         b.close()
         joined.close()
+
+
+@pytest.mark.gpu
+def test_streamed_upload_gives_the_same_batch(monkeypatch):
+    """a file in host memory beyond 96 MiB travels in 32 MiB chunks through pinned staging, every scan
+    carrying its state from chunk to chunk: the same codes, offsets and header positions as the one-copy
+    path, with records cut by the chunk seams (and the one-copy path is the oracle-checked one above)"""
+    from diverseseq_amd import engine
+
+    ctx = engine.default_context()
+    rng = np.random.default_rng(12)
+    recs = []
+    for r in range(37):
+        n = int(rng.integers(1_000_000, 6_000_000))
+        body = np.frombuffer(b"ACGTNacgt-", dtype=np.uint8)[rng.integers(0, 10, size=n)]
+        lines = np.concatenate([body, np.zeros((-n) % 61, dtype=np.uint8)]).reshape(-1, 61)
+        lines = np.concatenate([lines, np.full((lines.shape[0], 1), 10, dtype=np.uint8)], axis=1).ravel()
+        recs.append(np.frombuffer(b">rec%03d some description\r\n" % r, dtype=np.uint8))
+        recs.append(lines[lines != 0])
+    raw = np.concatenate(recs)
+    assert raw.size > 100 << 20
+    a = ctx.encode_fasta(raw)
+    monkeypatch.setenv("DVS_INGEST_NO_STREAM", "1")
+    b = ctx.encode_fasta(raw)
+    assert a.nseq == b.nseq == 37 and a.total == b.total
+    assert (a.offsets == b.offsets).all() and (a.header_positions == b.header_positions).all()
+    assert (a.codes() == b.codes()).all()
+    assert a.labels[5] == "rec005 some description"
+    _, seqs = oracle.load_fasta(raw[: int(a.header_positions[2])].tobytes())  # the first two records, in full
+    got = a.sequences()
+    assert (got[0] == seqs[0]).all() and (got[1] == seqs[1]).all()
+    # joined: one sequence, a gap between records
+    monkeypatch.delenv("DVS_INGEST_NO_STREAM")
+    j = ctx.encode_fasta(raw, join_records=True)
+    assert j.nseq == 1 and j.total == a.total + 36
+
+
+@pytest.mark.gpu
+def test_more_records_than_the_arrays_were_sized_for():
+    """records of a few bytes each: the record arrays (sized for records of >= 256 bytes) overflow, the
+    kernel says so and the last pass is repeated with arrays of the right size"""
+    from diverseseq_amd import engine
+
+    ctx = engine.default_context()
+    nrec = 1_500_000
+    raw = np.tile(np.frombuffer(b">a\nACGT\n", dtype=np.uint8), nrec)
+    b = ctx.encode_fasta(raw)
+    assert b.nseq == nrec and b.total == 4 * nrec
+    assert (b.offsets == np.arange(nrec + 1, dtype=np.uint64) * 4).all()
+    assert (b.header_positions == np.arange(nrec, dtype=np.uint64) * 8).all()
+    assert (b.codes()[:8] == np.array([2, 1, 3, 0, 2, 1, 3, 0], dtype=np.uint8)).all()
