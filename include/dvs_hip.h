@@ -98,8 +98,8 @@ uint32_t dvs_matrix_nrows(const dvs_matrix *m);
 uint64_t dvs_matrix_nbins(const dvs_matrix *m);
 /* device pointers (for zero-copy hand-off to the host framework) */
 /* counts [nrows x nbins], or NULL for a frequency matrix.  The elements are uint32, or uint16 when
- * every sequence of the build was at most 32768 k-mer windows long (no count can reach 2^16; the
- * build's write and the scan's read move half the bytes): dvs_matrix_count_bytes says which (4, 2;
+ * every sequence of the build was at most 32768 k-mer windows long and there are at most 4096 bins
+ * (no count can reach 2^16; the build's write and the scan's read move half the bytes): dvs_matrix_count_bytes says which (4, 2;
  * 0 for a frequency matrix).  DVS_COUNTS_U32=1 in the environment keeps every build at uint32. */
 const void *dvs_matrix_dev_counts(const dvs_matrix *m);
 uint32_t dvs_matrix_count_bytes(const dvs_matrix *m);
