@@ -187,6 +187,8 @@ void dvs_ctx_release(dvs_ctx *ctx) {
     dvs_dev_free(ctx, ctx->off_cache.d_off);
     dvs_dev_free(ctx, ctx->off_cache.d_rows);
     dvs_dev_free(ctx, ctx->off_cache.d_tiles);
+    if (ctx->off_cache.ev_up) (void)hipEventDestroy(ctx->off_cache.ev_up);
+    if (ctx->off_cache.h_off) (void)hipHostFree(ctx->off_cache.h_off);
     dvs_dev_free(ctx, ctx->d_clog_tbl);
     dvs_dev_trim(ctx);
     for (void *p : ctx->pinned_pool) (void)hipHostFree(p);

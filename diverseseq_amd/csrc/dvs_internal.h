@@ -46,14 +46,20 @@ struct dvs_ctx {
     // validation pass, the tile lists and their uploads (~0.1 ms of host time per 100k sequences,
     // during which the GPU would wait for its first launch).
     struct OffsetsCache {
-        std::vector<uint64_t> h_off;
-        // host sources of the uploads below: pageable memory an async copy may still read after the
+        // the offsets on the host, in PINNED memory: the validation pass writes them there and the upload
+        // reads them from there, so it is a real asynchronous copy (a pageable source is staged by the
+        // runtime inside the call); ev_up marks the last upload that read the block
+        uint64_t *h_off = nullptr;
+        size_t h_cap = 0, n_off = 0;  // capacity / valid entries (nseq + 1)
+        hipEvent_t ev_up = nullptr;
+        // host sources of the other uploads: pageable memory an async copy may still read after the
         // call returned, so they live as long as the cache entry
         std::vector<uint32_t> h_long_rows;
         std::vector<unsigned char> h_tiles;
         uint64_t nbytes = 0;
         uint32_t k = 0;
         void *d_off = nullptr, *d_rows = nullptr, *d_tiles = nullptr;
+        size_t d_off_cap = 0;
         size_t n_long = 0, n_tiles = 0;
     } off_cache;
 };

@@ -429,14 +429,32 @@ void dvs_matrix_free_fields(dvs_matrix *m) {
 int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint32_t k, uint64_t nbytes,
                      size_t *n_long_out) {
     dvs_ctx::OffsetsCache &oc = ctx->off_cache;
-    const bool hit = oc.d_off && oc.k == k && oc.nbytes == nbytes && oc.h_off.size() == size_t(nseq) + 1 &&
-                     std::memcmp(oc.h_off.data(), offsets, (size_t(nseq) + 1) * 8) == 0 &&
-                     !getenv("DVS_NO_OFFSETS_CACHE");
+    const size_t n_off = size_t(nseq) + 1;
+    const bool hit = oc.d_off && oc.h_off && oc.k == k && oc.nbytes == nbytes && oc.n_off == n_off &&
+                     !getenv("DVS_NO_OFFSETS_CACHE") && std::memcmp(oc.h_off, offsets, n_off * 8) == 0;
     if (!hit) {
+        // the pinned block: no upload may still be reading it, and it must be large enough
+        if (oc.ev_up) (void)hipEventSynchronize(oc.ev_up);
+        if (oc.h_cap < n_off) {
+            if (oc.h_off) (void)hipHostFree(oc.h_off);
+            oc.h_off = nullptr;
+            oc.h_cap = 0;
+            const size_t cap = std::max<size_t>(n_off + n_off / 4, 1024);
+            const hipError_t he = hipHostMalloc((void **)&oc.h_off, cap * 8, hipHostMallocDefault);
+            if (he != hipSuccess) {
+                oc.h_off = nullptr;
+                return dvs_hip_fail(ctx, he, "pinned offsets block");
+            }
+            oc.h_cap = cap;
+        }
+        oc.n_off = 0;  // (the block is being rewritten: no hit on a half-written copy after an error)
         std::vector<KTile> tiles;
         std::vector<uint32_t> long_rows;
-        for (uint32_t r = 0; r < nseq; r++) {
+        uint64_t *dst = oc.h_off;
+        dst[0] = offsets[0];
+        for (uint32_t r = 0; r < nseq; r++) {  // validation, tile lists and the pinned copy in one pass
             const uint64_t s0 = offsets[r], s1 = offsets[r + 1];
+            dst[r + 1] = s1;
             if (s1 < s0 || s1 > nbytes)
                 return dvs_set_error(ctx, DVS_ERR_VALUE, "offsets[%u..%u] = %llu..%llu out of range", r,
                                      r + 1, (unsigned long long)s0, (unsigned long long)s1);
@@ -455,21 +473,31 @@ int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint3
             }
         }
         // (the previous lists go back to the block cache; stream order protects them until the
-        // kernels that read them have run)
-        dvs_dev_free(ctx, oc.d_off);
+        // kernels that read them have run; the offsets block is kept while it is large enough)
         dvs_dev_free(ctx, oc.d_rows);
         dvs_dev_free(ctx, oc.d_tiles);
-        oc = dvs_ctx::OffsetsCache();
-        int arc = dvs_dev_alloc(ctx, &oc.d_off, size_t(nseq + 1) * 8, "offsets");
+        oc.d_rows = oc.d_tiles = nullptr;
+        oc.n_long = oc.n_tiles = 0;
+        int arc = DVS_OK;
+        if (oc.d_off_cap < n_off) {
+            dvs_dev_free(ctx, oc.d_off);
+            oc.d_off = nullptr;
+            oc.d_off_cap = 0;
+            arc = dvs_dev_alloc(ctx, &oc.d_off, (n_off + n_off / 4) * 8, "offsets");
+            if (!arc) oc.d_off_cap = n_off + n_off / 4;
+        }
         if (!arc && !long_rows.empty()) arc = dvs_dev_alloc(ctx, &oc.d_rows, long_rows.size() * 4, "row list");
         if (!arc && !tiles.empty()) arc = dvs_dev_alloc(ctx, &oc.d_tiles, tiles.size() * sizeof(KTile), "tile list");
         hipError_t ue = hipSuccess;
-        // (every upload reads from the cache entry's own copies, which outlive the call)
-        oc.h_off.assign(offsets, offsets + size_t(nseq) + 1);
+        // (the other uploads read from the cache entry's own copies, which outlive the call)
         oc.h_tiles.assign(reinterpret_cast<const unsigned char *>(tiles.data()),
                           reinterpret_cast<const unsigned char *>(tiles.data()) + tiles.size() * sizeof(KTile));
         oc.h_long_rows = long_rows;
-        if (!arc) ue = hipMemcpyAsync(oc.d_off, oc.h_off.data(), size_t(nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (!arc) ue = hipMemcpyAsync(oc.d_off, oc.h_off, n_off * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (!arc && ue == hipSuccess) {
+            if (!oc.ev_up) oc.ev_up = dvs_event_get(ctx);
+            if (oc.ev_up) ue = hipEventRecord(oc.ev_up, ctx->stream);
+        }
         if (!arc && ue == hipSuccess && !long_rows.empty()) {
             ue = hipMemcpyAsync(oc.d_rows, oc.h_long_rows.data(), long_rows.size() * 4, hipMemcpyHostToDevice, ctx->stream);
             if (ue == hipSuccess)
@@ -477,12 +505,12 @@ int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint3
                                     ctx->stream);
         }
         if (arc || ue != hipSuccess) {
-            dvs_dev_free(ctx, oc.d_off);
             dvs_dev_free(ctx, oc.d_rows);
             dvs_dev_free(ctx, oc.d_tiles);
-            oc = dvs_ctx::OffsetsCache();
+            oc.d_rows = oc.d_tiles = nullptr;
             return arc ? arc : dvs_hip_fail(ctx, ue, "histogram setup");
         }
+        oc.n_off = n_off;
         oc.nbytes = nbytes;
         oc.k = k;
         oc.n_long = long_rows.size();
