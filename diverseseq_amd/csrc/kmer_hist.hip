@@ -149,35 +149,80 @@ __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
     const uint64_t nchunks = t.end > t.begin ? (t.end - abase + 15) >> 4 : 0;
     const uint32_t bmask = uint32_t(B - 1);  // NS4: B = 4^k, power of two (k = 16 -> 2^32 - 1)
 
-    for (uint64_t c = tid; c < nchunks; c += nthreads) {
-        const uint64_t A = abase + (c << 4);
-        const uint4 cur = load16(seqs, A, nbytes);
-        const uint4 prev = (A >= 16) ? load16(seqs, A - 16, nbytes)
-                                     : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        // positions q = 0..31 <-> absolute A-16+q ; bases before the sequence start are invalid
-        const int64_t lead = int64_t(t.seq_begin) - (int64_t(A) - 16);
-        if (NS4) {
-            const uint64_t P = (uint64_t(pack16(prev)) << 32) | pack16(cur);
-            uint32_t I = (inv16(prev) << 16) | inv16(cur);  // bit 31-q
+    if (NS4) {
+        // Every wave takes a CONTIGUOUS run of 16-byte chunks, 64 at a time (lane l: chunk base + l), so
+        // the chunk in front of a lane's own -- the k - 1 halo -- is its neighbour lane's: its 2-bit pack
+        // and invalid mask arrive by one DPP shift (wave_shr:1) instead of a second load and a second
+        // pack; lane 0 takes lane 63's of the previous step (readlane), and only the first step of a
+        // wave loads a chunk it does not own.  When a wave's 1 KiB holds no byte >= 4 -- almost always --
+        // the invalid-mask arithmetic is skipped, and when all its 16 x 64 windows count, so are the
+        // per-window tests.
+        const uint32_t lane = tid & 63, wave = tid >> 6, nwaves = (nthreads + 63) >> 6;
+        const uint64_t per_wave = ((nchunks + nwaves - 1) / nwaves + 63) & ~63ull;
+        const uint64_t c_lo = uint64_t(wave) * per_wave;
+        const uint64_t c_hi = c_lo + per_wave < nchunks ? c_lo + per_wave : nchunks;
+        uint32_t carryP = 0, carryI = 0xFFFFu;
+        if (c_lo < c_hi) {  // the chunk in front of the wave's first one (uniform address)
+            const uint64_t A0 = abase + (c_lo << 4);
+            if (A0 >= 16) {
+                const uint4 pv = load16(seqs, A0 - 16, nbytes);
+                carryP = pack16(pv);
+                carryI = inv16(pv);
+            }
+        }
+        for (uint64_t c0 = c_lo; c0 < c_hi; c0 += 64) {
+            const uint64_t c = c0 + lane;
+            const bool live = c < c_hi;
+            const uint64_t A = abase + ((live ? c : c_hi - 1) << 4);
+            const uint4 cur = load16(seqs, A, nbytes);
+            const uint32_t Pc = pack16(cur);
+            uint32_t Ic = 0;
+            const uint32_t hib = (cur.x | cur.y | cur.z | cur.w) & 0xFCFCFCFCu;
+            if (__ballot(hib != 0)) Ic = inv16(cur);  // (wave-uniform branch)
+            // the neighbour's pack / mask: lane l <- lane l - 1, lane 0 <- the carry
+            const uint32_t Pp = uint32_t(__builtin_amdgcn_update_dpp(int(carryP), int(Pc), 0x138, 0xF, 0xF, false));
+            const uint32_t Ip = uint32_t(__builtin_amdgcn_update_dpp(int(carryI), int(Ic), 0x138, 0xF, 0xF, false));
+            carryP = uint32_t(__builtin_amdgcn_readlane(int(Pc), 63));
+            carryI = uint32_t(__builtin_amdgcn_readlane(int(Ic), 63));
+            const uint64_t P = (uint64_t(Pp) << 32) | Pc;
+            uint32_t I = (Ip << 16) | Ic;  // bit 31-q: position q = 0..31 <-> absolute A-16+q is invalid
+            // bases before the sequence start are invalid
+            const int64_t lead = int64_t(t.seq_begin) - (int64_t(A) - 16);
             if (lead > 0) I |= (lead >= 32) ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> lead);
             // bit 15-j of W: some base of the k-mer ending at A+j is invalid (OR of k bits of I)
-            uint32_t W = I, cover = 1;
-            while (2 * cover <= k) {
-                W |= W >> cover;
-                cover *= 2;
+            uint32_t W = I;
+            if (__ballot(I != 0)) {
+                uint32_t cover = 1;
+                while (2 * cover <= k) {
+                    W |= W >> cover;
+                    cover *= 2;
+                }
+                if (cover < k) W |= W >> (k - cover);
             }
-            if (cover < k) W |= W >> (k - cover);
             // bit 15-j of R: A+j lies in [t.begin, t.end)
             const uint32_t lo = t.begin > A ? uint32_t(t.begin - A < 16 ? t.begin - A : 16) : 0u;
             const uint32_t hi = t.end > A ? uint32_t(t.end - A < 16 ? t.end - A : 16) : 0u;
-            const uint32_t R = hi > lo ? ((0xFFFFu >> lo) & ~(0xFFFFu >> hi)) : 0u;
-            const uint32_t ok = R & ~W;
+            const uint32_t R = (live && hi > lo) ? ((0xFFFFu >> lo) & ~(0xFFFFu >> hi)) : 0u;
+            const uint32_t ok = R & ~W & 0xFFFFu;
+            if (__ballot(ok != 0xFFFFu) == 0) {  // every window of the wave's 1 KiB counts
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const uint32_t idx = uint32_t(P >> (2 * (15 - j))) & bmask;
-                if ((ok >> (15 - j)) & 1u) bump<LDS_HIST, PK16>(hist, idx);
+                for (int j = 0; j < 16; j++) bump<LDS_HIST, PK16>(hist, uint32_t(P >> (2 * (15 - j))) & bmask);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const uint32_t idx = uint32_t(P >> (2 * (15 - j))) & bmask;
+                    if ((ok >> (15 - j)) & 1u) bump<LDS_HIST, PK16>(hist, idx);
+                }
             }
-        } else {
+        }
+    } else {
+        for (uint64_t c = tid; c < nchunks; c += nthreads) {
+            const uint64_t A = abase + (c << 4);
+            const uint4 cur = load16(seqs, A, nbytes);
+            const uint4 prev = (A >= 16) ? load16(seqs, A - 16, nbytes)
+                                         : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            // positions q = 0..31 <-> absolute A-16+q ; bases before the sequence start are invalid
+            const int64_t lead = int64_t(t.seq_begin) - (int64_t(A) - 16);
             const uint32_t w[8] = {prev.x, prev.y, prev.z, prev.w, cur.x, cur.y, cur.z, cur.w};
             uint32_t idx = 0, run = 0;
             const uint32_t Bd = uint32_t(B / ns);  // ns^(k-1)
