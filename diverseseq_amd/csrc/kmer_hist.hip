@@ -205,8 +205,25 @@ __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
             const uint32_t R = (live && hi > lo) ? ((0xFFFFu >> lo) & ~(0xFFFFu >> hi)) : 0u;
             const uint32_t ok = R & ~W & 0xFFFFu;
             if (__ballot(ok != 0xFFFFu) == 0) {  // every window of the wave's 1 KiB counts
+                if constexpr (PK16) {
+                    // packed counters, four instructions a window: with P2 = P << 1, t = P2 >> s holds the
+                    // bin index times two -- masked to a multiple of four it is the byte address of the
+                    // bin's 32-bit word -- and bit 1 of t says which half of the word counts
+                    const uint64_t P2 = P << 1;
+                    const uint32_t p2lo = uint32_t(P2), p2hi = uint32_t(P2 >> 32);
+                    const uint32_t amask = (bmask << 1) & ~3u;
+                    unsigned char *hb = smem;  // (PK16 => the histogram is the start of the LDS block)
 #pragma unroll
-                for (int j = 0; j < 16; j++) bump<LDS_HIST, PK16>(hist, uint32_t(P >> (2 * (15 - j))) & bmask);
+                    for (int j = 0; j < 16; j++) {
+                        const uint32_t tq = __builtin_amdgcn_alignbit(p2hi, p2lo, 2 * (15 - j));
+                        uint32_t half = __builtin_amdgcn_ubfe(tq, 1, 1);
+                        asm volatile("" : "+v"(half));  // (keeps bfe + mad: two instructions, not and + cmp + select)
+                        atomicAdd(reinterpret_cast<uint32_t *>(hb + (tq & amask)), __umul24(half, 0xFFFFu) + 1u);  // (v_mad_u32_u24)
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) bump<LDS_HIST, PK16>(hist, uint32_t(P >> (2 * (15 - j))) & bmask);
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
