@@ -59,45 +59,3 @@ def ctree(seqs: dict, *, k: int = 12, sketch_size: int | None = 3000, distance_m
     else:
         dists = distance.euclidean_distances(arrays, k, num_states)
     return make_cluster_tree(names, dists)
-
-
-def clades(newick_or_tuple) -> set[frozenset]:
-    """the set of leaf sets below every internal node (for topology comparison)"""
-    def parse(text: str):
-        text = text.strip().rstrip(";")
-        pos = 0
-
-        def node():
-            nonlocal pos
-            while text[pos] == " ":
-                pos += 1
-            if text[pos] == "(":
-                pos += 1
-                kids = [node()]
-                while text[pos] == ",":
-                    pos += 1
-                    kids.append(node())
-                assert text[pos] == ")"
-                pos += 1
-                while pos < len(text) and text[pos] == " ":
-                    pos += 1
-                return tuple(kids)
-            start = pos
-            while pos < len(text) and text[pos] not in ",()":
-                pos += 1
-            return text[start:pos].strip()
-
-        return node()
-
-    tree = parse(newick_or_tuple) if isinstance(newick_or_tuple, str) else newick_or_tuple
-    out: set[frozenset] = set()
-
-    def walk(t):
-        if isinstance(t, str):
-            return frozenset([t])
-        leaves = frozenset().union(*[walk(c) for c in t])
-        out.add(leaves)
-        return leaves
-
-    walk(tree)
-    return out

@@ -102,7 +102,7 @@ def test_delta_jsd_app(brca1_text):
 def test_ctree_apps_topology(brca1_text, kw):
     """reference tests/test_ctree.py:9-74"""
     from diverseseq_amd import apps
-    from diverseseq_amd.cluster import clades
+    from conftest import clades
 
     names = ["Human", "Chimpanzee", "Rhesus", "Horse"]
     seqs = {n: brca1_text[n] for n in names}

@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 import oracle
+from conftest import clades
 from diverseseq_amd import cluster
 
 EXPECT = {
@@ -19,7 +20,7 @@ def test_make_cluster_tree_on_oracle_distances(brca1, sketch_size):
         sk = [oracle.mash_sketch(brca1[n], 16, sketch_size, 4, False) for n in names]
         d = oracle.mash_distances(sk, 16, sketch_size)
         got = cluster.make_cluster_tree(list(names), d)
-        assert cluster.clades(got) == cluster.clades(newick), (got, newick)
+        assert clades(got) == clades(newick), (got, newick)
 
 
 def test_ctree_argument_checks():
@@ -41,4 +42,4 @@ def test_ctree_argument_checks():
 def test_ctree_gpu(brca1, mode, kw):
     for names, newick in EXPECT.items():
         got = cluster.ctree({n: brca1[n] for n in names}, distance_mode=mode, **kw)
-        assert cluster.clades(got) == cluster.clades(newick), (got, newick)
+        assert clades(got) == clades(newick), (got, newick)
