@@ -185,7 +185,7 @@ def main():
     step(False)
     elapsed_cached = timed_loop(False)
 
-    if rank == 0 and not exact and not a.no_side_runs:
+    if rank == 0 and world == 1 and not exact and not a.no_side_runs:  # (single-GPU diagnostics; with more ranks rank 0 does not linger)
         # outside the timed region: the scan arithmetic alone, one launch over the whole stream
         m = ctx.build_matrix_device(seqs.data_ptr(), offsets, a.k, 4)
         sel = m.nmost(a.n, window=a.window)

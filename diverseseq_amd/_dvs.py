@@ -217,13 +217,26 @@ def get_seqids_from_store(path: str) -> list[str]:
 def _gather(store: ZarrStoreWrapper, seqids):
     """stream of sequences for `seqids` + integer identity labels (same id -> same label)"""
     ids = list(store.unique_seqids) if seqids is None else list(seqids)
-    seqs, labels, label_of = [], [], {}
-    for sid in ids:
-        if sid not in store:  # read_uint8_array(..).unwrap() panics (src/record.rs:206)
-            raise ValueError(f"sequence {sid!r} not in store")
-        seqs.append(store.read(sid))
-        labels.append(label_of.setdefault(sid, len(label_of)))
-    return ids, seqs, np.asarray(labels, dtype=np.uint32)
+    if store._disk is None:  # in-memory store: one dict look-up per id
+        mem = store._seqs
+        try:
+            seqs = [mem[sid] for sid in ids]
+        except KeyError as e:  # read_uint8_array(..).unwrap() panics (src/record.rs:206)
+            raise ValueError(f"sequence {e.args[0]!r} not in store") from None
+    else:
+        seqs = []
+        for sid in ids:
+            if sid not in store:
+                raise ValueError(f"sequence {sid!r} not in store")
+            seqs.append(store.read(sid))
+    label_of = dict.fromkeys(ids)  # first occurrence order
+    if len(label_of) == len(ids):
+        labels = np.arange(len(ids), dtype=np.uint32)
+    else:
+        for i, sid in enumerate(label_of):
+            label_of[sid] = i
+        labels = np.fromiter((label_of[sid] for sid in ids), dtype=np.uint32, count=len(ids))
+    return ids, seqs, labels
 
 
 def _result(sel: engine.Selection, ids, k: int, num_states: int) -> SummedRecordsResult:

@@ -15,6 +15,12 @@ from . import _lib
 
 def concat(seqs) -> tuple[np.ndarray, np.ndarray]:
     """list of byte-like / uint8 arrays -> (concatenated uint8, uint64 offsets[n+1])"""
+    if seqs and all(type(s) is bytes for s in seqs):  # the store's own representation: one C-level join
+        offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum(np.fromiter(map(len, seqs), dtype=np.int64, count=len(seqs)), dtype=np.uint64)
+        total = int(offsets[-1])
+        data = np.frombuffer(b"".join(seqs), dtype=np.uint8) if total else np.zeros(16, dtype=np.uint8)
+        return data, offsets
     arrs = []
     for s in seqs:
         if isinstance(s, (bytes, bytearray, memoryview)):

@@ -70,6 +70,16 @@ def test_dvs_module_runs_the_persistent_engine():
     exp = oracle.final_nmost(rows, 6)
     names = a.record_names + b.record_names
     assert merged.record_names == [names[i] for i in exp.members()[0]]
+    # ... and final_max (src/lib.rs:139-160) over two max results
+    ma = dvs.max_divergent(st, min_size=4, max_size=10, k=5, seqids=ids[:700])
+    mb = dvs.max_divergent(st, min_size=4, max_size=10, k=5, seqids=ids[700:])
+    mm = dvs.final_max([ma, mb], min_size=4, max_size=12, stat="stdev")
+    assert mm.stats["engine"] == 1
+    rows = np.array([r[1] for r in ma.records] + [r[1] for r in mb.records])
+    exp = oracle.final_max(rows, 4, 12, "stdev")
+    names = ma.record_names + mb.record_names
+    assert mm.record_names == [names[i] for i in exp.members()[0]]
+    assert abs(mm.total_jsd - exp.total_jsd) <= RTOL * exp.total_jsd
 
 
 def test_repeated_ids_keep_the_label_aware_engine():
