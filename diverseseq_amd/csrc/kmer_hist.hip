@@ -513,25 +513,37 @@ int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint3
         std::vector<KTile> tiles;
         std::vector<uint32_t> long_rows;
         uint64_t *dst = oc.h_off;
+        // first pass, branch-free (it vectorises): the pinned copy, whether any pair is out of order or
+        // out of range, and the longest sequence; rows are looked at one by one only when something is
+        // wrong or some sequence needs more than one tile
+        uint64_t bad = 0, longest = 0;
         dst[0] = offsets[0];
-        for (uint32_t r = 0; r < nseq; r++) {  // validation, tile lists and the pinned copy in one pass
+        for (uint32_t r = 0; r < nseq; r++) {
             const uint64_t s0 = offsets[r], s1 = offsets[r + 1];
             dst[r + 1] = s1;
-            if (s1 < s0 || s1 > nbytes)
-                return dvs_set_error(ctx, DVS_ERR_VALUE, "offsets[%u..%u] = %llu..%llu out of range", r,
-                                     r + 1, (unsigned long long)s0, (unsigned long long)s1);
-            if (s1 - s0 < k) continue;
-            const uint64_t first = s0 + k - 1;
-            if (s1 - first <= TILE_LEN) continue;
-            long_rows.push_back(r);
-            for (uint64_t b = first; b < s1; b += TILE_LEN) {
-                KTile t;
-                t.begin = b;
-                t.end = std::min<uint64_t>(b + TILE_LEN, s1);
-                t.seq_begin = s0;
-                t.row = r;
-                t.single = 0;
-                tiles.push_back(t);
+            bad |= uint64_t(s1 < s0) | uint64_t(s1 > nbytes);
+            const uint64_t len = s1 - s0;
+            longest = len > longest ? len : longest;
+        }
+        if (bad || longest >= uint64_t(TILE_LEN) + k) {
+            for (uint32_t r = 0; r < nseq; r++) {
+                const uint64_t s0 = offsets[r], s1 = offsets[r + 1];
+                if (s1 < s0 || s1 > nbytes)
+                    return dvs_set_error(ctx, DVS_ERR_VALUE, "offsets[%u..%u] = %llu..%llu out of range", r,
+                                         r + 1, (unsigned long long)s0, (unsigned long long)s1);
+                if (s1 - s0 < k) continue;
+                const uint64_t first = s0 + k - 1;
+                if (s1 - first <= TILE_LEN) continue;
+                long_rows.push_back(r);
+                for (uint64_t b = first; b < s1; b += TILE_LEN) {
+                    KTile t;
+                    t.begin = b;
+                    t.end = std::min<uint64_t>(b + TILE_LEN, s1);
+                    t.seq_begin = s0;
+                    t.row = r;
+                    t.single = 0;
+                    tiles.push_back(t);
+                }
             }
         }
         // (the previous lists go back to the block cache; stream order protects them until the
