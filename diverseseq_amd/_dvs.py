@@ -17,6 +17,8 @@ arithmetic runs in libdvs_hip.so (HIP kernels for gfx950) through ctypes.
 
 from __future__ import annotations
 
+import operator
+
 import numpy as np
 
 from . import _lib, engine
@@ -77,8 +79,15 @@ class ZarrStoreWrapper:
     """
 
     def __init__(self, path: str | None = None, mode: str = "r"):
-        self._seqs: dict[str, bytes] = {}
+        # in-memory store: every sequence appended to ONE byte arena (ids -> spans), so a selection
+        # over the store's ids in insertion order uploads the arena as it stands, with no gather
+        self._arena = bytearray()
+        self._index: dict[str, int] = {}   # seqid -> entry
+        self._starts: list[int] = []
+        self._lens: list[int] = []
+        self._keys: list[bytes] = []       # content digest per entry (the reference names content by its xxh3)
         self._meta: dict[str, dict] = {}
+        self._spans = None                 # (starts, lens) as arrays, rebuilt after writes
         self._disk = None
         self.source = ""
         if path is not None:
@@ -92,10 +101,10 @@ class ZarrStoreWrapper:
         return f"ZarrStoreWrapper(source={src}, num members={len(self)})"
 
     def __contains__(self, key: str) -> bool:
-        return key in (self._disk.seqid_to_hash if self._disk else self._seqs)
+        return key in (self._disk.seqid_to_hash if self._disk else self._index)
 
     def __len__(self) -> int:
-        return len(self._disk.seqid_to_hash if self._disk else self._seqs)
+        return len(self._disk.seqid_to_hash if self._disk else self._index)
 
     # pickling by path (src/zarr_py.rs:90-133); an in-memory store refuses
     def __getstate__(self):
@@ -133,10 +142,17 @@ class ZarrStoreWrapper:
             except (OSError, ValueError, RuntimeError) as e:
                 raise ValueError(f"Failed to create add {seqid}") from e
             return
-        if seqid in self._seqs:
+        if seqid in self._index:
             return  # idempotent per seqid (src/zarr_io.rs:217-219)
-        self._seqs[seqid] = data
+        import xxhash
+
+        self._index[seqid] = len(self._starts)
+        self._starts.append(len(self._arena))
+        self._lens.append(len(data))
+        self._keys.append(xxhash.xxh3_128_digest(data))
+        self._arena += data  # (BufferError while a selection holds a view of the arena: not re-entrant)
         self._meta[seqid] = meta
+        self._spans = None
 
     def write_log(self, unique_id: str, data: str) -> None:
         pass
@@ -146,7 +162,11 @@ class ZarrStoreWrapper:
 
     def read(self, seqid: str) -> bytes:
         try:
-            return self._disk.read(seqid) if self._disk else self._seqs[seqid]
+            if self._disk:
+                return self._disk.read(seqid)
+            i = self._index[seqid]
+            a = self._starts[i]
+            return bytes(self._arena[a:a + self._lens[i]])
         except (KeyError, OSError, RuntimeError, ValueError):
             raise RuntimeError(f"Failed to create add {seqid}") from None
 
@@ -157,8 +177,36 @@ class ZarrStoreWrapper:
             raise RuntimeError(f"Failed to read metadata for {seqid}: {e}") from None
 
     def _content_keys(self):
-        """(seqid, content key) in insertion order: the content hash on disk, the bytes in memory"""
-        return (self._disk.seqid_to_hash if self._disk else self._seqs).items()
+        """(seqid, content key) in insertion order: the content hash on disk, a digest in memory"""
+        if self._disk:
+            return self._disk.seqid_to_hash.items()
+        return zip(self._index, self._keys)
+
+    def _concat(self, ids):
+        """in-memory store: (uint8 data, uint64 offsets[n+1]) of the sequences of `ids`, in that order.
+        Ids that follow one another in the arena (the usual call: the store's own id list) come back
+        as a VIEW of the arena; anything else is gathered."""
+        if self._spans is None:
+            self._spans = (np.array(self._starts, dtype=np.int64), np.array(self._lens, dtype=np.int64))
+        index = self._index
+        if len(ids) == len(index) and all(map(operator.eq, ids, index)):  # the store's own id list
+            starts, lens = self._spans
+        else:
+            try:
+                idx = np.fromiter((index[sid] for sid in ids), dtype=np.int64, count=len(ids))
+            except KeyError as e:  # read_uint8_array(..).unwrap() panics (src/record.rs:206)
+                raise ValueError(f"sequence {e.args[0]!r} not in store") from None
+            starts, lens = self._spans[0][idx], self._spans[1][idx]
+        offsets = np.zeros(len(ids) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=offsets[1:], dtype=np.uint64)
+        if not len(ids):
+            return np.zeros(16, dtype=np.uint8), offsets
+        arena = np.frombuffer(self._arena, dtype=np.uint8)
+        if np.array_equal(starts[1:], starts[:-1] + lens[:-1]):
+            return arena[starts[0]:starts[0] + int(offsets[-1])], offsets
+        mv = memoryview(self._arena)
+        return np.frombuffer(b"".join([mv[a:a + n] for a, n in zip(starts.tolist(), lens.tolist())]),
+                             dtype=np.uint8), offsets
 
     def num_unique(self) -> int:
         return len({key for _, key in self._content_keys()})
@@ -214,29 +262,29 @@ def get_seqids_from_store(path: str) -> list[str]:
     return ZarrStoreWrapper(path, "r").get_seqids()
 
 
+def _labels(ids) -> np.ndarray:
+    """integer identity labels (same id -> same label, first-occurrence order)"""
+    label_of = dict.fromkeys(ids)
+    if len(label_of) == len(ids):
+        return np.arange(len(ids), dtype=np.uint32)
+    for i, sid in enumerate(label_of):
+        label_of[sid] = i
+    return np.fromiter((label_of[sid] for sid in ids), dtype=np.uint32, count=len(ids))
+
+
 def _gather(store: ZarrStoreWrapper, seqids):
-    """stream of sequences for `seqids` + integer identity labels (same id -> same label)"""
+    """the sequences of `seqids` as one stream (uint8 data, uint64 offsets[n+1]) + identity labels"""
     ids = list(store.unique_seqids) if seqids is None else list(seqids)
-    if store._disk is None:  # in-memory store: one dict look-up per id
-        mem = store._seqs
-        try:
-            seqs = [mem[sid] for sid in ids]
-        except KeyError as e:  # read_uint8_array(..).unwrap() panics (src/record.rs:206)
-            raise ValueError(f"sequence {e.args[0]!r} not in store") from None
+    if store._disk is None:
+        data, offsets = store._concat(ids)
     else:
         seqs = []
         for sid in ids:
             if sid not in store:
                 raise ValueError(f"sequence {sid!r} not in store")
             seqs.append(store.read(sid))
-    label_of = dict.fromkeys(ids)  # first occurrence order
-    if len(label_of) == len(ids):
-        labels = np.arange(len(ids), dtype=np.uint32)
-    else:
-        for i, sid in enumerate(label_of):
-            label_of[sid] = i
-        labels = np.fromiter((label_of[sid] for sid in ids), dtype=np.uint32, count=len(ids))
-    return ids, seqs, labels
+        data, offsets = engine.concat(seqs)
+    return ids, data, offsets, _labels(ids)
 
 
 def _result(sel: engine.Selection, ids, k: int, num_states: int) -> SummedRecordsResult:
@@ -264,12 +312,13 @@ def _check_k(k: int):
 def nmost_divergent(store: ZarrStoreWrapper, n: int, k: int, num_states: int = 4,
                     seqids=None) -> SummedRecordsResult:
     """src/lib.rs:59-73 -> select_nmost_divergent (src/records.rs:311-342)"""
-    ids, seqs, labels = _gather(store, seqids)
+    ids, data, offsets, labels = _gather(store, seqids)
     if len(ids) < n:
         raise ValueError(f"The number of sequences {len(ids)} is < n {n}")
     _check_k(k)
     ctx = engine.default_context()
-    m = ctx.build_matrix(seqs, k, num_states)
+    m = ctx.build_matrix_concat(data, offsets, k, num_states)
+    del data  # (a view of the store's arena: released before anything else can write to the store)
     try:
         sel = m.nmost(n, labels=labels)
         try:
@@ -283,12 +332,13 @@ def nmost_divergent(store: ZarrStoreWrapper, n: int, k: int, num_states: int = 4
 def max_divergent(store: ZarrStoreWrapper, min_size: int, max_size: int, k: int,
                   num_states: int = 4, seqids=None, stat: str = "stdev") -> SummedRecordsResult:
     """src/lib.rs:105-137 -> select_max_divergent (src/records.rs:390-454)"""
-    ids, seqs, labels = _gather(store, seqids)
+    ids, data, offsets, labels = _gather(store, seqids)
     if len(ids) < min_size:
         raise ValueError(f"The number of sequences {len(ids)} is < n {min_size}")
     _check_k(k)
     ctx = engine.default_context()
-    m = ctx.build_matrix(seqs, k, num_states)
+    m = ctx.build_matrix_concat(data, offsets, k, num_states)
+    del data
     try:
         sel = m.max_divergent(min_size, max_size, stat, labels=labels)
         try:

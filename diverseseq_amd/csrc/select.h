@@ -63,9 +63,10 @@ struct SelDev {
     uint32_t *wg_rows = nullptr;         // rows actually read by each scan workgroup (last launch)
     unsigned long long *evlog_pos = nullptr;  // accepted events in order: stream position ...
     uint32_t *evlog_kind = nullptr;           // ... and kind (1 replace_lowest, 2 kept push)
-    // stepwise / distributed use: the candidate of the pending event as delivered by the
-    // exchange step (B frequencies + entropy), instead of a row of the local matrix
-    const double *cand_ext = nullptr;
+    // stepwise / distributed use: every rank's gathered slot ([pos, H, row] x world) -- resolve picks
+    // the earliest event itself and takes the candidate from there instead of the local matrix
+    const double *gather_all = nullptr;
+    uint32_t gather_world = 0;
 };
 
 struct dvs_select {
@@ -88,6 +89,7 @@ struct dvs_select {
     size_t scan_lds = 0;
     bool base_in_lds = true;
     bool scan_hot = false;
+    bool one_launch_events = false;  // resolve, leave-one-out and finalize as one launch of cap workgroups (apply_kernel)
     bool fused = false;  // resolve + leave-one-out + finalize in one launch (small sets)
     // persistent single-launch engine (persist.hip)
     bool persist = false;

@@ -151,14 +151,12 @@ __device__ __forceinline__ void scan_rows_general(SelCtl *ctl, const T *__restri
 
 // HOT: identity order, unique ids, B a multiple of 256 * SCAN_CH (host-checked)
 template <typename T, bool HOT>
-__global__ __launch_bounds__(SCAN_THREADS, 4) void scan_kernel(
+__device__ __forceinline__ void scan_body(
     SelCtl *__restrict__ ctl, const T *__restrict__ mat, const uint32_t *__restrict__ totals,
     const double *__restrict__ rowH, const uint32_t *__restrict__ order,
     const uint32_t *__restrict__ labels, const uint8_t *__restrict__ inset, uint32_t nlabels,
-    const double *__restrict__ base, uint32_t *__restrict__ wg_rows, uint64_t B, int base_in_lds) {
-    // all LDS in the dynamic region (a static __shared__ in front of it would shift its
-    // base off 16 B and every ds_read_b128 of the state vector would be replayed)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const double *__restrict__ base, uint32_t *__restrict__ wg_rows, uint64_t B, int base_in_lds,
+    unsigned char *smem) {
     uint32_t *s_rows = reinterpret_cast<uint32_t *>(smem);  // 16 B header
     double *sb = reinterpret_cast<double *>(smem + 16);
     if (ctl->status != SEL_RUN) return;
@@ -204,6 +202,41 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void scan_kernel(
     if (threadIdx.x == 0 && s_rows[0]) {  // summed + cleared by resolve
         wg_rows[2 * blockIdx.x] = s_rows[0];
         wg_rows[2 * blockIdx.x + 1] = s_rows[1];
+    }
+}
+
+template <typename T, bool HOT>
+__global__ __launch_bounds__(SCAN_THREADS, 4) void scan_kernel(
+    SelCtl *__restrict__ ctl, const T *__restrict__ mat, const uint32_t *__restrict__ totals,
+    const double *__restrict__ rowH, const uint32_t *__restrict__ order,
+    const uint32_t *__restrict__ labels, const uint8_t *__restrict__ inset, uint32_t nlabels,
+    const double *__restrict__ base, uint32_t *__restrict__ wg_rows, uint64_t B, int base_in_lds) {
+    // all LDS in the dynamic region (a static __shared__ in front of it would shift its
+    // base off 16 B and every ds_read_b128 of the state vector would be replayed)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    scan_body<T, HOT>(ctl, mat, totals, rowH, order, labels, inset, nlabels, base, wg_rows, B, base_in_lds,
+                      smem);
+}
+
+// slot of the stepwise exchange: [0] event position as a double (< 0: none), [1] H(row), [2 ..] the
+// candidate's frequency row
+template <typename T>
+__device__ void pack_event_body(const SelDev &d, const T *__restrict__ mat, double *__restrict__ slot) {
+    const SelCtl *ctl = d.ctl;
+    const unsigned long long p =
+        __hip_atomic_load(&ctl->event_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t row = DVS_ROW_REMOTE;
+    if (ctl->status == SEL_RUN && p != SEL_NONE) row = d.order ? d.order[p] : uint32_t(p);
+    if (row == DVS_ROW_REMOTE) {
+        if (threadIdx.x == 0) slot[0] = -1.0;  // (the rest of the slot is not read)
+        return;
+    }
+    const double tot = double(d.totals[row]);
+    const T *rp = mat + uint64_t(row) * d.B;
+    for (uint64_t i = threadIdx.x; i < d.B; i += blockDim.x) slot[2 + i] = cand_freq(rp, i, tot);
+    if (threadIdx.x == 0) {
+        slot[0] = double(p);  // (exact below 2^53)
+        slot[1] = d.rowH[row];
     }
 }
 
@@ -261,7 +294,33 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, uint32_t scan
     if (ctl->status != SEL_RUN) return;
     const int tid = threadIdx.x;
     const uint32_t WIDE = blockDim.x;
-    const uint64_t p = ctl->event_pos;
+    const double *ext_row = nullptr, *ext_H = nullptr;
+    unsigned long long gathered_p = SEL_NONE;
+    if (d.gather_all) {
+        // stepwise mode: the earliest event among the gathered slots ([pos, H, row]) is this step's
+        // event on every rank
+        __shared__ int s_best;
+        if (tid == 0) {
+            int best = -1;
+            double bp = 0.0;
+            const uint64_t stride = d.B + 2;
+            for (uint32_t r = 0; r < d.gather_world; r++) {
+                const double q = d.gather_all[uint64_t(r) * stride];
+                if (q >= 0.0 && (best < 0 || q < bp)) {
+                    best = int(r);
+                    bp = q;
+                }
+            }
+            s_best = best;
+            ctl->event_pos = best < 0 ? SEL_NONE : (unsigned long long)bp;
+        }
+        __syncthreads();
+        const double *src = d.gather_all + uint64_t(s_best < 0 ? 0 : s_best) * (d.B + 2);
+        ext_row = src + 2;
+        ext_H = src + 1;
+        gathered_p = s_best < 0 ? SEL_NONE : (unsigned long long)src[0];
+    }
+    const uint64_t p = d.gather_all ? gathered_p : ctl->event_pos;
     if (ctl->ev_kind != 0) return;  // a finalize is pending (arbiter re-entry)
     {   // rows the scan launch actually read (an arbiter re-entry finds zeros)
         double cnt = 0.0, cnt2 = 0.0, mnz = 0.0;
@@ -290,10 +349,10 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, uint32_t scan
     const uint32_t row = d.order ? d.order[p] : uint32_t(p);
     uint32_t lab;
     double cand_H;
-    if (d.cand_ext) {  // exchanged candidate (its row may live on another rank)
+    if (ext_row) {  // exchanged candidate (its row may live on another rank)
         lab = (row == DVS_ROW_REMOTE) ? DVS_ROW_REMOTE : (d.labels ? d.labels[p] : row);
-        cand_H = d.cand_ext[d.B];
-        for (uint64_t i = tid; i < d.B; i += WIDE) d.cand[i] = d.cand_ext[i];
+        cand_H = *ext_H;
+        for (uint64_t i = tid; i < d.B; i += WIDE) d.cand[i] = ext_row[i];
     } else {
         lab = d.labels ? d.labels[p] : row;
         const double tot = double(d.totals[row]);
@@ -725,6 +784,41 @@ __global__ __launch_bounds__(WIDE_THREADS) void resolve_kernel(SelDev d, const T
     finalize_body(d, scratch, s_flag);
 }
 
+// One event in ONE launch: workgroup 0 resolves the candidate, every workgroup then takes one
+// leave-one-out job, the last one to finish finalizes.  The two hand-overs are agent-scope
+// flags in sync[0..1] (zero between launches); the grid is the set's capacity (<= APPLY_MAX_GRID
+// workgroups, far below what the chip keeps resident, and workgroup 0 is dispatched first).
+constexpr uint32_t APPLY_MAX_GRID = 128;
+template <typename T>
+__global__ __launch_bounds__(WIDE_THREADS) void apply_kernel(SelDev d, const T *__restrict__ mat,
+                                                          uint32_t scan_grid, uint32_t *__restrict__ sync) {
+    __shared__ double scratch[48];
+    __shared__ int s_flag;
+    if (blockIdx.x == 0) {
+        resolve_body<T>(d, mat, scan_grid, scratch, s_flag);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&sync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (threadIdx.x == 0) {
+        while (__hip_atomic_load(&sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (every thread reads what workgroup 0 wrote)
+    loo_body(d, blockIdx.x, scratch);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_flag = (t == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!s_flag) return;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (threadIdx.x == 0) sync[0] = sync[1] = 0;  // (the next launch starts from zeros)
+    __syncthreads();
+    finalize_body(d, scratch, s_flag);
+}
+
 __global__ __launch_bounds__(LOO_THREADS) void loo_kernel(SelDev d) {
     __shared__ double scratch[48];
     loo_body(d, blockIdx.x, scratch);
@@ -798,52 +892,11 @@ __global__ __launch_bounds__(LOO_THREADS) void gather_members_kernel(SelDev d, d
 // event of the window -- position, row entropy and the candidate's 4^k frequency row -- into its slot
 // of an all_gather; afterwards every rank holds all the slots, takes the smallest position (a stream
 // position is scored by exactly one rank) and resolves that candidate against its replica of the set.
-// slot: [0] event position as a double (< 0: none), [1] H(row), [2 ..] the frequency row.
+// (pick: the head of resolve_body)
 template <typename T>
 __global__ __launch_bounds__(LOO_THREADS) void pack_event_kernel(SelDev d, const T *__restrict__ mat,
                                                                 double *__restrict__ slot) {
-    const SelCtl *ctl = d.ctl;
-    const unsigned long long p = ctl->event_pos;
-    uint32_t row = DVS_ROW_REMOTE;
-    if (ctl->status == SEL_RUN && p != SEL_NONE) row = d.order ? d.order[p] : uint32_t(p);
-    if (row == DVS_ROW_REMOTE) {
-        if (threadIdx.x == 0) slot[0] = -1.0;  // (the rest of the slot is not read)
-        return;
-    }
-    const double tot = double(d.totals[row]);
-    const T *rp = mat + uint64_t(row) * d.B;
-    for (uint64_t i = threadIdx.x; i < d.B; i += LOO_THREADS) slot[2 + i] = cand_freq(rp, i, tot);
-    if (threadIdx.x == 0) {
-        slot[0] = double(p);  // (exact below 2^53)
-        slot[1] = d.rowH[row];
-    }
-}
-// the earliest event among the gathered slots -> the control block and the candidate buffer
-// (B frequencies, then the entropy: what resolve_body reads through cand_ext)
-__global__ __launch_bounds__(LOO_THREADS) void pick_event_kernel(SelDev d, const double *__restrict__ all,
-                                                                uint32_t world, uint64_t stride,
-                                                                double *__restrict__ pick) {
-    __shared__ int s_best;
-    SelCtl *ctl = d.ctl;
-    if (threadIdx.x == 0) {
-        int best = -1;
-        double bp = 0.0;
-        for (uint32_t r = 0; r < world; r++) {
-            const double q = all[uint64_t(r) * stride];
-            if (q >= 0.0 && (best < 0 || q < bp)) {
-                best = int(r);
-                bp = q;
-            }
-        }
-        s_best = best;
-        if (ctl->status == SEL_RUN) ctl->event_pos = best < 0 ? SEL_NONE : (unsigned long long)bp;
-    }
-    __syncthreads();
-    const int best = s_best;
-    if (best < 0) return;
-    const double *src = all + uint64_t(best) * stride;
-    for (uint64_t i = threadIdx.x; i < d.B; i += LOO_THREADS) pick[i] = src[2 + i];
-    if (threadIdx.x == 0) pick[d.B] = src[1];
+    pack_event_body<T>(d, mat, slot);
 }
 
 }  // namespace
@@ -896,6 +949,11 @@ static void launch_iteration(dvs_ctx *ctx_, dvs_select *s, const T *mat, int sta
                                s->scan_lds, ctx->stream, d.ctl, mat, d.totals, d.rowH, d.order, d.labels,
                                d.inset, d.nlabels, d.base, d.wg_rows, d.B, s->base_in_lds ? 1 : 0);
         if (s->time_scan) (void)hipEventRecord(e1, ctx->stream);
+    }
+    if (stage <= 1 && s->one_launch_events) {
+        hipLaunchKernelGGL((apply_kernel<T>), dim3(s->loo_grid), dim3(WIDE_THREADS), 0, ctx->stream, d, mat,
+                           s->scan_grid, d.wg_rows + 2 * size_t(s->scan_grid));
+        return;
     }
     if (stage <= 1) {
         if (s->fused)
@@ -1188,6 +1246,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     if (const char *e = getenv("DVS_SCAN_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
     s->scan_grid = std::max<uint32_t>(1, uint32_t(ctx->n_cu) * wg_per_cu);
     s->loo_grid = cap;
+    s->one_launch_events = cap <= APPLY_MAX_GRID && !getenv("DVS_EVENT_THREE_LAUNCH");
     // measured slower than three launches (one CU does the whole leave-one-out pass): opt-in only
     s->fused = cap <= FUSE_MAX + 1 && getenv("DVS_FUSE_EVENT");
     s->batch = 16;
@@ -1228,7 +1287,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     SEL_ALLOC(d.mPos, size_t(cap) * 8);
     SEL_ALLOC(d.ord, size_t(cap) * 4);
     SEL_ALLOC(d.inset, std::max<size_t>(nlabels, 1));
-    SEL_ALLOC(d.wg_rows, size_t(s->scan_grid) * 8);
+    SEL_ALLOC(d.wg_rows, size_t(s->scan_grid) * 8 + 8);  // (+ apply_kernel's two sync words)
     SEL_ALLOC(d.evlog_pos, size_t(npos - n_seed + 2) * 8);
     SEL_ALLOC(d.evlog_kind, size_t(npos - n_seed + 2) * 4);
     if (order) {
@@ -1242,7 +1301,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
                                     hipMemcpyHostToDevice, ctx->stream));
     }
 #undef SEL_ALLOC
-    SEL_HIP(hipMemsetAsync(d.wg_rows, 0, size_t(s->scan_grid) * 8, ctx->stream));
+    SEL_HIP(hipMemsetAsync(d.wg_rows, 0, size_t(s->scan_grid) * 8 + 8, ctx->stream));
     static_assert(sizeof(SelCtl) <= 4096, "control block must fit a cached pinned block");
     {
         int prc = dvs_pinned_get(ctx, (void **)&s->h_ctl);
@@ -1552,41 +1611,29 @@ extern "C" int dvs_selftest_fast_log2(dvs_ctx *ctx, double *max_abs_err) {
 
 // ---- stepwise driving (one process per GPU; the exchange between the steps is the host
 // framework's: ONE all_gather of every rank's slot per greedy step)
-template <typename T>
-static int step_scan(dvs_ctx *ctx, dvs_select *s, const T *mat) {
-    const SelDev &d = s->dev;
-    hipLaunchKernelGGL((scan_kernel<T, false>), dim3(s->scan_grid), dim3(SCAN_THREADS), s->scan_lds,
-                       ctx->stream, d.ctl, mat, d.totals, d.rowH, d.order, d.labels, d.inset, d.nlabels,
-                       d.base, d.wg_rows, d.B, s->base_in_lds ? 1 : 0);
-    DVS_HIP(ctx, hipGetLastError());
-    return DVS_OK;
-}
-
 extern "C" int dvs_select_step_pack(dvs_ctx *ctx, dvs_select *s, double *d_slot) {
     if (!ctx || !s || !d_slot) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
-    int rc = dvs_mat_dispatch(s->mat, [&](auto *mp) { return step_scan(ctx, s, mp); });
-    if (rc) return rc;
     dvs_mat_dispatch(s->mat, [&](auto *mp) {
         using T = std::remove_cv_t<std::remove_pointer_t<decltype(mp)>>;
-        hipLaunchKernelGGL((pack_event_kernel<T>), dim3(1), dim3(LOO_THREADS), 0, ctx->stream, s->dev, mp, d_slot);
+        // (scan and pack as ONE launch -- the last workgroup to arrive at a counter packs -- measured
+        // slower: 8.79 vs 7.57 ms per selection; every workgroup's arrival is a same-address atomic)
+        const SelDev &d = s->dev;
+        hipLaunchKernelGGL((scan_kernel<T, false>), dim3(s->scan_grid), dim3(SCAN_THREADS), s->scan_lds,
+                           ctx->stream, d.ctl, mp, d.totals, d.rowH, d.order, d.labels, d.inset, d.nlabels,
+                           d.base, d.wg_rows, d.B, s->base_in_lds ? 1 : 0);
+        hipLaunchKernelGGL((pack_event_kernel<T>), dim3(1), dim3(LOO_THREADS), 0, ctx->stream, s->dev, mp,
+                           d_slot);
         return 0;
     });
     DVS_HIP(ctx, hipGetLastError());
     return DVS_OK;
 }
 
-extern "C" int dvs_select_step_pick(dvs_ctx *ctx, dvs_select *s, const double *d_all, uint32_t world,
-                                    double *d_row) {
-    if (!ctx || !s || !d_all || !d_row || !world) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
-    hipLaunchKernelGGL(pick_event_kernel, dim3(1), dim3(LOO_THREADS), 0, ctx->stream, s->dev, d_all, world,
-                       s->dev.B + 2, d_row);
-    DVS_HIP(ctx, hipGetLastError());
-    return DVS_OK;
-}
-
-extern "C" int dvs_select_step_apply(dvs_ctx *ctx, dvs_select *s, const double *d_row) {
-    if (!ctx || !s || !d_row) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
-    s->dev.cand_ext = d_row;
+extern "C" int dvs_select_step_apply(dvs_ctx *ctx, dvs_select *s, const double *d_all, uint32_t world) {
+    if (!ctx || !s || !d_all || !world) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    s->dev.gather_all = d_all;
+    s->dev.gather_world = world;
+    s->fused = s->cap <= FUSE_MAX + 1 && getenv("DVS_FUSE_EVENT");  // (one workgroup doing all the leave-one-out jobs: measured 10.6 vs 8.9 ms per selection)
     dvs_mat_dispatch(s->mat, [&](auto *mp) {
         launch_iteration(ctx, s, mp, 1);
         return 0;

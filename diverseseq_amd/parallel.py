@@ -190,7 +190,6 @@ class HipStepper:
 
         self.ctx, self.sel, self.nbins = ctx, sel, nbins
         self.slot = torch.zeros(nbins + 2, dtype=torch.float64, device=device)
-        self.row = torch.zeros(nbins + 2, dtype=torch.float64, device=device)
 
     def pack(self):
         import ctypes as C
@@ -201,10 +200,8 @@ class HipStepper:
     def apply(self, all_slots, world: int):
         import ctypes as C
 
-        L = self.ctx._L
-        self.ctx.check(L.dvs_select_step_pick(self.ctx._h, self.sel._h, C.c_void_p(all_slots.data_ptr()), world,
-                                              C.c_void_p(self.row.data_ptr())))
-        self.ctx.check(L.dvs_select_step_apply(self.ctx._h, self.sel._h, C.c_void_p(self.row.data_ptr())))
+        self.ctx.check(self.ctx._L.dvs_select_step_apply(self.ctx._h, self.sel._h, C.c_void_p(all_slots.data_ptr()),
+                                                         world))
 
     def done(self) -> bool:
         import ctypes as C

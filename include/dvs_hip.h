@@ -215,14 +215,13 @@ int dvs_select_delta_jsd(dvs_ctx *ctx, const dvs_select *s, const dvs_matrix *qu
  *                          event into d_slot[nbins + 2]: position (as a double; < 0: none), the
  *                          row's entropy, the candidate's frequency row
  *   [host framework: all_gather of the slots -- RCCL; world x (nbins + 2) doubles, 8 x 32 KB at k=6]
- *   dvs_select_step_pick   the earliest event among the gathered slots becomes the window's event
- *                          and its row goes to d_row[nbins + 1] (a position is scored by one rank only)
- *   dvs_select_step_apply  resolve + leave-one-out + finalize with that candidate (identical
- *                          arithmetic on every rank: the replicas stay bit-identical)
+ *   dvs_select_step_apply  the earliest event among the gathered slots d_all[world][nbins + 2] is the
+ *                          step's event (a position is scored by one rank only): resolve +
+ *                          leave-one-out + finalize with that candidate, identical arithmetic on
+ *                          every rank so the replicas stay bit-identical
  * dvs_select_step_poll syncs and returns the status (0 running, 1 done) / cursor. */
 int dvs_select_step_pack(dvs_ctx *ctx, dvs_select *s, double *d_slot);
-int dvs_select_step_pick(dvs_ctx *ctx, dvs_select *s, const double *d_all, uint32_t world, double *d_row);
-int dvs_select_step_apply(dvs_ctx *ctx, dvs_select *s, const double *d_row);
+int dvs_select_step_apply(dvs_ctx *ctx, dvs_select *s, const double *d_all, uint32_t world);
 int dvs_select_step_poll(dvs_ctx *ctx, dvs_select *s, uint32_t *status, uint64_t *cursor);
 
 /* when on, every scan launch is bracketed by a pair of HIP events recorded on the

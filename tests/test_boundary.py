@@ -91,6 +91,41 @@ def test_store_semantics():
         _dvs.make_zarr_store("/tmp/no-such-store.dvseqsz", mode="r")
 
 
+def test_in_memory_store_hands_over_one_stream():
+    """the stream a selection uploads: a view of the store's arena for the store's own id order,
+    gathered bytes for any other order; repeated ids share a label; an unknown id is the reference's
+    panic (src/record.rs:206) as ValueError"""
+    rng = np.random.default_rng(11)
+    seqs = [rng.integers(0, 5, int(rng.integers(20, 60)), dtype=np.uint8).tobytes() for _ in range(200)]
+    seqs[10] = seqs[3]
+    st = _dvs.make_zarr_store()
+    for i, s in enumerate(seqs):
+        st.write(f"s{i}", s)
+    st.write("s5", b"\x01")  # a known id is not rewritten (src/zarr_io.rs:217-219)
+    assert st.read("s5") == seqs[5]
+    all_ids = [f"s{i}" for i in range(200)]
+    ids, data, offs, labels = _dvs._gather(st, all_ids)
+    assert data.tobytes() == b"".join(seqs) and labels.tolist() == list(range(200))
+    assert np.shares_memory(data, np.frombuffer(st._arena, dtype=np.uint8))
+    del data
+    perm = rng.permutation(200).tolist()
+    ids, data, offs, labels = _dvs._gather(st, [f"s{i}" for i in perm])
+    for j, i in enumerate(perm):
+        assert data[int(offs[j]):int(offs[j + 1])].tobytes() == seqs[i]
+    del data
+    ids, data, offs, labels = _dvs._gather(st, None)  # unique content, the last id written named
+    assert ids[3] == "s10" and "s3" not in ids and len(ids) == 199
+    assert data.tobytes() == b"".join(s for i, s in enumerate(seqs) if i != 10)
+    del data
+    ids, data, offs, labels = _dvs._gather(st, ["s1", "s7", "s1"])
+    assert labels.tolist() == [0, 1, 0] and data.tobytes() == seqs[1] + seqs[7] + seqs[1]
+    del data
+    with pytest.raises(ValueError, match="not in store"):
+        _dvs._gather(st, ["s1", "nope"])
+    st.write("late", b"\x00\x01")  # no view outstanding: the arena grows again
+    assert st.read("late") == b"\x00\x01" and len(st) == 201
+
+
 def test_result_pickles():
     """reference tests/test_records.py:88-97; src/records_py.rs:49-87"""
     r = _dvs.SummedRecordsResult()
