@@ -89,7 +89,6 @@ struct dvs_select {
     size_t scan_lds = 0;
     bool base_in_lds = true;
     bool scan_hot = false;
-    bool one_launch_events = false;  // resolve, leave-one-out and finalize as one launch of cap workgroups (apply_kernel)
     bool fused = false;  // resolve + leave-one-out + finalize in one launch (small sets)
     // persistent single-launch engine (persist.hip)
     bool persist = false;

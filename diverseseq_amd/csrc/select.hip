@@ -287,6 +287,7 @@ __device__ double block_entropy_div(const double *vec, double div, uint64_t B, d
     return (mn < 0.0) ? NAN : h;
 }
 
+
 template <typename T>
 __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, uint32_t scan_grid,
                              double *scratch, int &s_action) {
@@ -413,8 +414,6 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, uint32_t scan
             const uint32_t old_lab = d.mLabel[s];
             if (old_lab < d.nlabels) d.inset[old_lab] = 0;
             if (lab < d.nlabels) d.inset[lab] = 1;
-            for (uint32_t i = li; i + 1 < n; i++) d.ord[i] = d.ord[i + 1];  // Vec::remove
-            d.ord[n - 1] = s;                                              // push
             d.mH[s] = cand_H;
             d.mLabel[s] = lab;
             d.mPos[s] = p;
@@ -423,6 +422,15 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, uint32_t scan
             d.evlog_kind[ctl->n_logged] = 1;
             ctl->n_logged++;
         }
+        // Vec::remove(li) + push: the member order moves up by one from li, a block-wide chunk at a
+        // time (read, barrier, write; thread 0 doing it alone was a chain of n dependent round trips)
+        for (uint32_t b0 = li; b0 + 1 < n; b0 += WIDE) {
+            const uint32_t i = b0 + tid;
+            const uint32_t o = (i + 1 < n) ? d.ord[i + 1] : 0u;
+            __syncthreads();
+            if (i + 1 < n) d.ord[i] = o;
+        }
+        if (tid == 0) d.ord[n - 1] = s;  // (slot n-1 is read by no chunk after the one that wrote n-2)
         __syncthreads();
         double sm2;
         const double hm = block_entropy_div(d.S, double(n), d.B, scratch, &sm2);
@@ -784,41 +792,6 @@ __global__ __launch_bounds__(WIDE_THREADS) void resolve_kernel(SelDev d, const T
     finalize_body(d, scratch, s_flag);
 }
 
-// One event in ONE launch: workgroup 0 resolves the candidate, every workgroup then takes one
-// leave-one-out job, the last one to finish finalizes.  The two hand-overs are agent-scope
-// flags in sync[0..1] (zero between launches); the grid is the set's capacity (<= APPLY_MAX_GRID
-// workgroups, far below what the chip keeps resident, and workgroup 0 is dispatched first).
-constexpr uint32_t APPLY_MAX_GRID = 128;
-template <typename T>
-__global__ __launch_bounds__(WIDE_THREADS) void apply_kernel(SelDev d, const T *__restrict__ mat,
-                                                          uint32_t scan_grid, uint32_t *__restrict__ sync) {
-    __shared__ double scratch[48];
-    __shared__ int s_flag;
-    if (blockIdx.x == 0) {
-        resolve_body<T>(d, mat, scan_grid, scratch, s_flag);
-        __syncthreads();
-        if (threadIdx.x == 0)
-            __hip_atomic_store(&sync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (threadIdx.x == 0) {
-        while (__hip_atomic_load(&sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0)
-            __builtin_amdgcn_s_sleep(1);
-    }
-    __syncthreads();
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (every thread reads what workgroup 0 wrote)
-    loo_body(d, blockIdx.x, scratch);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t t = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        s_flag = (t == gridDim.x - 1);
-    }
-    __syncthreads();
-    if (!s_flag) return;
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    if (threadIdx.x == 0) sync[0] = sync[1] = 0;  // (the next launch starts from zeros)
-    __syncthreads();
-    finalize_body(d, scratch, s_flag);
-}
-
 __global__ __launch_bounds__(LOO_THREADS) void loo_kernel(SelDev d) {
     __shared__ double scratch[48];
     loo_body(d, blockIdx.x, scratch);
@@ -949,11 +922,6 @@ static void launch_iteration(dvs_ctx *ctx_, dvs_select *s, const T *mat, int sta
                                s->scan_lds, ctx->stream, d.ctl, mat, d.totals, d.rowH, d.order, d.labels,
                                d.inset, d.nlabels, d.base, d.wg_rows, d.B, s->base_in_lds ? 1 : 0);
         if (s->time_scan) (void)hipEventRecord(e1, ctx->stream);
-    }
-    if (stage <= 1 && s->one_launch_events) {
-        hipLaunchKernelGGL((apply_kernel<T>), dim3(s->loo_grid), dim3(WIDE_THREADS), 0, ctx->stream, d, mat,
-                           s->scan_grid, d.wg_rows + 2 * size_t(s->scan_grid));
-        return;
     }
     if (stage <= 1) {
         if (s->fused)
@@ -1246,7 +1214,6 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     if (const char *e = getenv("DVS_SCAN_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
     s->scan_grid = std::max<uint32_t>(1, uint32_t(ctx->n_cu) * wg_per_cu);
     s->loo_grid = cap;
-    s->one_launch_events = cap <= APPLY_MAX_GRID && !getenv("DVS_EVENT_THREE_LAUNCH");
     // measured slower than three launches (one CU does the whole leave-one-out pass): opt-in only
     s->fused = cap <= FUSE_MAX + 1 && getenv("DVS_FUSE_EVENT");
     s->batch = 16;
@@ -1287,7 +1254,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     SEL_ALLOC(d.mPos, size_t(cap) * 8);
     SEL_ALLOC(d.ord, size_t(cap) * 4);
     SEL_ALLOC(d.inset, std::max<size_t>(nlabels, 1));
-    SEL_ALLOC(d.wg_rows, size_t(s->scan_grid) * 8 + 8);  // (+ apply_kernel's two sync words)
+    SEL_ALLOC(d.wg_rows, size_t(s->scan_grid) * 8);
     SEL_ALLOC(d.evlog_pos, size_t(npos - n_seed + 2) * 8);
     SEL_ALLOC(d.evlog_kind, size_t(npos - n_seed + 2) * 4);
     if (order) {
@@ -1301,7 +1268,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
                                     hipMemcpyHostToDevice, ctx->stream));
     }
 #undef SEL_ALLOC
-    SEL_HIP(hipMemsetAsync(d.wg_rows, 0, size_t(s->scan_grid) * 8 + 8, ctx->stream));
+    SEL_HIP(hipMemsetAsync(d.wg_rows, 0, size_t(s->scan_grid) * 8, ctx->stream));
     static_assert(sizeof(SelCtl) <= 4096, "control block must fit a cached pinned block");
     {
         int prc = dvs_pinned_get(ctx, (void **)&s->h_ctl);
