@@ -89,7 +89,6 @@ struct dvs_select {
     size_t scan_lds = 0;
     bool base_in_lds = true;
     bool scan_hot = false;
-    bool fused = false;  // resolve + leave-one-out + finalize in one launch (small sets)
     // persistent single-launch engine (persist.hip)
     bool persist = false;
     bool persist_coop = false;       // launched with hipLaunchCooperativeKernel

@@ -261,16 +261,25 @@ __global__ void fast_log2_selftest_kernel(double *out) {
 // ------------------------------------------------------------- state kernels
 // JSD of the set with `lowest` swapped for the candidate in d.cand
 // (src/records.rs:70-84), all threads of the block get the result.
+// *h_out: the entropy of that mean vector; *clamped: some bin of S - lowest is one drop_lowest
+// would clamp to zero (records.rs:100-105) -- when none is, the vector is bit for bit the one
+// replace_lowest leaves in S / size, so an accept need not evaluate its entropy again.
 __device__ double block_delta_jsd(const SelDev &d, const SelCtl *ctl, double cand_H,
-                                  double *scratch, double *sum_out) {
+                                  double *scratch, double *sum_out, double *h_out, int *clamped) {
     const uint32_t low_slot = d.ord[ctl->lowest];
     const double *low = d.M + uint64_t(low_slot) * d.B;
     const double dsize = double(ctl->size);
     Ent e;
-    for (uint64_t i = threadIdx.x; i < d.B; i += blockDim.x)
-        e.add((d.S[i] - low[i] + d.cand[i]) / dsize);
+    int cl = 0;
+    for (uint64_t i = threadIdx.x; i < d.B; i += blockDim.x) {
+        const double v = d.S[i] - low[i];
+        cl |= (v <= DVS_EPS && v != 0.0) ? 1 : 0;
+        e.add((v + d.cand[i]) / dsize);
+    }
     double h = e.h, mn = e.mn, sm = e.sum;
     block_red3(h, mn, sm, scratch);
+    *clamped = __syncthreads_or(cl);
+    *h_out = (mn < 0.0) ? NAN : h;
     if (sum_out) *sum_out = sm;
     const double mean_entropy = (ctl->sum_entropy - d.mH[low_slot] + cand_H) / dsize;
     return (mn < 0.0) ? NAN : h - mean_entropy;
@@ -289,8 +298,7 @@ __device__ double block_entropy_div(const double *vec, double div, uint64_t B, d
 
 
 template <typename T>
-__device__ void resolve_body(SelDev &d, const T *__restrict__ mat, uint32_t scan_grid,
-                             double *scratch, int &s_action) {
+__device__ void resolve_body(SelDev &d, const T *__restrict__ mat, double *scratch, int &s_action) {
     SelCtl *ctl = d.ctl;
     if (ctl->status != SEL_RUN) return;
     const int tid = threadIdx.x;
@@ -323,20 +331,6 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, uint32_t scan
     }
     const uint64_t p = d.gather_all ? gathered_p : ctl->event_pos;
     if (ctl->ev_kind != 0) return;  // a finalize is pending (arbiter re-entry)
-    {   // rows the scan launch actually read (an arbiter re-entry finds zeros)
-        double cnt = 0.0, cnt2 = 0.0, mnz = 0.0;
-        for (uint32_t i = tid; i < scan_grid; i += WIDE) {
-            cnt += double(d.wg_rows[2 * i]);
-            cnt2 += double(d.wg_rows[2 * i + 1]);
-            d.wg_rows[2 * i] = 0;
-            d.wg_rows[2 * i + 1] = 0;
-        }
-        block_red3(cnt, mnz, cnt2, scratch);
-        if (tid == 0) {
-            ctl->rows_scored += (unsigned long long)cnt;
-            ctl->rows_rechecked += (unsigned long long)cnt2;
-        }
-    }
     if (p == SEL_NONE) {
         if (tid == 0) {
             const uint64_t end = umin64(ctl->cursor + uint64_t(ctl->window), ctl->npos);
@@ -363,7 +357,9 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, uint32_t scan
     }
     __syncthreads();
     double sm;
-    const double jsd = block_delta_jsd(d, ctl, cand_H, scratch, &sm);
+    double h_swapped;
+    int any_clamped;
+    const double jsd = block_delta_jsd(d, ctl, cand_H, scratch, &sm, &h_swapped, &any_clamped);
     if (tid == 0) {
         int action;
         const uint32_t forced = ctl->forced;
@@ -432,8 +428,9 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, uint32_t scan
         }
         if (tid == 0) d.ord[n - 1] = s;  // (slot n-1 is read by no chunk after the one that wrote n-2)
         __syncthreads();
-        double sm2;
-        const double hm = block_entropy_div(d.S, double(n), d.B, scratch, &sm2);
+        // H(S / n) of the new set: what delta_jsd evaluated, unless drop_lowest's clamp changed a bin
+        double sm2 = sm, hm = h_swapped;
+        if (any_clamped) hm = block_entropy_div(d.S, double(n), d.B, scratch, &sm2);
         if (tid == 0) {
             ctl->total_jsd = hm - ctl->sum_entropy / double(n);
             ctl->ev_kind = 1;
@@ -713,87 +710,36 @@ __device__ void finalize_body(SelDev &d, double *scratch, int &s_go) {
 }
 
 
-// All members' leave-one-out scores in ONE pass of one block (small sets): every thread
-// keeps a (h, sum) pair per member for its bins and the 2 * n values are reduced
-// together -- one barrier pair instead of n.  Same per-bin arithmetic as loo_body.
-constexpr uint32_t FUSE_MAX = 16;
-__device__ void loo_small(const SelDev &d, double *scratch, uint32_t *s_slot) {
-    const SelCtl *ctl = d.ctl;
-    const uint32_t kind = ctl->ev_kind;
-    const uint32_t n = ctl->ev_n;
-    const bool tent = kind == 2;
-    const double *Sv = tent ? d.Stmp : d.S;
-    const double sumH = tent ? ctl->t_sum_entropy : ctl->sum_entropy;
-    const double tj = tent ? ctl->t_total_jsd : ctl->total_jsd;
-    const double div = double(n) - 1.0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = (blockDim.x + 63) >> 6;
-    if (threadIdx.x < n) s_slot[threadIdx.x] = (tent && threadIdx.x == n - 1) ? n - 1 : d.ord[threadIdx.x];
-    __syncthreads();
-    double h[FUSE_MAX], sm[FUSE_MAX];
-#pragma unroll
-    for (uint32_t r = 0; r < FUSE_MAX; r++) h[r] = sm[r] = 0.0;
-    for (uint64_t i = threadIdx.x; i < d.B; i += blockDim.x) {
-        const double sv = Sv[i];
-#pragma unroll
-        for (uint32_t r = 0; r < FUSE_MAX; r++) {
-            if (r < n) {
-                double v = (sv - d.M[uint64_t(s_slot[r]) * d.B + i]) / div;
-                if (v <= DVS_EPS) v = 0.0;
-                if (v > 0.0) h[r] -= v * log2_acc(v);
-                sm[r] += v;
-            }
-        }
-    }
-    // scratch layout: [wave][2 * FUSE_MAX]
-#pragma unroll
-    for (uint32_t r = 0; r < FUSE_MAX; r++) {
-        if (r < n) {
-            const double a = dvs_wave_sum(h[r]), b = dvs_wave_sum(sm[r]);
-            if (lane == 0) {
-                scratch[wave * 2 * FUSE_MAX + r] = a;
-                scratch[wave * 2 * FUSE_MAX + FUSE_MAX + r] = b;
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < n) {
-        const uint32_t r = threadIdx.x;
-        double a = 0.0, b = 0.0;
-        for (int w = 0; w < nwave; w++) {
-            a += scratch[w * 2 * FUSE_MAX + r];
-            b += scratch[w * 2 * FUSE_MAX + FUSE_MAX + r];
-        }
-        const double mean_entropy = (sumH - d.mH[s_slot[r]]) / div;
-        d.dtmp[r] = tj - (a - mean_entropy);
-        d.dsum[r] = b;
-    }
-    __syncthreads();
-}
-
-// Resolve kernel.  FUSED (sets of at most FUSE_MAX members): the leave-one-out pass and
-// the finalize step run in the same launch, so an event costs one kernel after the scan.
-template <typename T, bool FUSED>
-__global__ __launch_bounds__(WIDE_THREADS) void resolve_kernel(SelDev d, const T *__restrict__ mat,
-                                                            uint32_t scan_grid) {
-    __shared__ double scratch[16 * 2 * FUSE_MAX];
-    __shared__ uint32_t s_slot[FUSE_MAX];
-    __shared__ int s_flag;
-    resolve_body<T>(d, mat, scan_grid, scratch, s_flag);
-    if (!FUSED) return;
-    __syncthreads();
-    const SelCtl *ctl = d.ctl;
-    if (ctl->status != SEL_RUN || ctl->ev_kind == 0) return;
-    if (ctl->ev_n <= FUSE_MAX) {
-        loo_small(d, scratch, s_slot);
-    } else {
-        for (uint32_t r = 0; r < ctl->ev_n; r++) loo_body(d, r, scratch);
-        __syncthreads();
-    }
-    finalize_body(d, scratch, s_flag);
-}
-
-__global__ __launch_bounds__(LOO_THREADS) void loo_kernel(SelDev d) {
+// Resolve kernel (one block).  (Resolve + leave-one-out + finalize as ONE single-block launch for
+// small sets measured slower -- 10.6 vs 8.9 ms per stepwise selection: one CU issues every
+// leave-one-out bin itself -- and was removed.)
+template <typename T>
+__global__ __launch_bounds__(WIDE_THREADS) void resolve_kernel(SelDev d, const T *__restrict__ mat) {
     __shared__ double scratch[48];
+    __shared__ int s_flag;
+    resolve_body<T>(d, mat, scratch, s_flag);
+}
+
+// Block r < n: the leave-one-out job of member r.  The LAST block adds up the rows the scan
+// launch read (per-workgroup counters, cleared for the next launch) beside them, off the event's
+// chain of dependent round trips.
+__global__ __launch_bounds__(LOO_THREADS) void loo_kernel(SelDev d, uint32_t scan_grid) {
+    __shared__ double scratch[48];
+    if (blockIdx.x + 1 == gridDim.x) {
+        double cnt = 0.0, cnt2 = 0.0, mnz = 0.0;
+        for (uint32_t i = threadIdx.x; i < scan_grid; i += LOO_THREADS) {
+            cnt += double(d.wg_rows[2 * i]);
+            cnt2 += double(d.wg_rows[2 * i + 1]);
+            d.wg_rows[2 * i] = 0;
+            d.wg_rows[2 * i + 1] = 0;
+        }
+        block_red3(cnt, mnz, cnt2, scratch);
+        if (threadIdx.x == 0 && (cnt != 0.0 || cnt2 != 0.0)) {  // (finalize_kernel, next in the stream, writes other words)
+            d.ctl->rows_scored += (unsigned long long)cnt;
+            d.ctl->rows_rechecked += (unsigned long long)cnt2;
+        }
+        return;
+    }
     loo_body(d, blockIdx.x, scratch);
 }
 
@@ -896,44 +842,36 @@ static void sel_free(dvs_select *s) {
 
 // stage 0: scan + resolve + loo + finalize; 1: resolve + loo + finalize; 2: loo + finalize
 template <typename T>
-static void launch_iteration(dvs_ctx *ctx_, dvs_select *s, const T *mat, int stage, hipStream_t on = nullptr) {
+static void launch_iteration(dvs_ctx *ctx, dvs_select *s, const T *mat, int stage, hipStream_t on = nullptr) {
     const SelDev &d = s->dev;
-    struct { hipStream_t stream; } ctx_l{on ? on : ctx_->stream}, *ctx = &ctx_l;  // (the launches below name ctx->stream)
-    auto dvs_event_get_ = [&]() { return dvs_event_get(ctx_); };
+    const hipStream_t stream = on ? on : ctx->stream;
     if (stage == 0) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (s->time_scan) {
             if (s->ev_used + 2 > s->ev_pool.size()) {
-                hipEvent_t a = dvs_event_get_(), b = dvs_event_get_();
+                hipEvent_t a = dvs_event_get(ctx), b = dvs_event_get(ctx);
                 s->ev_pool.push_back(a);
                 s->ev_pool.push_back(b);
             }
             e0 = s->ev_pool[s->ev_used];
             e1 = s->ev_pool[s->ev_used + 1];
             s->ev_used += 2;
-            (void)hipEventRecord(e0, ctx->stream);
+            (void)hipEventRecord(e0, stream);
         }
         if (s->scan_hot)
             hipLaunchKernelGGL((scan_kernel<T, true>), dim3(s->scan_grid), dim3(SCAN_THREADS),
-                               s->scan_lds, ctx->stream, d.ctl, mat, d.totals, d.rowH, d.order, d.labels,
+                               s->scan_lds, stream, d.ctl, mat, d.totals, d.rowH, d.order, d.labels,
                                d.inset, d.nlabels, d.base, d.wg_rows, d.B, s->base_in_lds ? 1 : 0);
         else
             hipLaunchKernelGGL((scan_kernel<T, false>), dim3(s->scan_grid), dim3(SCAN_THREADS),
-                               s->scan_lds, ctx->stream, d.ctl, mat, d.totals, d.rowH, d.order, d.labels,
+                               s->scan_lds, stream, d.ctl, mat, d.totals, d.rowH, d.order, d.labels,
                                d.inset, d.nlabels, d.base, d.wg_rows, d.B, s->base_in_lds ? 1 : 0);
-        if (s->time_scan) (void)hipEventRecord(e1, ctx->stream);
+        if (s->time_scan) (void)hipEventRecord(e1, stream);
     }
-    if (stage <= 1) {
-        if (s->fused)
-            hipLaunchKernelGGL((resolve_kernel<T, true>), dim3(1), dim3(WIDE_THREADS), 0, ctx->stream, d,
-                               mat, s->scan_grid);
-        else
-            hipLaunchKernelGGL((resolve_kernel<T, false>), dim3(1), dim3(WIDE_THREADS), 0, ctx->stream, d,
-                               mat, s->scan_grid);
-        if (s->fused) return;
-    }
-    hipLaunchKernelGGL(loo_kernel, dim3(s->loo_grid), dim3(LOO_THREADS), 0, ctx->stream, d);
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(WIDE_THREADS), 0, ctx->stream, d);
+    if (stage <= 1)
+        hipLaunchKernelGGL((resolve_kernel<T>), dim3(1), dim3(WIDE_THREADS), 0, stream, d, mat);
+    hipLaunchKernelGGL(loo_kernel, dim3(s->loo_grid + 1), dim3(LOO_THREADS), 0, stream, d, s->scan_grid);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(WIDE_THREADS), 0, stream, d);
 }
 
 static int sel_poll(dvs_ctx *ctx, dvs_select *s) {
@@ -1215,7 +1153,6 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     s->scan_grid = std::max<uint32_t>(1, uint32_t(ctx->n_cu) * wg_per_cu);
     s->loo_grid = cap;
     // measured slower than three launches (one CU does the whole leave-one-out pass): opt-in only
-    s->fused = cap <= FUSE_MAX + 1 && getenv("DVS_FUSE_EVENT");
     s->batch = 16;
     s->time_scan = ctx->timing;
     s->scan_hot = B % (256 * SCAN_CH) == 0 && !order && !labels && s->base_in_lds;
@@ -1600,7 +1537,6 @@ extern "C" int dvs_select_step_apply(dvs_ctx *ctx, dvs_select *s, const double *
     if (!ctx || !s || !d_all || !world) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
     s->dev.gather_all = d_all;
     s->dev.gather_world = world;
-    s->fused = s->cap <= FUSE_MAX + 1 && getenv("DVS_FUSE_EVENT");  // (one workgroup doing all the leave-one-out jobs: measured 10.6 vs 8.9 ms per selection)
     dvs_mat_dispatch(s->mat, [&](auto *mp) {
         launch_iteration(ctx, s, mp, 1);
         return 0;
