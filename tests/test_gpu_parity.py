@@ -1024,6 +1024,85 @@ def test_merge_nmost_over_rccl_world1(ctx, brca1):
         dist.destroy_process_group()
 
 
+def _chunk_merge_worker(rank, world, port, q):
+    import os
+    import sys
+
+    sys.path.insert(0, str(__import__("conftest").ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+
+    from diverseseq_amd import engine, parallel
+
+    torch.cuda.set_device(0)  # the ranks share the one GPU of the test box; gloo moves the words
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    stream = torch.cuda.Stream()
+    out = [rank]
+    with torch.cuda.stream(stream):
+        ctx = engine.Context(0, stream=stream.cuda_stream)
+        seqs = synth_seqs(907, 500, 31, invalid_frac=0.002, ragged=True)
+        n, k = 8, 4
+        bounds = parallel.chunk_bounds(len(seqs), world)
+        lo, hi = bounds[rank]
+        buffers = {}
+        for _ in range(2):  # the second pass reuses the exchange buffers, as bench.py's steps do
+            m = ctx.build_matrix(seqs[lo:hi], k, 4)
+            sel = m.nmost(n)
+            merged = parallel.merge_nmost(ctx, sel, n, rank, world, lo, dev, chunk_starts=[b[0] for b in bounds],
+                                          shared_stream=True, buffers=buffers)
+            mem = merged.members(with_freqs=False)
+            gids = merged.global_ids
+            out.append(([int(gids[p]) for p in mem.positions], mem.delta_jsd.tolist(), merged.summary().total_jsd))
+            merged.close()
+            sel.close()
+            m.close()
+    q.put(tuple(out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_chunk_merge_mode_across_ranks(world):
+    """what bench.py does with more than one rank (the reference's `-np G`: contiguous chunks, an
+    independent selection per rank, final_nmost over the winners): device-side gather, all_gather,
+    device-side merge on every rank == the oracle's chunk + merge, twice with the buffers reused"""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from diverseseq_amd import parallel
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_chunk_merge_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seqs = synth_seqs(907, 500, 31, invalid_frac=0.002, ragged=True)
+    rows, ids = [], []
+    for lo, hi in parallel.chunk_bounds(len(seqs), world):
+        lab, _, _, f = oracle.nmost(seqs[lo:hi], 8, 4, 4).members(with_freqs=True)
+        rows.append(f)
+        ids.append(lab.astype(np.int64) + lo)
+    rows, ids = np.vstack(rows), np.concatenate(ids)
+    exp = oracle.final_nmost(rows, 8)
+    epos, edelta, _, _ = exp.members()
+    for r in res:
+        assert r[1] == r[2]
+        got_ids, got_delta, got_total = r[1]
+        assert got_ids == ids[epos].tolist()
+        np.testing.assert_allclose(got_delta, edelta, rtol=RTOL, atol=1e-13)
+        np.testing.assert_allclose(got_total, exp.total_jsd, rtol=RTOL)
+    assert res[0][1:] == res[-1][1:]
+
+
 def test_large_sets_and_other_alphabets(ctx):
     """n beyond what the persistent engine replicates in LDS (multi-launch engine), a 20-state
     alphabet (k=2, 400 bins: not a multiple of 256) and a tiny one (3 states, k=3)"""
