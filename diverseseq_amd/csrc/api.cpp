@@ -177,6 +177,32 @@ hipStream_t dvs_ctx_stream2(dvs_ctx *ctx) {
     return ctx->stream2;
 }
 
+// Two streams that share no CU.  Mask bit i is CU i / 8 of XCD i % 8 on this part (checked with
+// scripts/micro/cu_mask.hip: bits 0..63 = 8 CUs on each of the 8 XCDs, no place shared with the
+// complement, cooperative launches accepted), so the first head_cus bits are an even share of every XCD.
+bool dvs_ctx_cu_split(dvs_ctx *ctx) {
+    if (ctx->cu_split_tried) return ctx->stream_head != nullptr;
+    ctx->cu_split_tried = true;
+    if (getenv("DVS_NO_CU_SPLIT") || ctx->n_cu < 128 || ctx->n_cu % 8) return false;
+    int head = 64;
+    if (const char *e = getenv("DVS_HEAD_CUS")) head = atoi(e);
+    head = std::max(16, std::min(ctx->n_cu / 2, head)) & ~7;
+    const uint32_t words = uint32_t(ctx->n_cu + 31) / 32;
+    std::vector<uint32_t> lo(words, 0u), hi(words, 0u);
+    for (int i = 0; i < ctx->n_cu; i++) (i < head ? lo : hi)[i / 32] |= 1u << (i % 32);
+    hipStream_t a = nullptr, b = nullptr;
+    if (hipExtStreamCreateWithCUMask(&a, words, lo.data()) != hipSuccess ||
+        hipExtStreamCreateWithCUMask(&b, words, hi.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        if (a) (void)hipStreamDestroy(a);
+        return false;
+    }
+    ctx->stream_head = a;
+    ctx->stream_rest = b;
+    ctx->head_cus = head;
+    return true;
+}
+
 void dvs_ctx_retain(dvs_ctx *ctx) {
     if (ctx) ctx->refs++;
 }
@@ -194,6 +220,8 @@ void dvs_ctx_release(dvs_ctx *ctx) {
     for (void *p : ctx->pinned_pool) (void)hipHostFree(p);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream_head) (void)hipStreamDestroy(ctx->stream_head);
+    if (ctx->stream_rest) (void)hipStreamDestroy(ctx->stream_rest);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -21,6 +21,17 @@ struct dvs_ctx {
     bool own_stream = false;
     hipStream_t stream2 = nullptr;  // second stream (created on first use): a selection's set-up kernels beside
                                     // the histogram of the rest of the matrix
+    // The CU split (created on first use, dvs_ctx_cu_split): `stream_head` may only use head_cus CUs
+    // (the same number on every XCD), `stream_rest` only the others.  A split build runs the histogram
+    // of everything behind the head rows on stream_rest while the selection's set-up and the HEAD
+    // PHASE of its persistent engine -- the event-dense first rows of the stream, a chain of
+    // hand-overs that keeps no CU busy -- run on stream_head beside it (kmer_hist.hip, select.hip).
+    hipStream_t stream_head = nullptr, stream_rest = nullptr;
+    int head_cus = 0;
+    bool cu_split_tried = false;
+    // a persistent launch of this context timed out at a grid barrier (its workgroups were not all
+    // resident): later selections go straight to the multi-launch engine
+    bool persist_failed = false;
     int n_cu = 0;
     size_t lds_per_block = 0;  // max dynamic LDS a block may ask for
     double *d_clog_tbl = nullptr;  // c log2 c, c < 256 (kmer_hist.hip)
@@ -67,6 +78,7 @@ struct dvs_ctx {
 int dvs_raise_dyn_lds(dvs_ctx *ctx, const void *fn, size_t bytes);
 void dvs_ctx_retain(dvs_ctx *ctx);
 hipStream_t dvs_ctx_stream2(dvs_ctx *ctx);  // NULL when it cannot be created
+bool dvs_ctx_cu_split(dvs_ctx *ctx);         // stream_head / stream_rest exist (false: no CU masks here)
 void dvs_ctx_release(dvs_ctx *ctx);
 
 // waits for a build that is still in flight (no-op otherwise) and moves the head totals to the vector
@@ -114,6 +126,9 @@ struct dvs_matrix {
     // rows [0, head_rows_built) were built by a launch of their own, finished when ev_built fires; the
     // rest of the matrix may still be in flight on the context's stream after that (0: no such split)
     uint32_t head_rows_built = 0;
+    // ... and that rest was launched on the context's stream_rest (CU split): the head CUs are free
+    // for a selection's head phase until the context's stream, which waits for it, moves on
+    bool rest_beside_head = false;
     int device = 0;
     dvs_ctx *ctx = nullptr;  // owner of the allocations
 };

@@ -676,23 +676,32 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
     if (m->kind == 2) {  // 16-bit rows (dvs_hist_rows_fit_u16 held when the matrix was allocated)
         const size_t lds16 = ((B * 2 + 15) & ~15ull) + (CLOG_TBL + 32) * sizeof(double);
         uint32_t *out16 = reinterpret_cast<uint32_t *>(m->d_counts16);
-        auto launch16 = [&](uint32_t row0, uint32_t count, uint32_t hot_end) {
+        auto launch16 = [&](uint32_t row0, uint32_t count, uint32_t hot_end, hipStream_t on) {
             if (ns4) {
                 rc = set_dyn_lds(ctx, kmer_hist_kernel<true, true, true, true>, lds16);
                 if (!rc)
-                    hipLaunchKernelGGL((kmer_hist_kernel<true, true, true, true>), dim3(count), dim3(128), lds16, ctx->stream,
+                    hipLaunchKernelGGL((kmer_hist_kernel<true, true, true, true>), dim3(count), dim3(128), lds16, on,
                                        d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), out16,
                                        m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_end, row0);
             } else {
                 rc = set_dyn_lds(ctx, kmer_hist_kernel<false, true, true, true>, lds16);
                 if (!rc)
-                    hipLaunchKernelGGL((kmer_hist_kernel<false, true, true, true>), dim3(count), dim3(128), lds16, ctx->stream,
+                    hipLaunchKernelGGL((kmer_hist_kernel<false, true, true, true>), dim3(count), dim3(128), lds16, on,
                                        d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), out16,
                                        m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_end, row0);
             }
         };
         if (head_rows) {
-            launch16(0, head_rows, head_rows);
+            // With a CU split (dvs_ctx_cu_split) the rest of the matrix is built on the stream that
+            // leaves the head CUs alone -- forked here, so that it is ordered behind everything the
+            // context's stream holds so far (the sequences' producer, the offsets' upload) and runs
+            // beside the head launch; the context's stream joins it again below.
+            const bool split = nseq - head_rows >= 16u * head_rows && dvs_ctx_cu_split(ctx);
+            hipEvent_t ev_fork = split ? dvs_event_get(ctx) : nullptr;
+            bool forked = ev_fork && hipEventRecord(ev_fork, ctx->stream) == hipSuccess &&
+                          hipStreamWaitEvent(ctx->stream_rest, ev_fork, 0) == hipSuccess;
+            if (ev_fork) dvs_event_put(ctx, ev_fork);  // (the wait took the record made above)
+            launch16(0, head_rows, head_rows, ctx->stream);
             void *pin = nullptr;
             if (!rc && dvs_pinned_get(ctx, &pin) == DVS_OK) {
                 m->head_count = uint32_t(std::min<size_t>(head_rows, 4096 / sizeof(uint32_t)));
@@ -711,9 +720,24 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
                     m->h_head_pinned = nullptr;
                 }
             }
-            if (!rc) launch16(head_rows, nseq - head_rows, std::min<uint64_t>(nseq, uint64_t(head_rows) + hot_rows));
+            if (!rc) {
+                const uint32_t hot_end = uint32_t(std::min<uint64_t>(nseq, uint64_t(head_rows) + hot_rows));
+                forked = forked && head_event_done;
+                launch16(head_rows, nseq - head_rows, hot_end, forked ? ctx->stream_rest : ctx->stream);
+                if (forked) {
+                    hipEvent_t ev_join = dvs_event_get(ctx);
+                    if (!ev_join || hipEventRecord(ev_join, ctx->stream_rest) != hipSuccess ||
+                        hipStreamWaitEvent(ctx->stream, ev_join, 0) != hipSuccess) {
+                        (void)hipGetLastError();
+                        (void)hipStreamSynchronize(ctx->stream_rest);  // (no event: the host orders the two streams)
+                    } else {
+                        m->rest_beside_head = true;
+                    }
+                    if (ev_join) dvs_event_put(ctx, ev_join);
+                }
+            }
         } else {
-            launch16(0, nseq, hot_rows);
+            launch16(0, nseq, hot_rows, ctx->stream);
         }
     } else if (pk16) {
         const size_t lds16 = ((B * 2 + 15) & ~15ull) + (CLOG_TBL + 32) * sizeof(double);

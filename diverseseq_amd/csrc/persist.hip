@@ -83,7 +83,8 @@ struct PSync {
     uint32_t wg_thresh;  // windows of up to wg_thresh rows per workgroup are scanned a row per WORKGROUP (0: never)
     float wg_scale;      // ... and are cursor * wg_scale / size rows long (rounded up to whole rounds)
     uint32_t no_coarse;  // measurement aid: skip the COARSE tier
-    uint32_t pad2[60];
+    uint32_t stop_at;    // head phase: leave at this stream position with status RUN (0: walk the whole stream)
+    uint32_t pad2[59];
     // event words, slot = epoch % 3, one copy per group g = blockIdx % 8 (a wave polls before every
     // row: one word for the whole grid serialises those loads at the memory side): ev[s][32 g] = first
     // event position, ev[s][32 g + 16] = the same position when the event is sure
@@ -705,6 +706,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     PState st;
     st.cursor = ctl->cursor;
     st.npos = ctl->npos;
+    const bool head_phase = sync->stop_at != 0u && uint64_t(sync->stop_at) < st.npos;
+    if (head_phase) st.npos = sync->stop_at;  // (the next launch carries on from the mirrored state)
     st.window = ctl->window;
     st.wmin = ctl->window_min;
     st.wmax = ctl->window_max;
@@ -1616,7 +1619,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             ctl->arb_pos = arb_pos;
             if (arb_stage == ARB_RESOLVE) ctl->event_pos = arb_pos;  // resolve_kernel re-evaluates it
         }
-        ctl->status = bail ? SEL_RUN : (exit_status == SEL_RUN ? SEL_ERROR : exit_status);
+        ctl->status = (bail || (head_phase && exit_status == SEL_DONE)) ? SEL_RUN
+                      : (exit_status == SEL_RUN ? SEL_ERROR : exit_status);
     }
 }
 
@@ -1624,12 +1628,18 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
 
 // One persistent launch.  Returns DVS_OK with *ran = false when the selection does not
 // qualify (the caller then uses the multi-launch engine).
+// head_stop != 0: the HEAD PHASE -- `grid` workgroups on stream `on` (the context's CU-masked head
+// stream) walk positions below head_stop and leave the state mirrored with status RUN.
 template <typename T>
-static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
+static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat, uint32_t grid, uint32_t head_stop,
+                          hipStream_t on) {
     const SelDev &d = s->dev;
-    // (the block's host image belongs to the selection: the async upload may read it after this returns)
-    s->h_psync.assign(sizeof(PSync), 0);
-    PSync &init = *reinterpret_cast<PSync *>(s->h_psync.data());
+    // (the block's host image belongs to the selection: the async upload may read it after this returns;
+    // the head phase has an image of its own, its upload may still be pending when the next one is made)
+    std::vector<unsigned char> &image = head_stop ? s->h_psync_head : s->h_psync;
+    image.assign(sizeof(PSync), 0);
+    PSync &init = *reinterpret_cast<PSync *>(image.data());
+    init.stop_at = head_stop;
     for (int i = 0; i < 3; i++)
         for (int w = 0; w < 16; w++) init.ev[i][w * 16] = SEL_NONE;
     // a row per workgroup while a window is at most this many rounds of the grid (default policy only)
@@ -1639,8 +1649,8 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     if (const char *e = getenv("DVS_PERSIST_WG_SCALE")) init.wg_scale = float(atof(e));
     init.no_coarse = (getenv("DVS_PERSIST_NO_COARSE") ? 1u : 0u) | (getenv("DVS_PERSIST_NO_EVENTS") ? 2u : 0u) |
                      (getenv("DVS_PERSIST_NO_BURST_DROP") ? 8u : 0u);
-    DVS_HIP(ctx, hipMemcpyAsync(s->psync, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
-    DVS_HIP(ctx, hipMemsetAsync(s->ppart, 0, p_acc_bytes(s->persist_maxn), ctx->stream));
+    DVS_HIP(ctx, hipMemcpyAsync(s->psync, &init, sizeof init, hipMemcpyHostToDevice, on));
+    DVS_HIP(ctx, hipMemsetAsync(s->ppart, 0, p_acc_bytes(s->persist_maxn), on));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->time_scan) {
         if (s->ev_used + 2 > s->ev_pool.size()) {
@@ -1651,7 +1661,7 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
         e0 = s->ev_pool[s->ev_used];
         e1 = s->ev_pool[s->ev_used + 1];
         s->ev_used += 2;
-        (void)hipEventRecord(e0, ctx->stream);
+        (void)hipEventRecord(e0, on);
     }
     const void *fn = s->params.mode == DVS_MODE_MAX ? reinterpret_cast<const void *>(persist_nmost_kernel<T, true, true>)
                      : d.B <= uint64_t(P_J) * P_THREADS ? reinterpret_cast<const void *>(persist_nmost_kernel<T, true>)
@@ -1660,17 +1670,22 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     const T *mat_arg = mat;
     PSync *sync_arg = static_cast<PSync *>(s->psync);
     unsigned long long *part_arg = static_cast<unsigned long long *>(s->ppart);
-    uint32_t g_arg = s->persist_grid;
+    uint32_t g_arg = grid;
     void *args[] = {&d_arg, &mat_arg, &sync_arg, &part_arg, &g_arg};
-    // The grid barrier needs every workgroup resident.  A cooperative launch makes the runtime
-    // refuse a grid the device cannot hold at once (a CU mask, a partition) instead of letting the
-    // workgroups spin into their timeout; kernels of other streams that occupy CUs for a while
-    // are what the bounded spins and the caller's fall-back to the multi-launch engine are for.
+    // The grid barrier needs every workgroup resident: dvs_persist_setup checked that the device holds
+    // the grid (one workgroup with this LDS per CU, grid <= CUs), every spin is bounded, and a launch
+    // that still gives up at a barrier -- CUs held by another stream's kernels, a CU mask the runtime
+    // does not report -- sends the selection to the multi-launch engine and, from then on, every
+    // later one of the context too (ctx->persist_failed).  hipLaunchCooperativeKernel adds a runtime
+    // check of the same arithmetic and no reservation, and costs ~0.2 ms per selection on this stack
+    // (a step of 2.13 -> 1.91 ms without it: the launch itself starts 40 us later, the memset in front
+    // of it and the copy behind it take 35 us longer each, and the kernel runs 3 % slower);
+    // DVS_PERSIST_COOP=1 turns it back on.
     hipError_t le = s->persist_coop
-                        ? hipLaunchCooperativeKernel(fn, dim3(s->persist_grid), dim3(P_THREADS), args,
-                                                     uint32_t(s->persist_lds), ctx->stream)
-                        : hipLaunchKernel(fn, dim3(s->persist_grid), dim3(P_THREADS), args, s->persist_lds, ctx->stream);
-    if (s->time_scan) (void)hipEventRecord(e1, ctx->stream);
+                        ? hipLaunchCooperativeKernel(fn, dim3(grid), dim3(P_THREADS), args,
+                                                     uint32_t(s->persist_lds), on)
+                        : hipLaunchKernel(fn, dim3(grid), dim3(P_THREADS), args, s->persist_lds, on);
+    if (s->time_scan) (void)hipEventRecord(e1, on);
     if (le != hipSuccess) {
         (void)hipGetLastError();
         return DVS_ERR_UNSUPPORTED;  // (the caller falls back; no message: nothing failed for the user)
@@ -1682,10 +1697,11 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat) {
 int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     const uint64_t B = s->dev.B;
     s->persist = false;
-    if (getenv("DVS_NO_PERSIST")) return DVS_OK;
+    if (getenv("DVS_NO_PERSIST") || ctx->persist_failed) return DVS_OK;
     const bool maxm = s->params.mode == DVS_MODE_MAX && !getenv("DVS_NO_PERSIST_MAX");
     if ((s->params.mode != DVS_MODE_NMOST && !maxm) || !s->h_order.empty() || !s->h_labels.empty()) return DVS_OK;
     s->persist_grid = uint32_t(ctx->n_cu);  // one 512-thread workgroup per CU: all resident
+    if (const char *e = getenv("DVS_PERSIST_GRID")) s->persist_grid = std::max(2, std::min(ctx->n_cu, atoi(e)));  // (measurement knob)
     const bool cached = B <= uint64_t(P_J) * P_THREADS;
     if (maxm && !cached) return DVS_OK;  // (the growth phase wants the candidate in registers and S in LDS)
     s->persist_maxn = p_maxn(cached);
@@ -1714,7 +1730,7 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     }
     int coop = 0;
     (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, ctx->device);
-    s->persist_coop = coop != 0 && !getenv("DVS_PERSIST_NO_COOP");
+    s->persist_coop = coop != 0 && getenv("DVS_PERSIST_COOP") != nullptr;
     rc = dvs_dev_alloc(ctx, &s->psync, sizeof(PSync), "persistent sync block");
     if (!rc) rc = dvs_dev_alloc(ctx, &s->ppart, p_acc_bytes(s->persist_maxn), "leave-one-out accumulators");
     if (rc) return rc;
@@ -1725,5 +1741,9 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
 size_t dvs_persist_dbg_offset(void) { return offsetof(PSync, dbg2); }  // dbg2[16] then dbg[16]
 
 int dvs_persist_launch(dvs_ctx *ctx, dvs_select *s) {
-    return dvs_mat_dispatch(s->mat, [&](auto *mp) { return persist_launch(ctx, s, mp); });
+    return dvs_mat_dispatch(s->mat, [&](auto *mp) { return persist_launch(ctx, s, mp, s->persist_grid, 0u, ctx->stream); });
+}
+
+int dvs_persist_launch_head(dvs_ctx *ctx, dvs_select *s, uint32_t grid, uint32_t stop_at, hipStream_t on) {
+    return dvs_mat_dispatch(s->mat, [&](auto *mp) { return persist_launch(ctx, s, mp, grid, stop_at, on); });
 }

@@ -97,6 +97,7 @@ struct dvs_select {
     size_t persist_lds = 0;
     void *psync = nullptr;
     std::vector<unsigned char> h_psync;  // host image of the sync block (source of its upload)
+    std::vector<unsigned char> h_psync_head;  // ... and the head phase's
     void *ppart = nullptr;
     hipEvent_t ev_side_done = nullptr;  // the set-up kernels on the context's second stream have run
     void *d_seed_list = nullptr;  // the seed positions on the device (kept until the selection goes: two streams read it)
@@ -119,4 +120,5 @@ void dvs_select_arbiter_free(dvs_select *s);
 // persist.hip
 int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s);
 int dvs_persist_launch(dvs_ctx *ctx, dvs_select *s);
+int dvs_persist_launch_head(dvs_ctx *ctx, dvs_select *s, uint32_t grid, uint32_t stop_at, hipStream_t on);
 size_t dvs_persist_dbg_offset(void);

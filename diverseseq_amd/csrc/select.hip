@@ -941,6 +941,7 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
             // the multi-launch engine, which needs no co-residency, serves the request.
             s->persist = false;
             s->persist_fell_back = true;
+            if (!fake_error) ctx->persist_failed = true;  // (the wait for the timeout is paid once per context)
             dvs_select_arbiter_free(s);  // (its replay of the event log belongs to the abandoned run)
             rc = sel_seed<T>(ctx, s, mat, ctx->stream);
             if (rc) return rc;
@@ -998,12 +999,28 @@ static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     // selection -- which read only the seed rows -- go to the second stream and run beside that launch
     // instead of queueing behind it; the engine itself is launched on the first stream behind both.
     hipStream_t side = nullptr;
+    bool head_phase = false;
     if (s->mat->head_rows_built && s->params.n_seed <= s->mat->head_rows_built && s->h_order.empty() &&
-        !(s->params.flags & DVS_SELECT_STEPWISE) && !getenv("DVS_NO_SIDE_STREAM"))
-        side = dvs_ctx_stream2(ctx);
+        !(s->params.flags & DVS_SELECT_STEPWISE) && !getenv("DVS_NO_SIDE_STREAM")) {
+        // HEAD PHASE: that launch runs on the context's stream_rest and leaves the head CUs alone (CU
+        // split), so the persistent engine starts on them right behind the set-up kernels and walks
+        // the rows that are already built -- the event-dense head of the stream, a chain of
+        // hand-overs that needs no more than a few workgroups -- while the histogram runs; the launch
+        // over the full grid then carries on from the state it mirrors.  (nmost; a set whose
+        // leave-one-out jobs fit the head grid one per workgroup.)
+        head_phase = s->mat->rest_beside_head && ctx->stream_head && s->persist &&
+                     s->params.mode == DVS_MODE_NMOST && s->params.window == 0 &&
+                     s->cap + 2 <= uint32_t(ctx->head_cus) && s->npos > 4ull * s->mat->head_rows_built &&
+                     s->params.n_seed + 64 <= s->mat->head_rows_built && !getenv("DVS_NO_HEAD_PHASE");
+        side = head_phase ? ctx->stream_head : dvs_ctx_stream2(ctx);
+    }
     hipStream_t st = side ? side : ctx->stream;
     int rc = sel_seed<T>(ctx, s, mat, st);
     if (rc) return rc;
+    if (head_phase) {
+        rc = dvs_persist_launch_head(ctx, s, uint32_t(ctx->head_cus), s->mat->head_rows_built, side);
+        if (rc && rc != DVS_ERR_UNSUPPORTED) return rc;  // (refused: the full-grid launch starts from the seeds)
+    }
     if (side) {
         if (!s->ev_side_done) s->ev_side_done = dvs_event_get(ctx);
         DVS_HIP(ctx, hipEventRecord(s->ev_side_done, side));
