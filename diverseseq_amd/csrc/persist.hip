@@ -1628,14 +1628,10 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
 
 // One persistent launch.  Returns DVS_OK with *ran = false when the selection does not
 // qualify (the caller then uses the multi-launch engine).
-// head_stop != 0: the HEAD PHASE -- `grid` workgroups on stream `on` (the context's CU-masked head
-// stream) walk positions below head_stop and leave the state mirrored with status RUN.
-template <typename T>
-static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat, uint32_t grid, uint32_t head_stop,
-                          hipStream_t on) {
-    const SelDev &d = s->dev;
-    // (the block's host image belongs to the selection: the async upload may read it after this returns;
-    // the head phase has an image of its own, its upload may still be pending when the next one is made)
+// Fresh sync block + cleared accumulators of the next launch, enqueued on `on`.  The head phase has
+// blocks (and a host image: the async upload may read it after this returns) of its own, so the
+// full-grid launch's can be made ready while the head phase is still running.
+static int persist_prepare(dvs_ctx *ctx, dvs_select *s, uint32_t head_stop, hipStream_t on) {
     std::vector<unsigned char> &image = head_stop ? s->h_psync_head : s->h_psync;
     image.assign(sizeof(PSync), 0);
     PSync &init = *reinterpret_cast<PSync *>(image.data());
@@ -1649,8 +1645,22 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat, uint32_t gr
     if (const char *e = getenv("DVS_PERSIST_WG_SCALE")) init.wg_scale = float(atof(e));
     init.no_coarse = (getenv("DVS_PERSIST_NO_COARSE") ? 1u : 0u) | (getenv("DVS_PERSIST_NO_EVENTS") ? 2u : 0u) |
                      (getenv("DVS_PERSIST_NO_BURST_DROP") ? 8u : 0u);
-    DVS_HIP(ctx, hipMemcpyAsync(s->psync, &init, sizeof init, hipMemcpyHostToDevice, on));
-    DVS_HIP(ctx, hipMemsetAsync(s->ppart, 0, p_acc_bytes(s->persist_maxn), on));
+    DVS_HIP(ctx, hipMemcpyAsync(head_stop ? s->psync_head : s->psync, &init, sizeof init, hipMemcpyHostToDevice, on));
+    DVS_HIP(ctx, hipMemsetAsync(head_stop ? s->ppart_head : s->ppart, 0, p_acc_bytes(s->persist_maxn), on));
+    return DVS_OK;
+}
+
+// head_stop != 0: the HEAD PHASE -- `grid` workgroups on stream `on` (the context's CU-masked head
+// stream) walk positions below head_stop and leave the state mirrored with status RUN.
+template <typename T>
+static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat, uint32_t grid, uint32_t head_stop,
+                          hipStream_t on) {
+    const SelDev &d = s->dev;
+    if (head_stop || !s->persist_prepared) {
+        int prc = persist_prepare(ctx, s, head_stop, on);
+        if (prc) return prc;
+    }
+    if (!head_stop) s->persist_prepared = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->time_scan) {
         if (s->ev_used + 2 > s->ev_pool.size()) {
@@ -1668,8 +1678,8 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat, uint32_t gr
                                                         : reinterpret_cast<const void *>(persist_nmost_kernel<T, false>);
     SelDev d_arg = d;
     const T *mat_arg = mat;
-    PSync *sync_arg = static_cast<PSync *>(s->psync);
-    unsigned long long *part_arg = static_cast<unsigned long long *>(s->ppart);
+    PSync *sync_arg = static_cast<PSync *>(head_stop ? s->psync_head : s->psync);
+    unsigned long long *part_arg = static_cast<unsigned long long *>(head_stop ? s->ppart_head : s->ppart);
     uint32_t g_arg = grid;
     void *args[] = {&d_arg, &mat_arg, &sync_arg, &part_arg, &g_arg};
     // The grid barrier needs every workgroup resident: dvs_persist_setup checked that the device holds
@@ -1745,5 +1755,17 @@ int dvs_persist_launch(dvs_ctx *ctx, dvs_select *s) {
 }
 
 int dvs_persist_launch_head(dvs_ctx *ctx, dvs_select *s, uint32_t grid, uint32_t stop_at, hipStream_t on) {
+    if (!s->psync_head) {
+        int rc = dvs_dev_alloc(ctx, &s->psync_head, sizeof(PSync), "head phase sync block");
+        if (!rc) rc = dvs_dev_alloc(ctx, &s->ppart_head, p_acc_bytes(s->persist_maxn), "head phase accumulators");
+        if (rc) return rc;
+    }
     return dvs_mat_dispatch(s->mat, [&](auto *mp) { return persist_launch(ctx, s, mp, grid, stop_at, on); });
+}
+
+// the full-grid launch's blocks, made ready on the context's stream ahead of the launch itself
+int dvs_persist_prepare_main(dvs_ctx *ctx, dvs_select *s) {
+    int rc = persist_prepare(ctx, s, 0u, ctx->stream);
+    if (!rc) s->persist_prepared = true;
+    return rc;
 }

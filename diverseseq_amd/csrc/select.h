@@ -99,6 +99,8 @@ struct dvs_select {
     std::vector<unsigned char> h_psync;  // host image of the sync block (source of its upload)
     std::vector<unsigned char> h_psync_head;  // ... and the head phase's
     void *ppart = nullptr;
+    void *psync_head = nullptr, *ppart_head = nullptr;  // the head phase's own blocks
+    bool persist_prepared = false;  // psync / ppart already hold a fresh image for the next full-grid launch
     hipEvent_t ev_side_done = nullptr;  // the set-up kernels on the context's second stream have run
     void *d_seed_list = nullptr;  // the seed positions on the device (kept until the selection goes: two streams read it)
     int batch = 16;
@@ -121,4 +123,5 @@ void dvs_select_arbiter_free(dvs_select *s);
 int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s);
 int dvs_persist_launch(dvs_ctx *ctx, dvs_select *s);
 int dvs_persist_launch_head(dvs_ctx *ctx, dvs_select *s, uint32_t grid, uint32_t stop_at, hipStream_t on);
+int dvs_persist_prepare_main(dvs_ctx *ctx, dvs_select *s);
 size_t dvs_persist_dbg_offset(void);

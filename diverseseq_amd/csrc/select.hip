@@ -833,6 +833,8 @@ static void sel_free(dvs_select *s) {
     for (hipEvent_t e : s->ev_pool) dvs_event_put(s->ctx, e);
     dvs_dev_free(s->ctx, s->psync);
     dvs_dev_free(s->ctx, s->ppart);
+    dvs_dev_free(s->ctx, s->psync_head);
+    dvs_dev_free(s->ctx, s->ppart_head);
     dvs_dev_free(s->ctx, s->d_seed_list);
     if (s->ev_side_done) dvs_event_put(s->ctx, s->ev_side_done);
     dvs_select_arbiter_free(s);
@@ -1020,6 +1022,10 @@ static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     if (head_phase) {
         rc = dvs_persist_launch_head(ctx, s, uint32_t(ctx->head_cus), s->mat->head_rows_built, side);
         if (rc && rc != DVS_ERR_UNSUPPORTED) return rc;  // (refused: the full-grid launch starts from the seeds)
+        // the full-grid launch's sync block and accumulators: behind the histogram on the context's
+        // stream, i.e. while the head phase runs, not between the two launches
+        rc = dvs_persist_prepare_main(ctx, s);
+        if (rc) return rc;
     }
     if (side) {
         if (!s->ev_side_done) s->ev_side_done = dvs_event_get(ctx);

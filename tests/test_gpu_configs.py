@@ -392,3 +392,58 @@ def test_config_c5_100_genomes_sketches_and_matrix_vs_oracle(ctx):
         de = oracle.mash_distances(exp, 12, 3000)
         np.testing.assert_allclose(d, de, rtol=RTOL, atol=0)
         assert (d == d.T).all() and (np.diag(d) == 0).all()
+
+
+# ---------------------------------------------------------------- head phase (CU split)
+def _device_build(ctx, seqs, k):
+    import torch
+
+    data, offs = oracle.concat(seqs)
+    t = torch.from_numpy(np.concatenate([data, np.zeros(16, np.uint8)])).to("cuda:0")
+    torch.cuda.synchronize()
+    return ctx.build_matrix_device(t.data_ptr(), offs, k, 4), t
+
+
+@pytest.mark.parametrize("k,n", [(6, 10), (5, 7), (6, 40)])
+@pytest.mark.parametrize("bad_seeds", [(), (0, 3)])
+def test_head_phase_of_a_split_build_vs_oracle(ctx, k, n, bad_seeds):
+    """A device-resident build of more than 17k short sequences is split (head rows first, the rest on
+    the CU-masked stream) and the persistent engine walks the head rows on the head CUs meanwhile: two persistent
+    launches, the oracle's answer -- also when some of the first rows have no valid k-mer and are
+    skipped as seeds (records.rs:299-306)."""
+    seqs = synth_seqs(20_000, 260, seed=4242 + k + n, ragged=True, invalid_frac=0.001)
+    for i, r in enumerate(bad_seeds):
+        seqs[r] = np.full(40, 4, dtype=np.uint8) if i % 2 else seqs[r][:k - 1].copy()
+    exp = oracle.nmost(seqs, n, k, 4)
+    ctx.set_timing(True)
+    try:
+        m, keep = _device_build(ctx, seqs, k)
+        assert m.count_bytes == 2
+        sel = m.nmost(n)
+        s = _assert_selection(sel, exp)
+        assert s.engine == 1
+        assert s.scan_launches == 2, "head phase + full-grid launch expected"
+        sel.close()
+        m.close()
+    finally:
+        ctx.set_timing(False)
+    del keep
+
+
+@pytest.mark.parametrize("env", [{"DVS_NO_HEAD_PHASE": "1"}, {"DVS_NO_CU_SPLIT": "1"}, {"DVS_PERSIST_COOP": "1"}, {"DVS_HEAD_CUS": "32"}])
+def test_head_phase_knobs_do_not_change_the_answer(env, monkeypatch):
+    from diverseseq_amd import engine
+
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    c = engine.Context(0)  # (the CU split is a property of the context: a fresh one sees the knobs)
+    seqs = synth_seqs(20_000, 260, seed=99, ragged=True, invalid_frac=0.001)
+    exp = oracle.nmost(seqs, 9, 6, 4)
+    m, keep = _device_build(c, seqs, 6)
+    sel = m.nmost(9)
+    s = _assert_selection(sel, exp)
+    assert s.engine == 1
+    sel.close()
+    m.close()
+    c.close()
+    del keep
