@@ -311,8 +311,12 @@ def main():
                 "ms_per_step_with_offsets_cache": elapsed_cached / a.steps * 1e3,
             },
             "roofline": {
-                "kernel": (f"persist_nmost_kernel<uint{8 * cb}> (one launch per selection: windowed delta-JSD scan + "
-                           "in-kernel set updates behind grid barriers)") if stats["engine"] == 1
+                "kernel": (f"persist_nmost_kernel<uint{8 * cb}> (windowed delta-JSD scan + in-kernel set updates behind "
+                           "grid barriers; " +
+                           ("two launches per selection: the head of the stream on 64 masked CUs beside the histogram "
+                            "of the rest of the matrix, then the full grid from the state it leaves"
+                            if stats["scan_launches"] >= 2 * a.steps else "one launch per selection") + ")")
+                          if stats["engine"] == 1
                           else f"scan_kernel<uint{8 * cb}> (one launch per window)",
                 "count_bytes": cb,
                 "achieved_if_counts_were_u32": achieved * 4 / cb,  # comparable with round 1's lines (uint32 rows)
