@@ -670,7 +670,11 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
     // behind it, then everything else.  The selection's set-up kernels run on the context's second
     // stream beside the second launch (select.hip sel_start).
     uint32_t head_rows = 0;
-    if (m->kind == 2 && no_wait && !getenv("DVS_HIST_NO_SPLIT")) head_rows = std::min<uint32_t>(nseq, DVS_HEAD_ROWS);
+    if (m->kind == 2 && no_wait && !getenv("DVS_HIST_NO_SPLIT")) {
+        uint32_t want = DVS_HEAD_ROWS;
+        if (const char *e = getenv("DVS_HEAD_ROWS")) want = std::max(64, atoi(e));  // (measurement knob)
+        head_rows = std::min<uint32_t>(nseq, want);
+    }
     if (head_rows == nseq) head_rows = 0;  // (nothing left to run beside)
     bool head_event_done = false;
     if (m->kind == 2) {  // 16-bit rows (dvs_hist_rows_fit_u16 held when the matrix was allocated)
