@@ -29,9 +29,10 @@ struct dvs_ctx {
     hipStream_t stream_head = nullptr, stream_rest = nullptr;
     int head_cus = 0;
     bool cu_split_tried = false;
-    // a persistent launch of this context timed out at a grid barrier (its workgroups were not all
-    // resident): later selections go straight to the multi-launch engine
-    bool persist_failed = false;
+    // persistent launches of this context that timed out at a grid barrier in a row (their workgroups
+    // were not all resident): after three of them later selections go straight to the multi-launch
+    // engine; one that runs to its end clears the count
+    int persist_timeouts = 0;
     int n_cu = 0;
     size_t lds_per_block = 0;  // max dynamic LDS a block may ask for
     double *d_clog_tbl = nullptr;  // c log2 c, c < 256 (kmer_hist.hip)

@@ -1685,8 +1685,8 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat, uint32_t gr
     // The grid barrier needs every workgroup resident: dvs_persist_setup checked that the device holds
     // the grid (one workgroup with this LDS per CU, grid <= CUs), every spin is bounded, and a launch
     // that still gives up at a barrier -- CUs held by another stream's kernels, a CU mask the runtime
-    // does not report -- sends the selection to the multi-launch engine and, from then on, every
-    // later one of the context too (ctx->persist_failed).  hipLaunchCooperativeKernel adds a runtime
+    // does not report -- sends the selection to the multi-launch engine, and after three such
+    // time-outs in a row every later selection of the context too (ctx->persist_timeouts).  hipLaunchCooperativeKernel adds a runtime
     // check of the same arithmetic and no reservation, and costs ~0.2 ms per selection on this stack
     // (a step of 2.13 -> 1.91 ms without it: the launch itself starts 40 us later, the memset in front
     // of it and the copy behind it take 35 us longer each, and the kernel runs 3 % slower);
@@ -1707,7 +1707,7 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat, uint32_t gr
 int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     const uint64_t B = s->dev.B;
     s->persist = false;
-    if (getenv("DVS_NO_PERSIST") || ctx->persist_failed) return DVS_OK;
+    if (getenv("DVS_NO_PERSIST") || ctx->persist_timeouts >= 3) return DVS_OK;
     const bool maxm = s->params.mode == DVS_MODE_MAX && !getenv("DVS_NO_PERSIST_MAX");
     if ((s->params.mode != DVS_MODE_NMOST && !maxm) || !s->h_order.empty() || !s->h_labels.empty()) return DVS_OK;
     s->persist_grid = uint32_t(ctx->n_cu);  // one 512-thread workgroup per CU: all resident

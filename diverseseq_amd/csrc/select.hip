@@ -943,14 +943,17 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
             // the multi-launch engine, which needs no co-residency, serves the request.
             s->persist = false;
             s->persist_fell_back = true;
-            if (!fake_error) ctx->persist_failed = true;  // (the wait for the timeout is paid once per context)
+            if (!fake_error) ctx->persist_timeouts++;  // (three in a row and the context stops trying)
             dvs_select_arbiter_free(s);  // (its replay of the event log belongs to the abandoned run)
             rc = sel_seed<T>(ctx, s, mat, ctx->stream);
             if (rc) return rc;
             persist_launches = 0;
             continue;
         }
-        if (c.status == SEL_DONE) return DVS_OK;
+        if (c.status == SEL_DONE) {
+            if (s->persist && persist_launches) ctx->persist_timeouts = 0;
+            return DVS_OK;
+        }
         if (c.status == SEL_ARBITER) {
             if (s->params.flags & DVS_SELECT_NO_ARBITER)
                 return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED,
