@@ -1708,6 +1708,8 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     const uint64_t B = s->dev.B;
     s->persist = false;
     if (getenv("DVS_NO_PERSIST") || ctx->persist_timeouts >= 3) return DVS_OK;
+    // a process-wide CU mask hides CUs the device still reports: the grid below could never be resident
+    if (getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK")) return DVS_OK;
     const bool maxm = s->params.mode == DVS_MODE_MAX && !getenv("DVS_NO_PERSIST_MAX");
     if ((s->params.mode != DVS_MODE_NMOST && !maxm) || !s->h_order.empty() || !s->h_labels.empty()) return DVS_OK;
     s->persist_grid = uint32_t(ctx->n_cu);  // one 512-thread workgroup per CU: all resident
