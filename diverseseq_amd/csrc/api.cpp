@@ -184,6 +184,7 @@ bool dvs_ctx_cu_split(dvs_ctx *ctx) {
     if (ctx->cu_split_tried) return ctx->stream_head != nullptr;
     ctx->cu_split_tried = true;
     if (getenv("DVS_NO_CU_SPLIT") || ctx->n_cu < 128 || ctx->n_cu % 8) return false;
+    if (getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK")) return false;  // (the bit layout below assumes every CU)
     int head = 64;
     if (const char *e = getenv("DVS_HEAD_CUS")) head = atoi(e);
     head = std::max(16, std::min(ctx->n_cu / 2, head)) & ~7;
