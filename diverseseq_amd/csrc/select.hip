@@ -1029,6 +1029,8 @@ static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat) {
         // stream, i.e. while the head phase runs, not between the two launches
         rc = dvs_persist_prepare_main(ctx, s);
         if (rc) return rc;
+        // (a later selection over the same matrix finds the histogram finished: nothing to run beside)
+        const_cast<dvs_matrix *>(s->mat)->rest_beside_head = false;
     }
     if (side) {
         if (!s->ev_side_done) s->ev_side_done = dvs_event_get(ctx);
