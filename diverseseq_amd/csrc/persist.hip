@@ -1656,11 +1656,12 @@ template <typename T>
 static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat, uint32_t grid, uint32_t head_stop,
                           hipStream_t on) {
     const SelDev &d = s->dev;
-    if (head_stop || !s->persist_prepared) {
+    if (head_stop ? !s->head_prepared : !s->persist_prepared) {
         int prc = persist_prepare(ctx, s, head_stop, on);
         if (prc) return prc;
     }
-    if (!head_stop) s->persist_prepared = false;
+    if (head_stop) s->head_prepared = false;
+    else s->persist_prepared = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->time_scan) {
         if (s->ev_used + 2 > s->ev_pool.size()) {
@@ -1756,13 +1757,25 @@ int dvs_persist_launch(dvs_ctx *ctx, dvs_select *s) {
     return dvs_mat_dispatch(s->mat, [&](auto *mp) { return persist_launch(ctx, s, mp, s->persist_grid, 0u, ctx->stream); });
 }
 
+static int persist_head_blocks(dvs_ctx *ctx, dvs_select *s) {
+    if (s->psync_head) return DVS_OK;
+    int rc = dvs_dev_alloc(ctx, &s->psync_head, sizeof(PSync), "head phase sync block");
+    if (!rc) rc = dvs_dev_alloc(ctx, &s->ppart_head, p_acc_bytes(s->persist_maxn), "head phase accumulators");
+    return rc;
+}
+
 int dvs_persist_launch_head(dvs_ctx *ctx, dvs_select *s, uint32_t grid, uint32_t stop_at, hipStream_t on) {
-    if (!s->psync_head) {
-        int rc = dvs_dev_alloc(ctx, &s->psync_head, sizeof(PSync), "head phase sync block");
-        if (!rc) rc = dvs_dev_alloc(ctx, &s->ppart_head, p_acc_bytes(s->persist_maxn), "head phase accumulators");
-        if (rc) return rc;
-    }
+    int rc = persist_head_blocks(ctx, s);
+    if (rc) return rc;
     return dvs_mat_dispatch(s->mat, [&](auto *mp) { return persist_launch(ctx, s, mp, grid, stop_at, on); });
+}
+
+// the head phase's blocks, made ready on its stream before the selection waits for the head rows' totals
+int dvs_persist_prepare_head(dvs_ctx *ctx, dvs_select *s, uint32_t stop_at, hipStream_t on) {
+    int rc = persist_head_blocks(ctx, s);
+    if (!rc) rc = persist_prepare(ctx, s, stop_at, on);
+    if (!rc) s->head_prepared = true;
+    return rc;
 }
 
 // the full-grid launch's blocks, made ready on the context's stream ahead of the launch itself

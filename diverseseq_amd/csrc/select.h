@@ -100,6 +100,7 @@ struct dvs_select {
     std::vector<unsigned char> h_psync_head;  // ... and the head phase's
     void *ppart = nullptr;
     void *psync_head = nullptr, *ppart_head = nullptr;  // the head phase's own blocks
+    bool head_prepared = false;     // ... and psync_head / ppart_head for the head phase
     bool persist_prepared = false;  // psync / ppart already hold a fresh image for the next full-grid launch
     hipEvent_t ev_side_done = nullptr;  // the set-up kernels on the context's second stream have run
     void *d_seed_list = nullptr;  // the seed positions on the device (kept until the selection goes: two streams read it)
@@ -124,4 +125,5 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s);
 int dvs_persist_launch(dvs_ctx *ctx, dvs_select *s);
 int dvs_persist_launch_head(dvs_ctx *ctx, dvs_select *s, uint32_t grid, uint32_t stop_at, hipStream_t on);
 int dvs_persist_prepare_main(dvs_ctx *ctx, dvs_select *s);
+int dvs_persist_prepare_head(dvs_ctx *ctx, dvs_select *s, uint32_t stop_at, hipStream_t on);
 size_t dvs_persist_dbg_offset(void);

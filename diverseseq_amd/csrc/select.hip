@@ -1250,6 +1250,15 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
             return prc;
         }
     }
+    // (what the head phase needs besides the seeds goes out before the wait below, on its stream)
+    if (s->persist && m->rest_beside_head && ctx->stream_head && m->head_rows_built && params->mode == DVS_MODE_NMOST &&
+        !order && !labels) {
+        int prc = dvs_persist_prepare_head(ctx, s, m->head_rows_built, ctx->stream_head);
+        if (prc) {
+            sel_free(s);
+            return prc;
+        }
+    }
     std::vector<uint64_t> seeds;
     {
         std::vector<uint32_t> h_tot(n_seed);
