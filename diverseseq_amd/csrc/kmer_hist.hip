@@ -704,7 +704,6 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
             hipEvent_t ev_fork = split ? dvs_event_get(ctx) : nullptr;
             bool forked = ev_fork && hipEventRecord(ev_fork, ctx->stream) == hipSuccess &&
                           hipStreamWaitEvent(ctx->stream_rest, ev_fork, 0) == hipSuccess;
-            if (ev_fork) dvs_event_put(ctx, ev_fork);  // (the wait took the record made above)
             launch16(0, head_rows, head_rows, ctx->stream);
             void *pin = nullptr;
             if (!rc && dvs_pinned_get(ctx, &pin) == DVS_OK) {
@@ -740,6 +739,9 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
                     if (ev_join) dvs_event_put(ctx, ev_join);
                 }
             }
+            // (back to the pool only now: an event handed out again and re-recorded while the wait on
+            // its first record is still queued would move that wait to the later record)
+            if (ev_fork) dvs_event_put(ctx, ev_fork);
         } else {
             launch16(0, nseq, hot_rows, ctx->stream);
         }
