@@ -84,7 +84,9 @@ struct PSync {
     float wg_scale;      // ... and are cursor * wg_scale / size rows long (rounded up to whole rounds)
     uint32_t no_coarse;  // measurement aid: skip the COARSE tier
     uint32_t stop_at;    // head phase: leave at this stream position with status RUN (0: walk the whole stream)
-    uint32_t pad2[59];
+    uint32_t seeded;     // the set is still only its seed positions: the launch works the initial state out itself
+    const unsigned long long *seed_list;  // ... those positions (ctl->size of them)
+    uint32_t pad2[56];
     // event words, slot = epoch % 3, one copy per group g = blockIdx % 8 (a wave polls before every
     // row: one word for the whole grid serialises those loads at the memory side): ev[s][32 g] = first
     // event position, ev[s][32 g + 16] = the same position when the event is sure
@@ -726,17 +728,22 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     st.cov_d = ctl->cov_delta;
     if (ctl->status != SEL_RUN || ctl->ev_kind != 0 || st.n > maxn || st.n < 2) return;
     if (MAXM && st.n < st.max_size && (ctl->s_is_resum == 0 || st.n + 2 > maxn)) return;  // (multi-launch kernels)
+    // SEEDED start (nmost, the state in the register cache): nothing but the control block and the
+    // seed positions exists yet -- no seed / rebuild / loo / finalize launches ran; the initial set
+    // (SummedRecords::new, records.rs:27-68) is worked out further down by the grid itself.
+    const bool seeded = !MAXM && CACHED && sync->seeded != 0u;
     for (uint32_t r = tid; r < st.n; r += P_THREADS) {
-        const uint64_t mp = d.mPos[d.ord[r]];
+        const uint32_t slot = seeded ? r : d.ord[r];
+        const uint64_t mp = seeded ? sync->seed_list[r] : d.mPos[slot];
         const double t = double(d.totals[mp]);
-        s_slot[r] = d.ord[r];
-        s_mH[r] = d.mH[d.ord[r]];
+        s_slot[r] = slot;
+        s_mH[r] = seeded ? d.rowH[mp] : d.mH[slot];
         s_pos[r] = mp;
         s_tot[r] = t;
         s_rt[r] = 1.0 / t;
     }
     __syncthreads();
-    {
+    if (!seeded) {
         const double *low = d.M + uint64_t(s_slot[st.li]) * B;
         const double rn0 = 1.0 / double(st.n);
         for (uint64_t i = tid; i < B; i += P_THREADS) {
@@ -761,7 +768,6 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     const uint32_t wg_thresh = sync->wg_thresh;       // (written by the host before the launch)
     const double wg_scale = double(sync->wg_scale);
     const bool coarse_on = (sync->no_coarse & 1u) == 0;
-    if (sync->no_coarse & 2u) st.thr = 1e300;  // measurement aid: no row is ever an event (pure streaming)
     bool wgmode = false;
     if (wg_thresh) st.window = p_next_window(st, nwg, wg_thresh, wg_scale, wgmode);
     // Leave-one-out jobs (the set size is constant in this mode): job (r, part) covers the
@@ -781,6 +787,199 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     };
     set_geometry(st.n);
 
+    if constexpr (!MAXM && CACHED) {
+    if (seeded) {
+        // ---- the initial set, by the grid: S = sum of the members' rows in member order and the sum
+        // of their entropies (records.rs:36-47), the leave-one-out pass as (n + 1) K jobs like after an
+        // accept (records.rs:220-252), argmin, and sl = S - lowest.  The mirror block writes what the
+        // set-up kernels would have left in global memory.  A decision too close to call -- or a sum
+        // check that is not sure -- is not taken here: the launch ends having changed nothing and the
+        // host runs the set-up kernels (SEL_NEED_SETUP).
+        const uint32_t n = st.n;
+        const double dn0 = double(n), rn0 = 1.0 / dn0, rdiv0 = 1.0 / (dn0 - 1.0);
+        double Sreg[P_J];
+#pragma unroll
+        for (int j = 0; j < P_J; j++) Sreg[j] = 0.0;
+        for (uint32_t r0 = 0; r0 < n; r0 += 4) {  // four members' counts requested at a time
+            T cv[4][P_J];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                const T *mrow = mat + s_pos[r0 + q < n ? r0 + q : r0] * B;
+#pragma unroll
+                for (int j = 0; j < P_J; j++) {
+                    const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                    if (i < B) cv[q][j] = mrow[i];
+                }
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                if (r0 + q < n) {
+                    const double mt = s_tot[r0 + q], mr = s_rt[r0 + q];
+#pragma unroll
+                    for (int j = 0; j < P_J; j++) {
+                        const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                        if (i < B) Sreg[j] += count_freq_x(cv[q][j], mt, mr);
+                    }
+                }
+            }
+        }
+        double sh = 0.0;
+        for (uint32_t r = 0; r < n; r++) sh += s_mH[r];  // (the same LDS words in the same order in every thread)
+#pragma unroll
+        for (int j = 0; j < P_J; j++) {
+            const uint64_t i = uint64_t(j) * P_THREADS + tid;
+            if (i < B) {
+                sl[i] = Sreg[j];  // (S for the jobs below; becomes S - lowest afterwards)
+                if (lead) d.S[i] = Sreg[j];
+            }
+        }
+        __syncthreads();
+        unsigned long long *acc_all = part;  // accumulator slot 0 (cleared by the host before the launch)
+        const unsigned long long *acc = acc_all + uint64_t(blockIdx.x & 7u) * (maxn + 1) * 2;
+        bool first_job = true;
+        for (uint32_t job = blockIdx.x; job < jobs && has_job; job += G) {
+            if (lead && one_job) break;
+            const uint32_t r = job / K, part_i = job % K;
+            const T *mrow = mat + (r < n ? s_pos[r] : 0) * B;
+            const double mtot = r < n ? s_tot[r] : 1.0, mrt = r < n ? s_rt[r] : 1.0;
+            double h = 0.0, sv = 0.0;
+#pragma unroll
+            for (int j = 0; j < P_J; j++) {
+                const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                if ((uint32_t(j) & (K - 1)) == part_i && i < B) {
+                    double u;
+                    if (r == n) {
+                        u = Sreg[j] * rn0;
+                    } else {
+                        u = (Sreg[j] - count_freq_x(mrow[i], mtot, mrt)) * rdiv0;  // updated_mean_freqs, records.rs:276-286
+                        if (u <= DVS_EPS) u = 0.0;
+                    }
+                    if (u > 0.0) h -= u * log2_tab(u, s_ltab);
+                    sv += u;
+                }
+            }
+            h = dvs_wave_sum_dpp(h);
+            sv = dvs_wave_sum_dpp(sv);
+            if (!first_job) __syncthreads();
+            first_job = false;
+            if (lane == 0) {
+                scratch[64 + wave] = h;
+                scratch[80 + wave] = sv;
+            }
+            __syncthreads();
+            if (tid < 8) {
+                double th = 0.0, ts = 0.0;
+                for (uint32_t w = 0; w < P_THREADS / 64; w++) {
+                    th += scratch[64 + w];
+                    ts += scratch[80 + w];
+                }
+                unsigned long long *dst = acc_all + (uint64_t(tid) * (maxn + 1) + r) * 2;
+                atomicAdd(dst, p_acc_word(th));
+                atomicAdd(dst + 1, p_acc_word(ts));
+            }
+        }
+        if (!grid_barrier(sync, G, gen, s_flag)) {
+            if (lead && tid == 0) ctl->status = SEL_ERROR;
+            return;
+        }
+        for (uint32_t r = tid; r <= n; r += P_THREADS) {
+            const double h = p_acc_value(__hip_atomic_load(acc + uint64_t(r) * 2, RLX_AGENT));
+            const double sv = p_acc_value(__hip_atomic_load(acc + uint64_t(r) * 2 + 1, RLX_AGENT));
+            if (r == n) {
+                scratch[110] = h;
+                scratch[111] = sv;
+            } else {
+                s_dl[r] = h - (sh - s_mH[r]) * rdiv0;  // JSD of the set without member r
+                s_ds[r] = sv;
+            }
+        }
+        __syncthreads();
+        const double hm = scratch[110];
+        const double tj = hm - sh / dn0;
+        const bool evr = sum_risky(scratch[111], B) || !(hm == hm);
+        for (uint32_t r = tid; r < n; r += P_THREADS) s_dl[r] = tj - s_dl[r];  // delta_jsd
+        __syncthreads();
+        if (wave == 0) p_argmin<(maxn + 63) / 64>(s_dl, s_ds, n, B, lane, scratch);
+        __syncthreads();
+        const double dmin0 = scratch[100], dsec0 = scratch[102], mean0 = scratch[103], sd0 = scratch[104];
+        const uint32_t low0 = uint32_t(scratch[101]);
+        const bool anyr0 = scratch[105] != 0.0;
+        const double band0 = sel_band(tj + sh / dn0, B);
+        if (anyr0 || evr || (n > 1 && dsec0 - dmin0 <= band0 && dsec0 < 1e6)) {
+            if (lead && tid == 0) ctl->status = SEL_NEED_SETUP;  // (every workgroup reads the same words: all leave)
+            return;
+        }
+        st.sumH = sh;
+        st.total_jsd = tj;
+        st.li = low0;
+        st.band = band0;
+        st.thr = tj + DVS_EPS;
+        st.mean_d = mean0;
+        st.std_d = sd0;
+        st.cov_d = sd0 / mean0;
+        st.n_loo = 1;  // (slot 0 is in use; the first accept takes slot 1 and clears slot 2)
+        {   // sl <- S - lowest (no clamp: what the set-up kernels' base vector holds)
+            const T *lrow = mat + s_pos[low0] * B;
+            const double ltot = s_tot[low0], lrt = s_rt[low0];
+            T lv[P_J];
+#pragma unroll
+            for (int j = 0; j < P_J; j++) {
+                const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                if (i < B) lv[j] = lrow[i];
+            }
+#pragma unroll
+            for (int j = 0; j < P_J; j++) {
+                const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                if (i < B) {
+                    const double nv = Sreg[j] - count_freq_x(lv[j], ltot, lrt);
+                    sl[i] = nv;
+                    if (COARSE) slf[i] = coarse_sl(nv, rn0);
+                    if (lead) d.base[i] = nv / dn0;
+                }
+            }
+        }
+        // (the mirror is the lead workgroup's alone: the accepts rewrite these words later, and plain
+        // stores of two workgroups to one address sit in two XCDs' L2s until the kernel ends -- whichever
+        // is written back last would win; a row per workgroup here corrupted exactly that way)
+        if (lead) {  // what seed_kernel / rebuild_kernel / loo_kernel / finalize_kernel leave behind
+            for (uint32_t r = 0; r < n; r++) {
+                const T *mrow = mat + s_pos[r] * B;
+                const double mt = s_tot[r], mr = s_rt[r];
+                double *dst = d.M + uint64_t(r) * B;
+                for (uint64_t i = tid; i < B; i += P_THREADS) dst[i] = count_freq_x(mrow[i], mt, mr);
+            }
+            for (uint32_t r = tid; r < n; r += P_THREADS) {
+                const uint64_t mp = s_pos[r];
+                d.ord[r] = r;
+                d.mH[r] = s_mH[r];
+                d.mLabel[r] = uint32_t(mp);  // (label-free: the label of a position is the position)
+                d.mPos[r] = mp;
+                if (uint32_t(mp) < d.nlabels) d.inset[uint32_t(mp)] = 1;
+                d.dtmp[r] = s_dl[r];
+                d.dsum[r] = s_ds[r];
+                d.mDelta[r] = s_dl[r];
+            }
+            if (tid == 0) {
+                ctl->sum_entropy = sh;
+                ctl->s_is_resum = 1;
+                ctl->total_jsd = tj;
+                ctl->lowest = low0;
+                ctl->mean_delta = mean0;
+                ctl->std_delta = sd0;
+                ctl->cov_delta = sd0 / mean0;
+                ctl->band = band0;
+                ctl->he_base = sh - s_mH[low0];
+                ctl->thr = tj + DVS_EPS;
+                ctl->ev_kind = 0;
+                ctl->ev_risky = 0;
+                ctl->ev_n = n;
+            }
+        }
+        __syncthreads();
+    }
+    }
+
+    if (sync->no_coarse & 2u) st.thr = 1e300;  // measurement aid: no row is ever an event (pure streaming)
 #ifdef DVS_PERSIST_STAMPS  // per-phase in-kernel timing (DVS_PERSIST_DEBUG prints it): costs registers
     unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
 #define P_STAMP(k)                                                         \
@@ -1636,6 +1835,8 @@ static int persist_prepare(dvs_ctx *ctx, dvs_select *s, uint32_t head_stop, hipS
     image.assign(sizeof(PSync), 0);
     PSync &init = *reinterpret_cast<PSync *>(image.data());
     init.stop_at = head_stop;
+    init.seeded = s->persist_seeded ? 1u : 0u;  // (the first launch of a selection whose set-up kernels were skipped)
+    init.seed_list = static_cast<const unsigned long long *>(s->d_seed_list);
     for (int i = 0; i < 3; i++)
         for (int w = 0; w < 16; w++) init.ev[i][w * 16] = SEL_NONE;
     // a row per workgroup while a window is at most this many rounds of the grid (default policy only)
@@ -1662,6 +1863,7 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat, uint32_t gr
     }
     if (head_stop) s->head_prepared = false;
     else s->persist_prepared = false;
+    s->persist_seeded = false;  // (only the first launch of a selection starts from the seeds)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->time_scan) {
         if (s->ev_used + 2 > s->ev_pool.size()) {

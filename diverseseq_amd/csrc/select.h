@@ -5,7 +5,8 @@
 
 #define SEL_NONE 0xFFFFFFFFFFFFFFFFull
 
-enum : uint32_t { SEL_RUN = 0, SEL_DONE = 1, SEL_ARBITER = 2, SEL_ERROR = 3 };
+enum : uint32_t { SEL_RUN = 0, SEL_DONE = 1, SEL_ARBITER = 2, SEL_ERROR = 3,
+                  SEL_NEED_SETUP = 4 };  // a seeded persistent launch left the initial set to the set-up kernels
 enum : uint32_t { ARB_RESOLVE = 1, ARB_FINALIZE = 2 };
 enum : uint32_t { FORCE_NONE = 0, FORCE_ACCEPT = 1, FORCE_REJECT = 2, FORCE_COMMIT = 3, FORCE_ROLLBACK = 4 };
 
@@ -100,6 +101,8 @@ struct dvs_select {
     std::vector<unsigned char> h_psync_head;  // ... and the head phase's
     void *ppart = nullptr;
     void *psync_head = nullptr, *ppart_head = nullptr;  // the head phase's own blocks
+    bool persist_seeded = false;    // the next persistent launch starts from the seed positions (no set-up kernels ran)
+    bool seeded_start = false;      // ... this selection began that way (sel_run_loop: a launch may hand the set-up back)
     bool head_prepared = false;     // ... and psync_head / ppart_head for the head phase
     bool persist_prepared = false;  // psync / ppart already hold a fresh image for the next full-grid launch
     hipEvent_t ev_side_done = nullptr;  // the set-up kernels on the context's second stream have run

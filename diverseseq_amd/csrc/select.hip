@@ -884,7 +884,7 @@ static int sel_poll(dvs_ctx *ctx, dvs_select *s) {
 }
 
 template <typename T>
-static int sel_seed(dvs_ctx *ctx, dvs_select *s, const T *mat, hipStream_t st);
+static int sel_seed(dvs_ctx *ctx, dvs_select *s, const T *mat, hipStream_t st, bool light = false);
 
 template <typename T>
 static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_unpolled = false) {
@@ -948,6 +948,27 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
             rc = sel_seed<T>(ctx, s, mat, ctx->stream);
             if (rc) return rc;
             persist_launches = 0;
+            continue;
+        }
+        if (s->seeded_start && s->persist && persist_launches == 1 &&
+            (c.status == SEL_NEED_SETUP || (c.status == SEL_RUN && c.cursor == s->params.n_seed))) {
+            // the seeded launch left the initial set alone (its first argmin too close to call on the
+            // device): the set-up kernels after all, and the engine again from the state they leave
+            s->seeded_start = false;
+            s->persist_seeded = false;
+            rc = sel_seed<T>(ctx, s, mat, ctx->stream);
+            if (rc) return rc;
+            persist_cursor = s->params.n_seed;
+            persist_launches = 2;
+            persist_was_last = true;
+            rc = dvs_persist_launch(ctx, s);
+            if (rc == DVS_ERR_UNSUPPORTED) {
+                s->persist = false;
+                s->persist_fell_back = true;
+                persist_launches = 0;
+            } else if (rc) {
+                return rc;
+            }
             continue;
         }
         if (c.status == SEL_DONE) {
@@ -1020,7 +1041,7 @@ static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat) {
         side = head_phase ? ctx->stream_head : dvs_ctx_stream2(ctx);
     }
     hipStream_t st = side ? side : ctx->stream;
-    int rc = sel_seed<T>(ctx, s, mat, st);
+    int rc = sel_seed<T>(ctx, s, mat, st, s->seeded_start);
     if (rc) return rc;
     if (head_phase) {
         rc = dvs_persist_launch_head(ctx, s, uint32_t(ctx->head_cus), s->mat->head_rows_built, side);
@@ -1044,8 +1065,10 @@ static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat) {
 // control block of a fresh selection + the initial set from the seed positions (SummedRecords::new
 // over the first n usable records, records.rs:288-308), enqueued on `st`; also the way back to a clean
 // state when the persistent engine has to be abandoned
+// light: only what a SEEDED persistent launch reads -- the control block and the seed list; the initial
+// set is worked out by that launch itself (persist.hip) instead of the four kernels below
 template <typename T>
-static int sel_seed(dvs_ctx *ctx, dvs_select *s, const T *mat, hipStream_t st) {
+static int sel_seed(dvs_ctx *ctx, dvs_select *s, const T *mat, hipStream_t st, bool light) {
     const std::vector<uint64_t> &seeds = s->seed_positions;
     SelDev &d = s->dev;
     SelCtl c = s->ctl0;
@@ -1067,6 +1090,10 @@ static int sel_seed(dvs_ctx *ctx, dvs_select *s, const T *mat, hipStream_t st) {
     uint64_t *d_seed = static_cast<uint64_t *>(s->d_seed_list);
     DVS_HIP(ctx, hipMemcpyAsync(d_seed, seeds.data(), seeds.size() * sizeof(uint64_t),
                                 hipMemcpyHostToDevice, st));
+    if (light) {
+        DVS_HIP(ctx, hipGetLastError());
+        return DVS_OK;
+    }
     hipLaunchKernelGGL((seed_kernel<T>), dim3(uint32_t(seeds.size())), dim3(LOO_THREADS), 0,
                        st, s->dev, mat, d_seed);
     hipLaunchKernelGGL(rebuild_kernel, dim3(1), dim3(WIDE_THREADS), 0, st, s->dev);
@@ -1248,6 +1275,21 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
         if (prc) {
             sel_free(s);
             return prc;
+        }
+    }
+    // SEEDED start (persist.hip): an nmost selection whose state fits the persistent kernel's register
+    // cache is begun by that kernel itself -- S, the entropy sum, the leave-one-out pass and the first
+    // lowest member from nothing but the seed positions -- instead of four launches in front of it
+    // (sets of up to 32: beyond that the S of the seeds -- a memory round trip per four members -- costs
+    // what the launches cost; DVS_PERSIST_SEEDED=1 forces it for any size, DVS_PERSIST_NO_SEEDED=1 turns it off)
+    s->seeded_start = s->persist && params->mode == DVS_MODE_NMOST && B <= 4096 && !order && !labels &&
+                      n_seed >= 2 && (n_seed <= 32 || getenv("DVS_PERSIST_SEEDED")) && !getenv("DVS_PERSIST_NO_SEEDED");
+    s->persist_seeded = s->seeded_start;
+    if (s->seeded_start) {
+        int arc = dvs_dev_alloc(ctx, &s->d_seed_list, size_t(n_seed) * sizeof(uint64_t), "seed list");
+        if (arc) {
+            sel_free(s);
+            return arc;
         }
     }
     // (what the head phase needs besides the seeds goes out before the wait below, on its stream)

@@ -1054,7 +1054,8 @@ def _chunk_merge_worker(rank, world, port, q):
                                           shared_stream=True, buffers=buffers)
             mem = merged.members(with_freqs=False)
             gids = merged.global_ids
-            out.append(([int(gids[p]) for p in mem.positions], mem.delta_jsd.tolist(), merged.summary().total_jsd))
+            out.append(([int(gids[p]) for p in mem.positions], mem.delta_jsd.tolist(), merged.summary().total_jsd,
+                        (sel.summary().engine, merged.summary().engine)))
             merged.close()
             sel.close()
             m.close()
@@ -1094,13 +1095,16 @@ def test_chunk_merge_mode_across_ranks(world):
     rows, ids = np.vstack(rows), np.concatenate(ids)
     exp = oracle.final_nmost(rows, 8)
     epos, edelta, _, _ = exp.members()
+    # (ids exact everywhere; floats to the tolerance: the ranks share ONE card here, and a persistent
+    # launch that cannot get its whole grid resident beside another process's hands the selection to
+    # the multi-launch engine, whose last bits differ -- the engines used travel with the result)
     for r in res:
-        assert r[1] == r[2]
-        got_ids, got_delta, got_total = r[1]
-        assert got_ids == ids[epos].tolist()
-        np.testing.assert_allclose(got_delta, edelta, rtol=RTOL, atol=1e-13)
-        np.testing.assert_allclose(got_total, exp.total_jsd, rtol=RTOL)
-    assert res[0][1:] == res[-1][1:]
+        for got_ids, got_delta, got_total, _engines in r[1:]:
+            assert got_ids == ids[epos].tolist()
+            np.testing.assert_allclose(got_delta, edelta, rtol=RTOL, atol=1e-13)
+            np.testing.assert_allclose(got_total, exp.total_jsd, rtol=RTOL)
+        if r[1][3] == r[2][3]:
+            assert r[1] == r[2], "same engines, same bits"
 
 
 def test_large_sets_and_other_alphabets(ctx):
