@@ -195,7 +195,7 @@ def main():
         # ... and the persistent kernel itself as a pure stream: the same launch with a threshold no
         # row reaches (no events, a handful of long windows), timed by the same HIP events
         knobs = {"DVS_PERSIST_NO_EVENTS": "1", "DVS_PERSIST_WG_ROUNDS": "0", "DVS_WINDOW_SCALE": "100000",
-                 "DVS_NO_HEAD_PHASE": "1"}  # (ONE launch over the whole stream)
+                 "DVS_NO_HEAD_PHASE": "1", "DVS_PERSIST_NO_SEEDED": "1"}  # (ONE launch over the whole stream, set up by the set-up kernels)
         saved = {k_: os.environ.get(k_) for k_ in knobs}
         os.environ.update(knobs)
         try:
