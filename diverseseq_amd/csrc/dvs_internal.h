@@ -53,6 +53,7 @@ struct dvs_ctx {
     int refs = 1;
     bool owner_gone = false;
     std::map<const void *, size_t> lds_raised;  // kernels whose dynamic-LDS limit was raised, and to what
+    std::map<std::pair<const void *, size_t>, bool> persist_fits;  // (kernel, LDS bytes) -> a 512-thread workgroup fits a CU
     // The offsets of the last histogram build, on both sides (kmer_hist.hip): a caller that builds
     // again over the same sequences -- same offsets, k, byte count, compared by content -- skips the
     // validation pass, the tile lists and their uploads (~0.1 ms of host time per 100k sequences,

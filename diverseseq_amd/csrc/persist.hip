@@ -1937,15 +1937,23 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     int rc = dvs_raise_dyn_lds(ctx, fn, lds);
     if (rc) return rc;
     {   // one 512-thread workgroup with this much LDS must fit a CU, or the grid can never be resident
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, P_THREADS, lds) != hipSuccess || per_cu < 1) {
-            (void)hipGetLastError();
-            return DVS_OK;
+        // (asked of the runtime once per kernel and LDS size: the answer does not change)
+        auto key = std::make_pair(fn, lds);
+        auto hit = ctx->persist_fits.find(key);
+        if (hit == ctx->persist_fits.end()) {
+            int per_cu = 0;
+            const bool fits = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, P_THREADS, lds) == hipSuccess && per_cu >= 1;
+            if (!fits) (void)hipGetLastError();
+            hit = ctx->persist_fits.emplace(key, fits).first;
         }
+        if (!hit->second) return DVS_OK;
     }
-    int coop = 0;
-    (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, ctx->device);
-    s->persist_coop = coop != 0 && getenv("DVS_PERSIST_COOP") != nullptr;
+    s->persist_coop = false;
+    if (getenv("DVS_PERSIST_COOP")) {
+        int coop = 0;
+        (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, ctx->device);
+        s->persist_coop = coop != 0;
+    }
     rc = dvs_dev_alloc(ctx, &s->psync, sizeof(PSync), "persistent sync block");
     if (!rc) rc = dvs_dev_alloc(ctx, &s->ppart, p_acc_bytes(s->persist_maxn), "leave-one-out accumulators");
     if (rc) return rc;
