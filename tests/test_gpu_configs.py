@@ -447,3 +447,26 @@ def test_head_phase_knobs_do_not_change_the_answer(env, monkeypatch):
     m.close()
     c.close()
     del keep
+
+
+def test_seeded_start_hands_a_tied_initial_set_back(ctx):
+    """The persistent kernel works the initial set out itself (no set-up launches) unless its first
+    argmin is too close to call: two identical seed rows tie exactly, the launch ends having changed
+    nothing, the set-up kernels and the arbiter take over -- one more persistent launch, the oracle's
+    answer.  Without the tie: a single launch."""
+    seqs = synth_seqs(3000, 300, seed=808, ragged=True)
+    ctx.set_timing(True)
+    try:
+        for tied in (False, True):
+            if tied:
+                seqs[1] = seqs[0].copy()
+            exp = oracle.nmost(seqs, 6, 5, 4)
+            m = ctx.build_matrix(seqs, 5, 4)
+            sel = m.nmost(6)
+            s = _assert_selection(sel, exp)
+            assert s.engine == 1
+            assert (s.scan_launches >= 2) == tied, (tied, s.scan_launches, s.n_arbitrated)
+            sel.close()
+            m.close()
+    finally:
+        ctx.set_timing(False)
