@@ -902,6 +902,12 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
             s->persist = false;
             s->persist_fell_back = true;
             persist_launches = 0;
+            if (s->seeded_start) {  // (nothing set the initial set up yet: the set-up kernels do)
+                s->seeded_start = false;
+                s->persist_seeded = false;
+                int src = sel_seed<T>(ctx, s, mat, ctx->stream);
+                if (src) return src;
+            }
         } else if (rc0) {
             return rc0;
         }
@@ -1046,6 +1052,12 @@ static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     if (head_phase) {
         rc = dvs_persist_launch_head(ctx, s, uint32_t(ctx->head_cus), s->mat->head_rows_built, side);
         if (rc && rc != DVS_ERR_UNSUPPORTED) return rc;  // (refused: the full-grid launch starts from the seeds)
+        if (rc == DVS_ERR_UNSUPPORTED && s->seeded_start) {  // ... which, unseeded, it needs the set-up kernels for
+            s->seeded_start = false;
+            s->persist_seeded = false;
+            rc = sel_seed<T>(ctx, s, mat, st);
+            if (rc) return rc;
+        }
         // the full-grid launch's sync block and accumulators: behind the histogram on the context's
         // stream, i.e. while the head phase runs, not between the two launches
         rc = dvs_persist_prepare_main(ctx, s);
