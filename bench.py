@@ -93,6 +93,7 @@ def main():
     from diverseseq_amd import engine
     from diverseseq_amd.parallel import merge_nmost, nmost_exact, shard_order
 
+    failed = False
     exact = a.mode == "exact"
     dist_on = world > 1 or force_dist
     stream = torch.cuda.Stream() if (exact or dist_on) else None
@@ -128,8 +129,9 @@ def main():
              "n_windows": 0, "n_arbitrated": 0, "hist_ms": 0.0, "engine": 0, "count_bytes": 4}
 
     exact_timing = {} if exact else None
+    last = {}  # members and statistics of the last timed step (checked against the oracle below)
 
-    def step(collect: bool):
+    def step(collect: bool, keep: bool = False):
         t0 = time.perf_counter()
         m = ctx.build_matrix_device(seqs.data_ptr(), offsets, a.k, 4)
         t1 = time.perf_counter()
@@ -150,6 +152,10 @@ def main():
             stats["hist_ms"] += (t1 - t0) * 1e3
             stats["engine"] = s.engine
             stats["count_bytes"] = m.count_bytes
+            if keep:
+                mem = sel.members(False)
+                last.update(positions=np.asarray(mem.positions).copy(), delta_jsd=np.asarray(mem.delta_jsd).copy(),
+                            total_jsd=s.total_jsd, n_accepts=s.n_accepts, size=s.size)
         sel.close()
         m.close()
 
@@ -159,8 +165,8 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
-            step(collect)
+        for i in range(a.steps):
+            step(collect, keep=collect and i == a.steps - 1)
         ctx.sync()
         torch.cuda.synchronize()
         if world > 1 or force_dist:
@@ -357,24 +363,47 @@ def main():
         if "dvs_module" in stats:
             out["config"]["through_dvs_module"] = stats["dvs_module"]
         # HBM traffic of the dominant kernel: measured separately with rocprofv3 PMC passes
-        # (bench.py cannot run under the profiler and time itself); committed in profiles/
+        # (bench.py cannot run under the profiler and time itself); committed in profiles/.
+        # The headline workload MUST find its profile: a missing or drifted file is an error, not a
+        # silently absent field.
+        wl = f"nmost n={a.n}, {a.nseq} x {a.length} bp, k={a.k}"
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+        headline = (a.n, a.nseq, a.length, a.k) == (10, 100_000, 5_000, 6) and world == 1 and not exact
         try:
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                              "pmc_traffic.json")))
-            if (pmc.get("workload") == f"nmost n={a.n}, {a.nseq} x {a.length} bp, k={a.k}"
-                    and stats["engine"] == 1):
+            pmc = json.load(open(pmc_path))
+            if pmc.get("workload") != wl:
+                raise KeyError(f"profile is for {pmc.get('workload')!r}, this run is {wl!r}")
+            if stats["engine"] == 1:
                 out["roofline"]["traffic"] = pmc["persist_nmost_kernel"]["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, KiB -> B)"
-        except (OSError, KeyError, ValueError):
-            pass
+        except (OSError, KeyError, ValueError) as e:
+            if headline:
+                raise SystemExit(f"bench.py: profiles/pmc_traffic.json does not serve the headline workload: {e}")
+            out["roofline"]["traffic_source"] = f"none: no PMC profile committed for this workload ({wl})"
         if world == 1 and not a.no_cpu_baseline:
             import oracle
 
             ns = min(a.cpu_sample, a.nseq)
             host = seqs[: ns * a.length].cpu().numpy()
             t0 = time.perf_counter()
-            oracle.nmost_concat(host, offsets[: ns + 1], a.n, a.k, 4)
+            oset, oacc = oracle.nmost_concat(host, offsets[: ns + 1], a.n, a.k, 4)
             dt = time.perf_counter() - t0
+            if ns == a.nseq and last:
+                # the oracle has just selected from the very sequences the timed steps used: the last
+                # timed step's members must be its members (ids and order bit-exact, floats within the
+                # north star's 1e-6 relative)
+                elab, edelta, _, _ = oset.members()
+                ok = (last["size"] == oset.size and last["positions"].tolist() == elab.tolist()
+                      and last["n_accepts"] == oacc
+                      and bool(np.allclose(last["delta_jsd"], edelta, rtol=1e-6, atol=1e-13))
+                      and abs(last["total_jsd"] - oset.total_jsd) <= 1e-6 * abs(oset.total_jsd))
+                out["verified_vs_oracle"] = ok
+                if not ok:
+                    out["verified_detail"] = {"got_ids": last["positions"].tolist(), "oracle_ids": elab.tolist(),
+                                              "got_accepts": last["n_accepts"], "oracle_accepts": int(oacc),
+                                              "got_total_jsd": last["total_jsd"], "oracle_total_jsd": oset.total_jsd}
+            else:
+                out["verified_vs_oracle"] = None  # (the CPU sample is not the whole workload)
             out["cpu_baseline"] = {
                 "value": ns / dt, "unit": "sequences/s", "cores": 1, "kind": "port",
                 "sample": (f"the first {ns} sequences of the same workload, 1 thread, C restatement of the "
@@ -394,8 +423,12 @@ def main():
                                         "sample_all_cores": "same sample, the reference's chunk + merge "
                                         "(-np cores), one worker thread per usable host core"})
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        if out.get("verified_vs_oracle") is False:
+            failed = True
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit("bench.py: the last timed step's selection differs from the oracle's")
 
 
 if __name__ == "__main__":

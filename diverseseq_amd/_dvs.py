@@ -312,16 +312,24 @@ def _check_k(k: int):
         raise ValueError("k cannot be 0")  # src/record.rs:126
 
 
+def _gather_and_build(store: ZarrStoreWrapper, seqids, n_min: int, k: int, num_states: int):
+    """ids, count matrix and labels of a selection's stream.  `data` may be a VIEW of the in-memory
+    store's arena: it is let go on every way out of here -- also when the checks or the build raise, since
+    a traceback would otherwise keep the frame's view alive and the store's next write fail (BufferError)."""
+    ids, data, offsets, labels = _gather(store, seqids)
+    try:
+        if len(ids) < n_min:
+            raise ValueError(f"The number of sequences {len(ids)} is < n {n_min}")
+        _check_k(k)
+        return ids, engine.default_context().build_matrix_concat(data, offsets, k, num_states), labels
+    finally:
+        data = None
+
+
 def nmost_divergent(store: ZarrStoreWrapper, n: int, k: int, num_states: int = 4,
                     seqids=None) -> SummedRecordsResult:
     """src/lib.rs:59-73 -> select_nmost_divergent (src/records.rs:311-342)"""
-    ids, data, offsets, labels = _gather(store, seqids)
-    if len(ids) < n:
-        raise ValueError(f"The number of sequences {len(ids)} is < n {n}")
-    _check_k(k)
-    ctx = engine.default_context()
-    m = ctx.build_matrix_concat(data, offsets, k, num_states)
-    del data  # (a view of the store's arena: released before anything else can write to the store)
+    ids, m, labels = _gather_and_build(store, seqids, n, k, num_states)
     try:
         sel = m.nmost(n, labels=labels)
         try:
@@ -335,13 +343,7 @@ def nmost_divergent(store: ZarrStoreWrapper, n: int, k: int, num_states: int = 4
 def max_divergent(store: ZarrStoreWrapper, min_size: int, max_size: int, k: int,
                   num_states: int = 4, seqids=None, stat: str = "stdev") -> SummedRecordsResult:
     """src/lib.rs:105-137 -> select_max_divergent (src/records.rs:390-454)"""
-    ids, data, offsets, labels = _gather(store, seqids)
-    if len(ids) < min_size:
-        raise ValueError(f"The number of sequences {len(ids)} is < n {min_size}")
-    _check_k(k)
-    ctx = engine.default_context()
-    m = ctx.build_matrix_concat(data, offsets, k, num_states)
-    del data
+    ids, m, labels = _gather_and_build(store, seqids, min_size, k, num_states)
     try:
         sel = m.max_divergent(min_size, max_size, stat, labels=labels)
         try:

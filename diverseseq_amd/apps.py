@@ -73,7 +73,12 @@ def _as_mapping(seqs, moltype: str):
         data = {s.name: np.array(s).tobytes() for s in degapped.seqs}
         return list(data), data, seqs.take_seqs
     data = {str(n): _encode(s, moltype) for n, s in dict(seqs).items()}
-    return list(data), data, lambda names: {n: seqs[n] for n in seqs if n in set(names)}
+
+    def take(names):  # (the store's names are str(n): compare on those, whatever the mapping's keys are)
+        sel = {str(n) for n in names}
+        return {n: seqs[n] for n in seqs if str(n) in sel}
+
+    return list(data), data, take
 
 
 def _populate_inmem_zstore(data: dict):

@@ -124,6 +124,7 @@ struct dvs_matrix {
     // way: a pinned block the copy lands in and the event recorded behind it
     uint32_t *h_head_pinned = nullptr;
     hipEvent_t ev_built = nullptr;
+    hipEvent_t ev_join = nullptr;  // split build: recorded behind the rest-of-matrix launch, waited for by the context's stream
     uint32_t head_count = 0;
     // rows [0, head_rows_built) were built by a launch of their own, finished when ev_built fires; the
     // rest of the matrix may still be in flight on the context's stream after that (0: no such split)

@@ -469,6 +469,8 @@ int dvs_matrix_settle(dvs_ctx *ctx, const dvs_matrix *cm) {
 void dvs_matrix_free_fields(dvs_matrix *m) {
     if (!m) return;
     (void)dvs_matrix_settle(m->ctx, m);  // the pinned block must not go back to the cache with a copy pending
+    if (m->ev_join) dvs_event_put(m->ctx, m->ev_join);
+    m->ev_join = nullptr;
     dvs_dev_free(m->ctx, m->d_counts);
     dvs_dev_free(m->ctx, m->d_counts16);
     m->d_counts16 = nullptr;
@@ -736,7 +738,9 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
                     } else {
                         m->rest_beside_head = true;
                     }
-                    if (ev_join) dvs_event_put(ctx, ev_join);
+                    // (kept with the matrix until it goes, for the reason ev_fork is kept below: the
+                    // context's stream may not have performed its wait yet when this call returns)
+                    m->ev_join = ev_join;
                 }
             }
             // (back to the pool only now: an event handed out again and re-recorded while the wait on

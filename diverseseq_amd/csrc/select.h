@@ -105,6 +105,7 @@ struct dvs_select {
     bool seeded_start = false;      // ... this selection began that way (sel_run_loop: a launch may hand the set-up back)
     bool head_prepared = false;     // ... and psync_head / ppart_head for the head phase
     bool persist_prepared = false;  // psync / ppart already hold a fresh image for the next full-grid launch
+    bool used_side_streams = false;   // work of this selection was queued on ctx->stream_head / stream2 (sel_free waits)
     hipEvent_t ev_side_done = nullptr;  // the set-up kernels on the context's second stream have run
     void *d_seed_list = nullptr;  // the seed positions on the device (kept until the selection goes: two streams read it)
     int batch = 16;

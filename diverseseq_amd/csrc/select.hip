@@ -823,6 +823,13 @@ __global__ __launch_bounds__(LOO_THREADS) void pack_event_kernel(SelDev d, const
 // ------------------------------------------------------------------ host side
 static void sel_free(dvs_select *s) {
     if (!s) return;
+    // Work this selection queued on the context's side streams (the head phase's sync block, the seed
+    // list, set-up kernels) may still be pending on an error path; the pool only orders reuse on the
+    // context's own stream, so those streams are drained before their blocks go back to it.
+    if (s->used_side_streams && s->ctx) {
+        if (s->ctx->stream_head) (void)hipStreamSynchronize(s->ctx->stream_head);
+        if (s->ctx->stream2) (void)hipStreamSynchronize(s->ctx->stream2);
+    }
     void *ptrs[] = {s->dev.ctl, s->dev.S, s->dev.Stmp, s->dev.base, s->dev.cand, s->dev.M,
                     s->dev.mH, s->dev.mDelta, s->dev.dtmp, s->dev.dsum, s->dev.mLabel, s->dev.mPos,
                     s->dev.ord, s->dev.inset, s->dev.wg_rows, s->dev.evlog_pos, s->dev.evlog_kind,
@@ -1047,6 +1054,7 @@ static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat) {
         side = head_phase ? ctx->stream_head : dvs_ctx_stream2(ctx);
     }
     hipStream_t st = side ? side : ctx->stream;
+    if (side) s->used_side_streams = true;
     int rc = sel_seed<T>(ctx, s, mat, st, s->seeded_start);
     if (rc) return rc;
     if (head_phase) {
@@ -1294,8 +1302,9 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     // lowest member from nothing but the seed positions -- instead of four launches in front of it
     // (sets of up to 32: beyond that the S of the seeds -- a memory round trip per four members -- costs
     // what the launches cost; DVS_PERSIST_SEEDED=1 forces it for any size, DVS_PERSIST_NO_SEEDED=1 turns it off)
+    // (a STEPWISE selection never launches the persistent kernel: its set-up kernels must run)
     s->seeded_start = s->persist && params->mode == DVS_MODE_NMOST && B <= 4096 && !order && !labels &&
-                      n_seed >= 2 && (n_seed <= 32 || getenv("DVS_PERSIST_SEEDED")) && !getenv("DVS_PERSIST_NO_SEEDED");
+                      !(s->params.flags & DVS_SELECT_STEPWISE) && n_seed >= 2 && (n_seed <= 32 || getenv("DVS_PERSIST_SEEDED")) && !getenv("DVS_PERSIST_NO_SEEDED");
     s->persist_seeded = s->seeded_start;
     if (s->seeded_start) {
         int arc = dvs_dev_alloc(ctx, &s->d_seed_list, size_t(n_seed) * sizeof(uint64_t), "seed list");
@@ -1307,6 +1316,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     // (what the head phase needs besides the seeds goes out before the wait below, on its stream)
     if (s->persist && m->rest_beside_head && ctx->stream_head && m->head_rows_built && params->mode == DVS_MODE_NMOST &&
         !order && !labels) {
+        s->used_side_streams = true;
         int prc = dvs_persist_prepare_head(ctx, s, m->head_rows_built, ctx->stream_head);
         if (prc) {
             sel_free(s);

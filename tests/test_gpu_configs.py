@@ -470,3 +470,74 @@ def test_seeded_start_hands_a_tied_initial_set_back(ctx):
             m.close()
     finally:
         ctx.set_timing(False)
+
+
+# ---------------------------------------------------------------- the bench's own path at the bench's own shape
+@pytest.fixture(scope="module")
+def north_star_device():
+    """100 000 x 5 000 bp generated in HBM (as bench.py does), 0.1 % invalid symbols, and the oracle's
+    selections of the same bytes (n = 10 and n = 100: ~10 s of CPU)."""
+    import torch
+
+    seqs, offs = synth_device(100_000, 5_000, 5_000, seed=20260421)
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(77)
+    bad = torch.randint(0, 100_000 * 5_000, (100_000 * 5_000 // 1000,), device="cuda:0", generator=g)
+    seqs[bad] = 4
+    torch.cuda.synchronize()
+    host = seqs[: 100_000 * 5_000].cpu().numpy()
+    exp = {n: oracle.nmost_concat(host, offs, n, 6, 4) for n in (10, 100)}
+    return seqs, offs, exp
+
+
+@pytest.mark.parametrize("env", [{}, {"DVS_NO_HEAD_PHASE": "1"}, {"DVS_PERSIST_NO_SEEDED": "1"},
+                                 {"DVS_PERSIST_NO_SMALL": "1"}])
+def test_the_timed_path_is_the_tested_path(north_star_device, env, monkeypatch):
+    """bench.py's path at bench.py's shape against the oracle (src/records.rs:311-342): device-resident
+    sequences -> build_matrix_device (not waited for, split in a head launch and the rest on the CU-masked
+    stream) -> nmost with the head phase on the head CUs, the seeded start and the full-grid launch --
+    ids, member order, frequency rows bit-exact, the floats within 1e-6, the accept count the oracle's,
+    no tie arbitration; the same with each of those stages switched off."""
+    from diverseseq_amd import engine
+
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    seqs, offs, exp = north_star_device
+    c = engine.Context(0)  # (the knobs are read when the context / selection is made)
+    c.set_timing(True)
+    try:
+        for n in (10, 100):
+            oset, oacc = exp[n]
+            for rep in range(2):  # the second build takes the offsets from the context's cache, as bench.py's steps do
+                m = c.build_matrix_device(seqs.data_ptr(), offs, 6, 4)
+                assert m.count_bytes == 2
+                sel = m.nmost(n)
+                s = _assert_selection(sel, oset)
+                assert s.engine == 1 and s.n_arbitrated == 0
+                assert s.n_accepts == oacc
+                if n == 10:
+                    assert s.scan_launches == (1 if "DVS_NO_HEAD_PHASE" in env else 2), s.scan_launches
+                sel.close()
+                m.close()
+    finally:
+        c.close()
+
+
+def test_stepwise_selection_without_an_order_array(ctx):
+    """dvs_select_step_pack / _apply driven at world 1 on a selection started with order=None and
+    SELECT_STEPWISE (the public C API allows it): the set-up kernels must have run -- a seeded 'light'
+    start would leave the step kernels on uninitialised state (round-2 advisor finding) -- and the answer
+    is the oracle's (src/records.rs:311-342)."""
+    import torch
+
+    from diverseseq_amd import _lib
+    from diverseseq_amd.parallel import HipStepper, drive_exact
+
+    seqs = synth_seqs(1200, 500, 31, invalid_frac=0.001, ragged=True)
+    exp = oracle.nmost(seqs, 9, 5, 4)
+    m = ctx.build_matrix(seqs, 5, 4)
+    sel = m.select(_lib.MODE_NMOST, 9, window=4096, flags=_lib.SELECT_STEPWISE)
+    drive_exact(HipStepper(ctx, sel, m.nbins, torch.device("cuda:0")), 1, torch.device("cuda:0"))
+    _assert_selection(sel, exp)
+    sel.close()
+    m.close()
