@@ -53,6 +53,11 @@ constexpr int P_CH = 16;                    // row chunks requested per burst (4
 constexpr uint32_t P_MAXN = 512;            // members the LDS replica holds when 4^k <= 4096 ...
 constexpr uint32_t P_MAXN_BIG = 256;        // ... and beyond (k = 7: 128 KB of LDS go to the set state)
 constexpr uint32_t p_maxn(bool cached) { return cached ? P_MAXN : P_MAXN_BIG; }
+// SMALL sets (nmost over 16-bit count rows of 4096 bins): the members' count rows live in every
+// workgroup's LDS, so the leave-one-out pass of an accept needs no other workgroup (see the kernel)
+constexpr uint32_t P_SMALLN = 16;      // members the replica arrays of a SMALL launch hold ...
+constexpr uint32_t P_SMALL_ROWS = 13;  // ... and rows (8 KB each) that fit beside the state in 160 KB of LDS
+constexpr uint32_t P_SMALL_LOO = P_SMALLN * 16 + 16;  // doubles of scratch for the local leave-one-out passes
 // leave-one-out jobs per event: (n + 1) * K <= max(G - 1, n + 1) <= maxn + 1 (G <= maxn + 2 is checked)
 constexpr uint32_t p_maxjobs(bool cached) { return p_maxn(cached) + 1; }
 // leave-one-out accumulators: 3 slots (accept % 3) x 8 group replicas x (maxn + 1) members x 2 words
@@ -86,7 +91,8 @@ struct PSync {
     uint32_t stop_at;    // head phase: leave at this stream position with status RUN (0: walk the whole stream)
     uint32_t seeded;     // the set is still only its seed positions: the launch works the initial state out itself
     const unsigned long long *seed_list;  // ... those positions (ctl->size of them)
-    uint32_t pad2[56];
+    uint32_t small_rows;  // SMALL instantiation: member rows the LDS replica has room for
+    uint32_t pad2[55];
     // event words, slot = epoch % 3, one copy per group g = blockIdx % 8 (a wave polls before every
     // row: one word for the whole grid serialises those loads at the memory side): ev[s][32 g] = first
     // event position, ev[s][32 g + 16] = the same position when the event is sure
@@ -658,6 +664,61 @@ __device__ __forceinline__ void p_argmin(const double *s_dl, const double *s_ds,
     }
 }
 
+// ---- SMALL sets: the leave-one-out pass of an accept inside every workgroup, all f32.
+// Member r's leave-one-out mean vector is u_i = (S'_i - f_ri) / (n - 1) (updated_mean_freqs,
+// records.rs:276-286); here y_i = S'_i / (n - 1) - c_ri * rho_r with S'_i / (n - 1) and
+// rho_r = 1 / (T_r (n - 1)) rounded to f32 and one fma, v_log_f32 on y, the products folded in f32 four
+// at a time (coarse4's scheme).  With e = 2^-24, w = n / (n - 1) = sum_i S'_i / (n - 1) and
+// lb = log2 B >= H, the sum of y log2 y differs from the reference's sum of u log2 u by at most
+//   3 e w (23.42 + lb)   inputs: |y - u| <= d_i = 3 e S'_i / (n - 1) (the two roundings and the fma; member r
+//                        is part of S', so c rho <= the first term), and |g(a) - g(b)| <= g(|a - b|) for
+//                        g(x) = -x log2 x (the lemma behind Fannes' inequality), g(d_i) = d_i (22.42 +
+//                        |log2(S'_i / (n - 1))|), sum_i S'_i / (n - 1) |log2 ..| <= w (1 + lb); the clamp
+//                        u <= eps -> 0 of the reference moves a bin by <= 2.3e-16
+// + 2 k e (lb + 1)       v_log_f32, k <= 1.5 ulp (dvs_selftest_log2_f32, every f32 in [2^-101, 2))
+// + e lb + 9 e lb        the f32 product, and nine levels of f32 addition between a product and its wave's
+//                        total (three inside the thread, six across the lanes); the eight waves' totals
+//                        are added in f64
+// = e (3 w (23.42 + lb) + 13 lb + 3); p_loo_band adds a quarter on top (2.1e-5 at 4^6 bins, n = 10).
+// The argmin is taken from these sums only when the two smallest delta_jsd are more than two bands (+ the
+// reference's own noise band) apart -- ~13 in 14 accepts at n = 10 on random 5 kb sequences; otherwise the
+// exact f64 pass over the grid decides as before.  A bin y <= 0 (cancellation noise where member r is
+// the bin's only contributor) counts as 1e-30: its true contribution is below 1e-10 either way.
+__device__ __forceinline__ double p_loo_band(uint64_t B, double dn) {
+    const double w = dn / (dn - 1.0), lb = log2(double(B));
+    return 1.25 * 0x1p-24 * (3.0 * w * (23.42 + lb) + 13.0 * lb + 3.0);
+}
+// f32 sum over the wave by DPP, the total in lane 63 (fixed order: the same bits in every workgroup):
+// four butterfly steps inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 add the rows up
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float p_dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ float p_wave_sum_f32_lane63(float v) {
+    v += p_dpp_f32<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v += p_dpp_f32<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v += p_dpp_f32<0x141, 0xF>(v);  // row_half_mirror
+    v += p_dpp_f32<0x140, 0xF>(v);  // row_mirror: every lane holds the sum of its row
+    v += p_dpp_f32<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v += p_dpp_f32<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ float p_loo4(const uint2 c, float b0, float b1, float b2, float b3, const dvs_f2 nrho2) {
+    const dvs_f2 c01 = {float(c.x & 0xFFFFu), float(c.x >> 16)}, c23 = {float(c.y & 0xFFFFu), float(c.y >> 16)};
+    const dvs_f2 tiny = {1e-30f, 1e-30f};
+    const dvs_f2 y01 = __builtin_elementwise_max(__builtin_elementwise_fma(c01, nrho2, (dvs_f2){b0, b1}), tiny);
+    const dvs_f2 y23 = __builtin_elementwise_max(__builtin_elementwise_fma(c23, nrho2, (dvs_f2){b2, b3}), tiny);
+    const dvs_f2 l01 = {__builtin_amdgcn_logf(y01.x), __builtin_amdgcn_logf(y01.y)};
+    const dvs_f2 l23 = {__builtin_amdgcn_logf(y23.x), __builtin_amdgcn_logf(y23.y)};
+    const dvs_f2 s = y01 * l01 + y23 * l23;
+    return s.x + s.y;
+}
+// a thread's eight bins of one member (packed 16-bit counts q, bins j = 0..7 of the thread) -> sum y log2 y
+__device__ __forceinline__ float p_loo8(const uint4 q, const float (&sf)[8], const dvs_f2 nrho2) {
+    return p_loo4(make_uint2(q.x, q.y), sf[0], sf[1], sf[2], sf[3], nrho2) +
+           p_loo4(make_uint2(q.z, q.w), sf[4], sf[5], sf[6], sf[7], nrho2);
+}
+
 // LDS: [sl B f64][scratch 128 f64][s_mH, s_tot, s_rt, s_dl, s_ds maxn f64][s_pos maxn u64]
 //      [s_slot maxn u32][s_soft P_SOFT u64][flags]
 // maxn = p_maxn(CACHED): compile-time offsets (runtime ones cost registers the scan loop needs),
@@ -670,10 +731,20 @@ __device__ __forceinline__ void p_argmin(const double *s_dl, const double *s_ds,
 // rose; a rollback leaves every replica untouched.  At max_size the stream continues as above
 // (replace_lowest).  The summed vector S lives in LDS beside sl.  Anything too close to call ends
 // the launch with the event unconsumed; the multi-launch kernels (and the arbiter) take it.
-template <typename T, bool CACHED, bool MAXM = false>
+// SMALL: nmost over 16-bit count rows of exactly 4096 bins with a set of <= P_SMALL_ROWS members.  The
+// members' count rows (8 KB each) sit in every workgroup's LDS, thread-major (thread t's bins
+// j * 512 + t, j < 8, are the 16 bytes at t * 16: no thread ever reads another's part), so after an
+// accept EVERY workgroup works out the new lowest member on its own -- H(S'/n) in f64 and the
+// leave-one-out sums of all members in f32 (p_loo8) -- instead of spreading (n + 1) K f64 jobs over the
+// grid and waiting for their totals, and rebuilds sl from its LDS instead of fetching the new lowest
+// member's row: one grid-wide hop and two memory round trips less per accept.  The members' exact
+// delta_jsd are brought up to date by the mirror block when the launch ends (they are results, not inputs
+// of any decision in this mode).
+template <typename T, bool CACHED, bool MAXM = false, bool SMALL = false>
 __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, const T *__restrict__ mat,
                                                                     PSync *sync, unsigned long long *part, uint32_t G) {
-    constexpr uint32_t maxn = p_maxn(CACHED);
+    static_assert(!SMALL || (CACHED && !MAXM && sizeof(T) == 2), "SMALL: nmost, 16-bit rows, state in the register cache");
+    constexpr uint32_t maxn = SMALL ? P_SMALLN : p_maxn(CACHED);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint64_t B0 = d.B;
     const uint64_t B = B0;  // (the event loop below takes its own, laundered copy)
@@ -695,6 +766,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     int *s_flag = reinterpret_cast<int *>(s_soft + P_SOFT);
     static_assert(maxn % 4 == 0 && P_SOFT % 2 == 0, "s_ltab below must sit on a 16-byte boundary");
     double2 *s_ltab = reinterpret_cast<double2 *>(s_soft + P_SOFT + 2);  // log2_tab's 128 entries
+    [[maybe_unused]] double *s_loo = reinterpret_cast<double *>(s_ltab + 128);  // SMALL: partial sums of the local leave-one-out pass
+    [[maybe_unused]] uint16_t *s_rows = reinterpret_cast<uint16_t *>(s_loo + P_SMALL_LOO);  // SMALL: member count rows by slot
     if (threadIdx.x < 128) log2_tab_fill(s_ltab, threadIdx.x);
     SelCtl *ctl = d.ctl;
     const int tid0 = threadIdx.x;
@@ -979,6 +1052,29 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     }
     }
 
+    // SMALL: the members' count rows into LDS, thread-major (see above).  A slot the replica has no room
+    // for (never: an nmost set occupies slots 0 .. n - 1) leaves the launch with the state untouched;
+    // the host then carries on with the multi-launch kernels.
+    [[maybe_unused]] bool delta_stale = false;  // the mirrored delta_jsd of the members are older than the set
+    [[maybe_unused]] uint32_t n_local = 0;      // accepts whose lowest member was worked out inside the workgroup
+    if constexpr (SMALL) {
+        const uint32_t rows_cap = sync->small_rows;
+        bool fits = B == 4096 && st.n <= rows_cap;
+        for (uint32_t r = 0; r < st.n; r++) fits = fits && s_slot[r] < rows_cap;
+        if (!fits) return;
+        for (uint32_t r = 0; r < st.n; r++) {
+            const T *mrow = mat + s_pos[r] * B;
+            T cv[P_J];
+#pragma unroll
+            for (int j = 0; j < P_J; j++) cv[j] = mrow[uint64_t(j) * P_THREADS + tid];
+            uint4 q;
+            q.x = uint32_t(cv[0]) | (uint32_t(cv[1]) << 16);
+            q.y = uint32_t(cv[2]) | (uint32_t(cv[3]) << 16);
+            q.z = uint32_t(cv[4]) | (uint32_t(cv[5]) << 16);
+            q.w = uint32_t(cv[6]) | (uint32_t(cv[7]) << 16);
+            *reinterpret_cast<uint4 *>(s_rows + uint64_t(s_slot[r]) * 4096 + uint32_t(tid) * 8) = q;
+        }
+    }
     if (sync->no_coarse & 2u) st.thr = 1e300;  // measurement aid: no row is ever an event (pure streaming)
 #ifdef DVS_PERSIST_STAMPS  // per-phase in-kernel timing (DVS_PERSIST_DEBUG prints it): costs registers
     unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
@@ -990,8 +1086,18 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             t_prev = t_now;                                                \
         }                                                                  \
     } while (0)
+// (block 0 only, slots 9..15 of its array: the SMALL accept path in detail)
+#define P_STAMP2(k)                                                        \
+    do {                                                                   \
+        if (blockIdx.x == 0 && !lead && tid == 0) {                        \
+            const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); \
+            sync->dbg2[k] += t_now - t_prev;                               \
+            t_prev = t_now;                                                \
+        }                                                                  \
+    } while (0)
 #else
 #define P_STAMP(k) do { } while (0)
+#define P_STAMP2(k) do { } while (0)
 #endif
     for (;;) {
         // The loop body's view of the bin count and the thread index goes through an empty asm:
@@ -1035,6 +1141,24 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                                        nrows, lane, nread, nprecise, nmid, coarse_on,
                                        (sync->no_coarse & 8u) == 0);
         }
+        // SMALL: the counts of the candidate this window will most likely end with -- the event word as it
+        // stands when this workgroup leaves the scan -- are requested BEFORE the rendezvous, so that the
+        // row's memory round trip runs beside the barrier instead of behind it (an earlier event posted
+        // later only means the row is fetched again below).
+        [[maybe_unused]] T craw[P_J];
+        [[maybe_unused]] uint64_t craw_pos = SEL_NONE;  // the position whose counts craw holds
+        [[maybe_unused]] auto fetch_raw = [&](uint64_t q) {
+            if (craw_pos != q) {
+                const T *gp = mat + q * B;
+#pragma unroll
+                for (int j = 0; j < P_J; j++) craw[j] = gp[uint64_t(j) * P_THREADS + tid];
+                craw_pos = q;
+            }
+        };
+        if constexpr (SMALL) {
+            const uint64_t guess = __hip_atomic_load(evp, RLX_AGENT);
+            if (guess != SEL_NONE) fetch_raw(guess);
+        }
         P_STAMP(0);
         if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
         P_STAMP(1);
@@ -1057,7 +1181,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         const uint32_t job_r = one_job ? blockIdx.x / K : 0u, job_part = one_job ? blockIdx.x % K : 0u;
         T mc[P_J];
         double job_tot = 1.0, job_rt = 1.0;
-        if (CACHED && one_job && has_job && job_r + 1 < st.n) {
+        if (CACHED && !SMALL && one_job && has_job && job_r + 1 < st.n) {
             const uint32_t old = job_r < st.li ? job_r : job_r + 1;
             const T *mrow = mat + s_pos[old] * B;
             job_tot = s_tot[old];
@@ -1083,13 +1207,16 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             rtot = 1.0 / tot;
             cand_H = d.rowH[q];
             rp = mat + q * B;
+            if constexpr (SMALL) fetch_raw(q);
             Ent e;
             for (uint64_t b0 = 0; b0 < B; b0 += uint64_t(P_J) * P_THREADS) {
 #pragma unroll
                 for (int j = 0; j < P_J; j++) {
                     const uint64_t i = b0 + uint64_t(j) * P_THREADS + tid;
                     if (i < B) {
-                        const double f = cand_freq_x(rp, i, tot, rtot);
+                        double f;
+                        if constexpr (SMALL) f = count_freq_x(craw[j], tot, rtot);
+                        else f = cand_freq_x(rp, i, tot, rtot);
                         if (CACHED) fr[j] = f;
                         e.add((sl[i] + f) * rn, s_ltab);
                     }
@@ -1151,7 +1278,11 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 cand_H = d.rowH[p];
                 rp = mat + p * B;
                 rtot = 1.0 / tot;
-                if (CACHED) {
+                if constexpr (SMALL) {
+                    fetch_raw(p);
+#pragma unroll
+                    for (int j = 0; j < P_J; j++) fr[j] = count_freq_x(craw[j], tot, rtot);
+                } else if (CACHED) {
 #pragma unroll
                     for (int j = 0; j < P_J; j++) {
                         const uint64_t i = uint64_t(j) * P_THREADS + tid;
@@ -1382,8 +1513,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             }
         }
         // ================= replace_lowest (records.rs:94-147) + leave-one-out
-        const uint32_t acc_slot = st.n_loo % 3;
-        st.n_loo++;
+        const uint32_t acc_slot = st.n_loo % 3;  // (taken only when the grid-wide pass below runs)
         st.n_accepts++;
         const uint32_t n = st.n, li = st.li;
         const uint32_t slot_low = s_slot[li];
@@ -1459,6 +1589,101 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         }
         __syncthreads();
         st.sumH = sh;
+        // ================= SMALL: the whole leave-one-out pass inside the workgroup (see the kernel's header)
+        bool local_done = false;
+        [[maybe_unused]] double l_tj = 0.0, l_min = 0.0, l_sec = 0.0;
+        [[maybe_unused]] uint32_t l_low = 0;
+        if constexpr (SMALL) {
+            const double rdiv_l = 1.0 / (dn - 1.0);
+            float sf[P_J];
+            Ent e;
+#pragma unroll
+            for (int j = 0; j < P_J; j++) {
+                double v = sl[uint64_t(j) * P_THREADS + tid];
+                if (v <= DVS_EPS) v = 0.0;           // drop_lowest's clamp (records.rs:105-107)
+                const double sn = v + fr[j];         // S' (push, records.rs:135-137)
+                e.add(sn * rn, s_ltab);              // H(S'/n), f64: the new total_jsd
+                sf[j] = float(sn * rdiv_l);
+            }
+            {   // the candidate's counts take the slot of the member it replaces
+                uint4 q;
+                q.x = uint32_t(craw[0]) | (uint32_t(craw[1]) << 16);
+                q.y = uint32_t(craw[2]) | (uint32_t(craw[3]) << 16);
+                q.z = uint32_t(craw[4]) | (uint32_t(craw[5]) << 16);
+                q.w = uint32_t(craw[6]) | (uint32_t(craw[7]) << 16);
+                *reinterpret_cast<uint4 *>(s_rows + uint64_t(slot_low) * 4096 + uint32_t(tid) * 8) = q;
+            }
+            P_STAMP2(9);
+            // members in the NEW order (the candidate is member n - 1); unrolled over the rows the replica
+            // can hold, so that the rows' LDS reads run ahead of the arithmetic and a thread's partial sums
+            // stay in registers until the wave adds them up
+            float part_f[P_SMALL_ROWS];
+#pragma unroll
+            for (uint32_t r = 0; r < P_SMALL_ROWS; r++) {
+                part_f[r] = 0.0f;
+                if (r < n) {
+                    const float nrho = -float(s_rt[r] * rdiv_l);
+                    const uint4 q = *reinterpret_cast<const uint4 *>(s_rows + uint64_t(s_slot[r]) * 4096 + uint32_t(tid) * 8);
+                    part_f[r] = p_loo8(q, sf, (dvs_f2){nrho, nrho});
+                }
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < P_SMALL_ROWS; r++) {
+                if (r < n) {
+                    const float a = p_wave_sum_f32_lane63(part_f[r]);
+                    if (lane == 63) s_loo[r * 8 + wave] = double(a);
+                }
+            }
+            {
+                const double hw = dvs_wave_sum_dpp(e.h), sw = dvs_wave_sum_dpp(e.sum);
+                if (lane == 0) {
+                    s_loo[P_SMALLN * 16 + wave] = hw;
+                    s_loo[P_SMALLN * 16 + 8 + wave] = sw;
+                }
+            }
+            P_STAMP2(10);
+            __syncthreads();
+            if (wave == 0) {
+                double hm = 0.0, svn = 0.0, hr = 0.0;
+#pragma unroll
+                for (int w = 0; w < 8; w++) {
+                    hm += s_loo[P_SMALLN * 16 + w];
+                    svn += s_loo[P_SMALLN * 16 + 8 + w];
+                    if (lane < n) hr += s_loo[lane * 8 + w];
+                }
+                const double tj = hm - sh / dn;
+                const bool mem = lane < n;
+                // delta_jsd_r = total_jsd - (H(mean_r) - (sumH - H_r) / (n - 1)); H(mean_r) = -sum y log2 y
+                const double dl = mem ? tj - (-hr - (sh - s_mH[lane]) * rdiv_l) : 1e6;
+                const double mn = dvs_wave_min(dl);
+                const unsigned long long at = __ballot(mem && dl == mn && mn < 1e6);
+                const uint32_t lw = at ? uint32_t(__builtin_ctzll(at)) : 0u;
+                const double sec = dvs_wave_min((mem && lane != lw) ? dl : 1e6);
+                // the members' sum-to-one guards (sum_risky on each leave-one-out mean vector): every
+                // count row sums to 1 within 2e-16 (correctly rounded quotients of one total), so
+                // sum_i u_i = (sum_i S'_i - 1) / (n - 1) up to a few eps -- checked from the f64 sum of
+                // S'/n at an eighth of the reference's tolerance instead of per bin
+                const bool guard = sum_risky(svn, B) || !(hm == hm) ||
+                                   !(fabs((svn * dn - 1.0) * rdiv_l - 1.0) <= 0.125 * double(B) * DVS_EPS);
+                if (lane == 0) {
+                    scratch[100] = mn;
+                    scratch[101] = double(lw);
+                    scratch[102] = sec;
+                    scratch[103] = tj;
+                    scratch[104] = guard ? 1.0 : 0.0;
+                }
+            }
+            __syncthreads();
+            l_min = scratch[100];
+            l_low = uint32_t(scratch[101]);
+            l_sec = scratch[102];
+            l_tj = scratch[103];
+            const double need = 2.0 * p_loo_band(B, dn) + sel_band(l_tj + sh / dn, B);
+            local_done = scratch[104] == 0.0 && (sync->no_coarse & 16u) == 0 && l_min < 1e6 && l_sec - l_min > need;
+            __syncthreads();  // scratch[100..] is rewritten by the grid-wide pass below
+            P_STAMP2(11);
+        }
+        if (!local_done) st.n_loo++;
         // S_new_i = clamp(S_i - low_i) + f_i.  The mirror block writes it, and the new member's
         // row, to global memory (it takes no job below, so this overlaps the others' arithmetic).
         if (lead) {
@@ -1487,10 +1712,12 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             // accepts ago) before it arrived at this window's first barrier
             // (all eight group replicas; the stores are acknowledged before this block's next
             // barrier arrival, and nobody adds to that slot before that barrier has completed)
-            unsigned long long *nx = part + uint64_t((acc_slot + 1) % 3) * 8 * (maxn + 1) * 2;
-            for (uint32_t i = tid; i < 8u * (n + 1) * 2u; i += P_THREADS) {
-                const uint32_t g = i / ((n + 1) * 2u), w = i % ((n + 1) * 2u);
-                __hip_atomic_store(nx + (uint64_t(g) * (maxn + 1)) * 2 + w, 0ull, RLX_AGENT);
+            if (!local_done) {
+                unsigned long long *nx = part + uint64_t((acc_slot + 1) % 3) * 8 * (maxn + 1) * 2;
+                for (uint32_t i = tid; i < 8u * (n + 1) * 2u; i += P_THREADS) {
+                    const uint32_t g = i / ((n + 1) * 2u), w = i % ((n + 1) * 2u);
+                    __hip_atomic_store(nx + (uint64_t(g) * (maxn + 1)) * 2 + w, 0ull, RLX_AGENT);
+                }
             }
         }
         // ================= leave-one-out (get_lowest_record_index, records.rs:220-252, with
@@ -1504,11 +1731,11 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         unsigned long long *acc_all = part + uint64_t(acc_slot) * 8 * (maxn + 1) * 2;          // the slot's replicas
         const unsigned long long *acc = acc_all + uint64_t(blockIdx.x & 7u) * (maxn + 1) * 2;  // this group's
         bool first_job = true;
-        for (uint32_t job = blockIdx.x; job < jobs && has_job; job += G) {
+        for (uint32_t job = blockIdx.x; job < jobs && has_job && !local_done; job += G) {
             if (lead && one_job) break;
             const uint32_t r = job / K, part_i = job % K;
             const bool is_new = r == n - 1;
-            const bool pre = CACHED && one_job;  // member counts already requested above
+            const bool pre = CACHED && !SMALL && one_job;  // member counts already requested above
             const uint64_t mp = r < n ? s_pos[r] : 0;
             const T *mrow = mat + mp * B;
             const double mtot = pre ? job_tot : (r < n ? s_tot[r] : 1.0);
@@ -1603,7 +1830,17 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         uint32_t lowest;
         double dmin, dsecond;
         bool any_risky, ev_risky;
-        if (n < 128) {
+        if (local_done) {
+            lowest = l_low;
+            dmin = l_min;
+            dsecond = l_sec;
+            st.total_jsd = l_tj;
+            any_risky = ev_risky = false;
+            delta_stale = true;  // (the mirror block refreshes the members' delta_jsd when the launch ends)
+            n_local++;
+            if (lead && tid == 0) ctl->total_jsd = l_tj;
+        } else if (n < 128) {
+            delta_stale = false;
             // No barrier: one wave polls this group's replica (lane l holds members l and l + 64, entry
             // n is the whole set) until every word carries K contributions, takes the decisions and
             // hands them to the other waves through LDS.  Bounded like every other spin of the kernel.
@@ -1757,6 +1994,13 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 // every count of the block is requested before the first is used: 2 P_J loads in
                 // flight per thread instead of one memory round trip per bin (k = 7: 32 bins a thread)
                 T cv[P_J], lv[P_J];
+                if constexpr (SMALL) {  // the new lowest member's counts: this thread's 16 bytes of its LDS row
+                    const uint4 q = *reinterpret_cast<const uint4 *>(s_rows + uint64_t(s_slot[lowest]) * 4096 + uint32_t(tid) * 8);
+                    lv[0] = T(q.x & 0xFFFFu); lv[1] = T(q.x >> 16);
+                    lv[2] = T(q.y & 0xFFFFu); lv[3] = T(q.y >> 16);
+                    lv[4] = T(q.z & 0xFFFFu); lv[5] = T(q.z >> 16);
+                    lv[6] = T(q.w & 0xFFFFu); lv[7] = T(q.w >> 16);
+                } else {
 #pragma unroll
                 for (int j = 0; j < P_J; j++) {
                     const uint64_t i = b0 + uint64_t(j) * P_THREADS + tid;
@@ -1764,6 +2008,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                         if (!CACHED) cv[j] = rp[i];
                         if (!low_is_new) lv[j] = lrow[i];
                     }
+                }
                 }
 #ifdef DVS_PERSIST_STAMPS
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1800,6 +2045,68 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         epoch++;
     }
 
+    // ---- SMALL: the members' delta_jsd as get_lowest_record_index leaves them (records.rs:220-252), in
+    // f64, by the mirror block alone from its LDS rows and the S it mirrored -- once per launch instead
+    // of once per accept.  Its argmin must be the member the f32 passes chose (their bands prove it): a
+    // disagreement, or a sum check that is not sure, ends the launch as a failed one and the selection
+    // starts over on the multi-launch engine.
+    if constexpr (SMALL) {
+        if (lead && delta_stale && exit_status != SEL_ERROR) {
+            const uint32_t n = st.n;
+            const double rdiv_x = 1.0 / (double(n) - 1.0);
+            double Sx[P_J];
+#pragma unroll
+            for (int j = 0; j < P_J; j++)  // (this workgroup's own stores of this launch, read past its L1)
+                Sx[j] = __longlong_as_double((long long)__hip_atomic_load(
+                    reinterpret_cast<unsigned long long *>(d.S) + uint64_t(j) * P_THREADS + tid, RLX_AGENT));
+            __syncthreads();
+            for (uint32_t r = 0; r < n; r++) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(s_rows + uint64_t(s_slot[r]) * 4096 + uint32_t(tid) * 8);
+                const uint32_t cw[4] = {q.x, q.y, q.z, q.w};
+                const double mt = s_tot[r], mr = s_rt[r];
+                double h = 0.0, sv = 0.0;
+#pragma unroll
+                for (int j = 0; j < P_J; j++) {
+                    const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                    double u = (Sx[j] - exact_div_u32(double(c), mt, mr)) * rdiv_x;  // updated_mean_freqs, records.rs:276-286
+                    if (u <= DVS_EPS) u = 0.0;
+                    if (u > 0.0) h -= u * log2_tab(u, s_ltab);
+                    sv += u;
+                }
+                h = dvs_wave_sum_dpp(h);
+                sv = dvs_wave_sum_dpp(sv);
+                if (lane == 0) {
+                    s_loo[r * 8 + wave] = h;
+                    s_loo[P_SMALLN * 8 + r * 8 + wave] = sv;
+                }
+            }
+            __syncthreads();
+            if (uint32_t(tid) < n) {
+                double h = 0.0, sv = 0.0;
+                for (int w = 0; w < 8; w++) {
+                    h += s_loo[tid * 8 + w];
+                    sv += s_loo[P_SMALLN * 8 + tid * 8 + w];
+                }
+                s_dl[tid] = st.total_jsd - (h - (st.sumH - s_mH[tid]) * rdiv_x);  // delta_jsd
+                s_ds[tid] = sv;
+            }
+            __syncthreads();
+            if (wave == 0) p_argmin<1>(s_dl, s_ds, n, B, lane, scratch);
+            __syncthreads();
+            if (uint32_t(scratch[101]) != st.li || scratch[105] != 0.0) exit_status = SEL_ERROR;
+            if (uint32_t(tid) < n) {
+                d.dtmp[tid] = s_dl[tid];
+                d.dsum[tid] = s_ds[tid];
+                d.mDelta[tid] = s_dl[tid];
+            }
+            if (tid == 0) {
+                ctl->mean_delta = scratch[103];
+                ctl->std_delta = scratch[104];
+                ctl->cov_delta = scratch[104] / scratch[103];
+            }
+        }
+        if (lead && tid == 0) ctl->n_local_loo += n_local;
+    }
     // ---- exit: counters, and the lead block's scalar mirror
     if (lane == 0 && nread) {
         atomicAdd(&ctl->rows_scored, (unsigned long long)nread);
@@ -1825,6 +2132,18 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
 
 }  // namespace
 
+// the instantiation that serves a selection (dvs_persist_setup decided maxm / cached / small)
+template <typename T>
+static const void *persist_fn(const dvs_select *s) {
+    const bool cached = s->dev.B <= uint64_t(P_J) * P_THREADS;
+    if (s->params.mode == DVS_MODE_MAX) return reinterpret_cast<const void *>(persist_nmost_kernel<T, true, true>);
+    if constexpr (std::is_same_v<T, uint16_t>) {
+        if (s->persist_small) return reinterpret_cast<const void *>(persist_nmost_kernel<T, true, false, true>);
+    }
+    return cached ? reinterpret_cast<const void *>(persist_nmost_kernel<T, true>)
+                  : reinterpret_cast<const void *>(persist_nmost_kernel<T, false>);
+}
+
 // One persistent launch.  Returns DVS_OK with *ran = false when the selection does not
 // qualify (the caller then uses the multi-launch engine).
 // Fresh sync block + cleared accumulators of the next launch, enqueued on `on`.  The head phase has
@@ -1845,7 +2164,9 @@ static int persist_prepare(dvs_ctx *ctx, dvs_select *s, uint32_t head_stop, hipS
     if (const char *e = getenv("DVS_PERSIST_WG_ROUNDS")) init.wg_thresh = uint32_t(atoi(e));
     if (const char *e = getenv("DVS_PERSIST_WG_SCALE")) init.wg_scale = float(atof(e));
     init.no_coarse = (getenv("DVS_PERSIST_NO_COARSE") ? 1u : 0u) | (getenv("DVS_PERSIST_NO_EVENTS") ? 2u : 0u) |
-                     (getenv("DVS_PERSIST_NO_BURST_DROP") ? 8u : 0u);
+                     (getenv("DVS_PERSIST_NO_BURST_DROP") ? 8u : 0u) |
+                     (getenv("DVS_PERSIST_NO_LOCAL_LOO") ? 16u : 0u);  // (SMALL: every accept takes the grid-wide f64 pass)
+    init.small_rows = s->persist_small ? s->persist_small_rows : 0u;
     DVS_HIP(ctx, hipMemcpyAsync(head_stop ? s->psync_head : s->psync, &init, sizeof init, hipMemcpyHostToDevice, on));
     DVS_HIP(ctx, hipMemsetAsync(head_stop ? s->ppart_head : s->ppart, 0, p_acc_bytes(s->persist_maxn), on));
     return DVS_OK;
@@ -1876,9 +2197,7 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat, uint32_t gr
         s->ev_used += 2;
         (void)hipEventRecord(e0, on);
     }
-    const void *fn = s->params.mode == DVS_MODE_MAX ? reinterpret_cast<const void *>(persist_nmost_kernel<T, true, true>)
-                     : d.B <= uint64_t(P_J) * P_THREADS ? reinterpret_cast<const void *>(persist_nmost_kernel<T, true>)
-                                                        : reinterpret_cast<const void *>(persist_nmost_kernel<T, false>);
+    const void *fn = persist_fn<T>(s);
     SelDev d_arg = d;
     const T *mat_arg = mat;
     PSync *sync_arg = static_cast<PSync *>(head_stop ? s->psync_head : s->psync);
@@ -1919,20 +2238,30 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     if (const char *e = getenv("DVS_PERSIST_GRID")) s->persist_grid = std::max(2, std::min(ctx->n_cu, atoi(e)));  // (measurement knob)
     const bool cached = B <= uint64_t(P_J) * P_THREADS;
     if (maxm && !cached) return DVS_OK;  // (the growth phase wants the candidate in registers and S in LDS)
-    s->persist_maxn = p_maxn(cached);
-    s->persist_maxjobs = p_maxjobs(cached);
+    // SMALL sets (see the kernel): nmost, 16-bit rows of 4096 bins, every member's row in LDS
+    s->persist_small_rows = s->params.n_seed;
+    s->persist_small = !maxm && s->params.mode == DVS_MODE_NMOST && s->mat_kind == 2 && B == 4096 &&
+                       s->params.n_seed >= 2 && s->params.n_seed <= P_SMALL_ROWS && !getenv("DVS_PERSIST_NO_SMALL");
+    auto lds_for = [&](uint32_t maxn_) {
+        return ((B + 1) & ~1ull) * 8 + (cached && s->mat_kind != 1 ? ((B + 3) & ~3ull) * 4 : 0) +
+               (maxm ? ((B + 1) & ~1ull) * 8 : 0) + 128 * 8 + size_t(maxn_) * 52 + 8 + P_SOFT * 8 + 64 +
+               128 * 16;  // (+ log2_tab's table)
+    };
+    size_t lds = lds_for(p_maxn(cached));
+    if (s->persist_small) {
+        const size_t lds_small = lds_for(P_SMALLN) + P_SMALL_LOO * 8 + size_t(s->persist_small_rows) * B * 2 + 16;
+        if (lds_small <= ctx->lds_per_block) lds = lds_small;
+        else s->persist_small = false;
+    }
+    s->persist_maxn = s->persist_small ? P_SMALLN : p_maxn(cached);
+    s->persist_maxjobs = s->persist_small ? P_SMALLN + 1 : p_maxjobs(cached);
     // (MODE_MAX: max_size may be the whole stream; the kernel hands over when its LDS replica is full)
     if (!maxm && s->cap > s->persist_maxn) return DVS_OK;
-    const size_t lds = ((B + 1) & ~1ull) * 8 + (cached && s->mat_kind != 1 ? ((B + 3) & ~3ull) * 4 : 0) +
-                       (maxm ? ((B + 1) & ~1ull) * 8 : 0) + 128 * 8 + size_t(s->persist_maxn) * 52 + 8 + P_SOFT * 8 + 64 +
-                       128 * 16;  // (+ log2_tab's table)
     if (lds > ctx->lds_per_block) return DVS_OK;
     s->persist_lds = lds;
     const void *fn = dvs_mat_dispatch(s->mat, [&](auto *mp) -> const void * {
         using T = std::remove_cv_t<std::remove_pointer_t<decltype(mp)>>;
-        return maxm     ? reinterpret_cast<const void *>(persist_nmost_kernel<T, true, true>)
-               : cached ? reinterpret_cast<const void *>(persist_nmost_kernel<T, true>)
-                        : reinterpret_cast<const void *>(persist_nmost_kernel<T, false>);
+        return persist_fn<T>(s);
     });
     int rc = dvs_raise_dyn_lds(ctx, fn, lds);
     if (rc) return rc;

@@ -28,6 +28,7 @@ struct SelCtl {
     uint32_t s_is_resum;  // S still equals the members' rows added up in member order (only pushes so far)
     uint32_t n_windows, n_events, n_accepts;
     uint32_t n_logged;  // entries of the event log (accepted set changes, for the arbiter)
+    uint32_t n_local_loo;  // accepts whose new lowest member the persistent engine's workgroups worked out locally (SMALL)
     double total_jsd, sum_entropy;      // records.rs: total_jsd, summed_entropies
     double thr, band;                   // total_jsd + eps ; width of the undecidable zone
     double he_base;                     // summed_entropies - H(lowest)
@@ -95,6 +96,8 @@ struct dvs_select {
     bool persist_coop = false;       // launched with hipLaunchCooperativeKernel
     bool persist_fell_back = false;  // the persistent kernel gave up (not co-resident): multi-launch engine from the seeds
     uint32_t persist_grid = 0, persist_maxn = 0, persist_maxjobs = 0;
+    bool persist_small = false;       // the SMALL instantiation: member count rows in every workgroup's LDS
+    uint32_t persist_small_rows = 0;  // ... that many of them
     size_t persist_lds = 0;
     void *psync = nullptr;
     std::vector<unsigned char> h_psync;  // host image of the sync block (source of its upload)
