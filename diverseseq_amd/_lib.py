@@ -56,7 +56,7 @@ class SelectSummary(C.Structure):
                 ("n_windows", C.c_uint32), ("n_events", C.c_uint32),
                 ("n_accepts", C.c_uint32), ("n_arbitrated", C.c_uint32),
                 ("scan_ms", C.c_double), ("scan_launches", C.c_uint64),
-                ("engine", C.c_uint32), ("rows_coarse_passed", C.c_uint32), ("n_local_loo", C.c_uint32)]
+                ("engine", C.c_uint32), ("rows_coarse_passed", C.c_uint32)]
 
 
 class DvsLibraryMissing(RuntimeError):

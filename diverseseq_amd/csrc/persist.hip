@@ -54,10 +54,9 @@ constexpr uint32_t P_MAXN = 512;            // members the LDS replica holds whe
 constexpr uint32_t P_MAXN_BIG = 256;        // ... and beyond (k = 7: 128 KB of LDS go to the set state)
 constexpr uint32_t p_maxn(bool cached) { return cached ? P_MAXN : P_MAXN_BIG; }
 // SMALL sets (nmost over 16-bit count rows of 4096 bins): the members' count rows live in every
-// workgroup's LDS, so the leave-one-out pass of an accept needs no other workgroup (see the kernel)
+// workgroup's LDS (see the kernel)
 constexpr uint32_t P_SMALLN = 16;      // members the replica arrays of a SMALL launch hold ...
 constexpr uint32_t P_SMALL_ROWS = 13;  // ... and rows (8 KB each) that fit beside the state in 160 KB of LDS
-constexpr uint32_t P_SMALL_LOO = P_SMALLN * 16 + 16;  // doubles of scratch for the local leave-one-out passes
 // leave-one-out jobs per event: (n + 1) * K <= max(G - 1, n + 1) <= maxn + 1 (G <= maxn + 2 is checked)
 constexpr uint32_t p_maxjobs(bool cached) { return p_maxn(cached) + 1; }
 // leave-one-out accumulators: 3 slots (accept % 3) x 8 group replicas x (maxn + 1) members x 2 words
@@ -93,9 +92,12 @@ struct PSync {
     const unsigned long long *seed_list;  // ... those positions (ctl->size of them)
     uint32_t small_rows;  // SMALL instantiation: member rows the LDS replica has room for
     uint32_t pad2[55];
-    // event words, slot = epoch % 3, one copy per group g = blockIdx % 8 (a wave polls before every
-    // row: one word for the whole grid serialises those loads at the memory side): ev[s][32 g] = first
-    // event position, ev[s][32 g + 16] = the same position when the event is sure
+    // event records, slot = epoch % 3, one copy per group g = blockIdx % 8 on a cache line of its own (a
+    // wave polls before every row: one word for the whole grid serialises those loads at the memory
+    // side).  A record is 16 bytes that ONE load reads: ev[s][32 g] = {u32 generation of the rendezvous
+    // that ended the slot's window, u32 "candidates were listed" flag}, ev[s][32 g + 1] = the window's first
+    // event as (position << 1) | (1 if it is not a sure one) -- so the workgroup that sees the release
+    // has the window's outcome in the same round trip.
     unsigned long long ev[3][8 * 32];
     // candidates whose fast score is within FAST_BAND of the threshold: count at [s][0], positions
     // from [s][8]; the workgroups re-evaluate them in f64 after the rendezvous, in stream order
@@ -161,18 +163,75 @@ __device__ bool grid_barrier(PSync *sync, uint32_t G, uint32_t &gen, int *s_ok) 
     return *s_ok != 0;
 }
 
-// publishing an event: every group copy of the slot (evs = its base)
-__device__ __forceinline__ void p_post_event_wave(unsigned long long *evs, uint64_t p, bool sure, uint32_t lane) {
-    if (lane < 8) {
-        atomicMin(evs + lane * 32, (unsigned long long)p);
-        if (sure) atomicMin(evs + lane * 32 + 16, (unsigned long long)p);
+// The same rendezvous in two halves, for work that can be done while the others are still on their
+// way: grid_arrive announces this workgroup (and releases everybody if it is the last), grid_wait
+// waits for the release.  s_ok[1] carries "released by this workgroup" between the two.
+// 16 bytes in one agent-scope load (one request: a consistent view of a record)
+__device__ __forceinline__ uint4 p_load16_agent(const void *ptr) {
+    uint4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+// The release of a WINDOW's rendezvous is the generation word of the window's event records (evs: the
+// slot, eight group copies): whoever polls it reads the window's first event and the "listed" flag
+// in the same 16-byte load.
+__device__ void grid_arrive(PSync *sync, uint32_t G, uint32_t gen, unsigned long long *evs) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t target = gen + 1;
+        const uint32_t x = blockIdx.x & 7u, ng = G < 8u ? G : 8u;
+        const uint32_t gsz = (G - x + 7u) >> 3;
+        if (__hip_atomic_fetch_add(&sync->gcount[x].v, 1u, RLX_AGENT) == gsz * target - 1 &&
+            __hip_atomic_fetch_add(&sync->count, 1u, RLX_AGENT) == ng * target - 1) {
+            for (uint32_t g = 0; g < 8u; g++)
+                __hip_atomic_store(reinterpret_cast<uint32_t *>(evs + g * 32), target, RLX_AGENT);
+        }
     }
 }
-__device__ __forceinline__ void p_post_event_thread(unsigned long long *evs, uint64_t p, bool sure) {
-    for (uint32_t g = 0; g < 8; g++) {
-        atomicMin(evs + g * 32, (unsigned long long)p);
-        if (sure) atomicMin(evs + g * 32 + 16, (unsigned long long)p);
+// -> s_out[0] = the event word (bits), s_out[1] = the listed flag; false on timeout
+__device__ bool grid_wait(PSync *sync, uint32_t &gen, int *s_ok, const unsigned long long *rec, double *s_out) {
+    if (threadIdx.x == 0) {
+        const uint32_t target = gen + 1;
+        int ok = 1;
+        uint32_t spins = 0;
+        uint4 v = p_load16_agent(rec);
+        while (v.x < target) {
+            if ((++spins & 255u) == 0 &&
+                (spins > P_SPIN_LIMIT || __hip_atomic_load(&sync->timeout, RLX_AGENT))) {
+                __hip_atomic_store(&sync->timeout, 1u, RLX_AGENT);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            v = p_load16_agent(rec);
+        }
+        s_out[0] = __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z));
+        s_out[1] = double(v.y);
+        *s_ok = ok;
     }
+    __syncthreads();
+    gen++;
+    return *s_ok != 0;
+}
+
+// publishing an event: every group copy of the slot (evs = its base)
+__device__ __forceinline__ unsigned long long p_ev_word(uint64_t p, bool sure) {
+    return ((unsigned long long)p << 1) | (sure ? 0ull : 1ull);
+}
+__device__ __forceinline__ uint64_t p_ev_pos(unsigned long long w) { return w == SEL_NONE ? SEL_NONE : uint64_t(w >> 1); }
+__device__ __forceinline__ void p_post_event_wave(unsigned long long *evs, uint64_t p, bool sure, uint32_t lane) {
+    if (lane < 8) atomicMin(evs + lane * 32 + 1, p_ev_word(p, sure));
+}
+__device__ __forceinline__ void p_post_event_thread(unsigned long long *evs, uint64_t p, bool sure) {
+    for (uint32_t g = 0; g < 8; g++) atomicMin(evs + g * 32 + 1, p_ev_word(p, sure));
+}
+// a candidate was listed: the flag of every group's record (the results are consumed: performed before
+// this thread's workgroup can arrive at the rendezvous)
+__device__ __forceinline__ void p_flag_listed(unsigned long long *evs, unsigned long long *softp) {
+    uint32_t seen = 0;
+    for (uint32_t g = 0; g < 8; g++)
+        seen |= __hip_atomic_fetch_or(reinterpret_cast<uint32_t *>(evs + g * 32) + 1, 1u, RLX_AGENT);
+    if (seen == 0xDEADBEEFu) softp[7] = 1;  // (never)
 }
 
 // One wave's share of the window, as scan_rows_hot but against the unscaled vector sl:
@@ -198,7 +257,7 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
     for (uint64_t r = first; r < nrows; r += stride) {
         const uint64_t p = st.cursor + r;
         const T *rp = mat + p * B;
-        const unsigned long long ev = __hip_atomic_load(evp, RLX_AGENT);
+        const unsigned long long ev = p_ev_pos(__hip_atomic_load(evp, RLX_AGENT));
         const uint32_t tot = totals[p];
         const double hrow = rowH[p];
         if (ev < p) break;
@@ -237,7 +296,7 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                 uint64_t i0 = 0;
                 bool dropped = false;
                 for (; i0 < full; i0 += 256 * C_CH) {
-                    if (i0 && burst_drop && __hip_atomic_load(evp, RLX_AGENT) < p) {
+                    if (i0 && burst_drop && p_ev_pos(__hip_atomic_load(evp, RLX_AGENT)) < p) {
                         dropped = true;
                         break;
                     }
@@ -337,6 +396,7 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                 if (idx < P_SOFT) {
                     if (__hip_atomic_exchange(softp + 8 + idx, (unsigned long long)p, RLX_AGENT) == 1ull)
                         softp[7] = 1;  // (never: position 1 is a seed; consumes the result)
+                    p_flag_listed(evs, softp);
                 } else {
                     p_post_event_thread(evs, p, false);  // list full: a plain (unsure) event
                 }
@@ -371,7 +431,7 @@ __device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const 
     for (uint64_t r = first; r < nrows; r += stride, par ^= 1) {
         const uint64_t p = st.cursor + r;
         const T *rp = mat + p * B;
-        const unsigned long long ev = wave == 0 ? __hip_atomic_load(evp, RLX_AGENT) : 0ull;
+        const unsigned long long ev = wave == 0 ? p_ev_pos(__hip_atomic_load(evp, RLX_AGENT)) : 0ull;
         const uint32_t tot = totals[p];
         const double hrow = rowH[p];
         const double rt = tot ? 1.0 / double(tot) : 0.0;
@@ -476,6 +536,7 @@ __device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const 
                     if (idx < P_SOFT) {
                         if (__hip_atomic_exchange(softp + 8 + idx, (unsigned long long)p, RLX_AGENT) == 1ull)
                             softp[7] = 1;  // (never: position 1 is a seed; consumes the result)
+                        p_flag_listed(evs, softp);
                     } else {
                         p_post_event_thread(evs, p, false);  // list full: a plain (unsure) event
                     }
@@ -525,7 +586,7 @@ __device__ __forceinline__ void p_scan_rows_wg_stream(const T *__restrict__ mat,
         w.tot = totals[p];
         if (wave == 0) {  // the row's entropy and the event word travel through LDS with the partial sums
             w.hrow = rowH[p];
-            w.ev = __hip_atomic_load(evp, RLX_AGENT);
+            w.ev = p_ev_pos(__hip_atomic_load(evp, RLX_AGENT));
         }
     };
     uint32_t par = 0;
@@ -664,61 +725,6 @@ __device__ __forceinline__ void p_argmin(const double *s_dl, const double *s_ds,
     }
 }
 
-// ---- SMALL sets: the leave-one-out pass of an accept inside every workgroup, all f32.
-// Member r's leave-one-out mean vector is u_i = (S'_i - f_ri) / (n - 1) (updated_mean_freqs,
-// records.rs:276-286); here y_i = S'_i / (n - 1) - c_ri * rho_r with S'_i / (n - 1) and
-// rho_r = 1 / (T_r (n - 1)) rounded to f32 and one fma, v_log_f32 on y, the products folded in f32 four
-// at a time (coarse4's scheme).  With e = 2^-24, w = n / (n - 1) = sum_i S'_i / (n - 1) and
-// lb = log2 B >= H, the sum of y log2 y differs from the reference's sum of u log2 u by at most
-//   3 e w (23.42 + lb)   inputs: |y - u| <= d_i = 3 e S'_i / (n - 1) (the two roundings and the fma; member r
-//                        is part of S', so c rho <= the first term), and |g(a) - g(b)| <= g(|a - b|) for
-//                        g(x) = -x log2 x (the lemma behind Fannes' inequality), g(d_i) = d_i (22.42 +
-//                        |log2(S'_i / (n - 1))|), sum_i S'_i / (n - 1) |log2 ..| <= w (1 + lb); the clamp
-//                        u <= eps -> 0 of the reference moves a bin by <= 2.3e-16
-// + 2 k e (lb + 1)       v_log_f32, k <= 1.5 ulp (dvs_selftest_log2_f32, every f32 in [2^-101, 2))
-// + e lb + 9 e lb        the f32 product, and nine levels of f32 addition between a product and its wave's
-//                        total (three inside the thread, six across the lanes); the eight waves' totals
-//                        are added in f64
-// = e (3 w (23.42 + lb) + 13 lb + 3); p_loo_band adds a quarter on top (2.1e-5 at 4^6 bins, n = 10).
-// The argmin is taken from these sums only when the two smallest delta_jsd are more than two bands (+ the
-// reference's own noise band) apart -- ~13 in 14 accepts at n = 10 on random 5 kb sequences; otherwise the
-// exact f64 pass over the grid decides as before.  A bin y <= 0 (cancellation noise where member r is
-// the bin's only contributor) counts as 1e-30: its true contribution is below 1e-10 either way.
-__device__ __forceinline__ double p_loo_band(uint64_t B, double dn) {
-    const double w = dn / (dn - 1.0), lb = log2(double(B));
-    return 1.25 * 0x1p-24 * (3.0 * w * (23.42 + lb) + 13.0 * lb + 3.0);
-}
-// f32 sum over the wave by DPP, the total in lane 63 (fixed order: the same bits in every workgroup):
-// four butterfly steps inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 add the rows up
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float p_dpp_f32(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
-}
-__device__ __forceinline__ float p_wave_sum_f32_lane63(float v) {
-    v += p_dpp_f32<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-    v += p_dpp_f32<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-    v += p_dpp_f32<0x141, 0xF>(v);  // row_half_mirror
-    v += p_dpp_f32<0x140, 0xF>(v);  // row_mirror: every lane holds the sum of its row
-    v += p_dpp_f32<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
-    v += p_dpp_f32<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
-    return v;
-}
-__device__ __forceinline__ float p_loo4(const uint2 c, float b0, float b1, float b2, float b3, const dvs_f2 nrho2) {
-    const dvs_f2 c01 = {float(c.x & 0xFFFFu), float(c.x >> 16)}, c23 = {float(c.y & 0xFFFFu), float(c.y >> 16)};
-    const dvs_f2 tiny = {1e-30f, 1e-30f};
-    const dvs_f2 y01 = __builtin_elementwise_max(__builtin_elementwise_fma(c01, nrho2, (dvs_f2){b0, b1}), tiny);
-    const dvs_f2 y23 = __builtin_elementwise_max(__builtin_elementwise_fma(c23, nrho2, (dvs_f2){b2, b3}), tiny);
-    const dvs_f2 l01 = {__builtin_amdgcn_logf(y01.x), __builtin_amdgcn_logf(y01.y)};
-    const dvs_f2 l23 = {__builtin_amdgcn_logf(y23.x), __builtin_amdgcn_logf(y23.y)};
-    const dvs_f2 s = y01 * l01 + y23 * l23;
-    return s.x + s.y;
-}
-// a thread's eight bins of one member (packed 16-bit counts q, bins j = 0..7 of the thread) -> sum y log2 y
-__device__ __forceinline__ float p_loo8(const uint4 q, const float (&sf)[8], const dvs_f2 nrho2) {
-    return p_loo4(make_uint2(q.x, q.y), sf[0], sf[1], sf[2], sf[3], nrho2) +
-           p_loo4(make_uint2(q.z, q.w), sf[4], sf[5], sf[6], sf[7], nrho2);
-}
-
 // LDS: [sl B f64][scratch 128 f64][s_mH, s_tot, s_rt, s_dl, s_ds maxn f64][s_pos maxn u64]
 //      [s_slot maxn u32][s_soft P_SOFT u64][flags]
 // maxn = p_maxn(CACHED): compile-time offsets (runtime ones cost registers the scan loop needs),
@@ -733,13 +739,10 @@ __device__ __forceinline__ float p_loo8(const uint4 q, const float (&sf)[8], con
 // the launch with the event unconsumed; the multi-launch kernels (and the arbiter) take it.
 // SMALL: nmost over 16-bit count rows of exactly 4096 bins with a set of <= P_SMALL_ROWS members.  The
 // members' count rows (8 KB each) sit in every workgroup's LDS, thread-major (thread t's bins
-// j * 512 + t, j < 8, are the 16 bytes at t * 16: no thread ever reads another's part), so after an
-// accept EVERY workgroup works out the new lowest member on its own -- H(S'/n) in f64 and the
-// leave-one-out sums of all members in f32 (p_loo8) -- instead of spreading (n + 1) K f64 jobs over the
-// grid and waiting for their totals, and rebuilds sl from its LDS instead of fetching the new lowest
-// member's row: one grid-wide hop and two memory round trips less per accept.  The members' exact
-// delta_jsd are brought up to date by the mirror block when the launch ends (they are results, not inputs
-// of any decision in this mode).
+// j * 512 + t, j < 8, are the 16 bytes at t * 16: no thread ever reads another's part).  An accept then
+// takes its leave-one-out job's member counts and the new lowest member's row from LDS instead of two
+// memory round trips, and the candidate's own row is requested before the rendezvous that ends the
+// window (the event word already names it), not behind it.
 template <typename T, bool CACHED, bool MAXM = false, bool SMALL = false>
 __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, const T *__restrict__ mat,
                                                                     PSync *sync, unsigned long long *part, uint32_t G) {
@@ -766,8 +769,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     int *s_flag = reinterpret_cast<int *>(s_soft + P_SOFT);
     static_assert(maxn % 4 == 0 && P_SOFT % 2 == 0, "s_ltab below must sit on a 16-byte boundary");
     double2 *s_ltab = reinterpret_cast<double2 *>(s_soft + P_SOFT + 2);  // log2_tab's 128 entries
-    [[maybe_unused]] double *s_loo = reinterpret_cast<double *>(s_ltab + 128);  // SMALL: partial sums of the local leave-one-out pass
-    [[maybe_unused]] uint16_t *s_rows = reinterpret_cast<uint16_t *>(s_loo + P_SMALL_LOO);  // SMALL: member count rows by slot
+    [[maybe_unused]] uint16_t *s_rows = reinterpret_cast<uint16_t *>(s_ltab + 128);  // SMALL: member count rows by slot
     if (threadIdx.x < 128) log2_tab_fill(s_ltab, threadIdx.x);
     SelCtl *ctl = d.ctl;
     const int tid0 = threadIdx.x;
@@ -1055,8 +1057,6 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     // SMALL: the members' count rows into LDS, thread-major (see above).  A slot the replica has no room
     // for (never: an nmost set occupies slots 0 .. n - 1) leaves the launch with the state untouched;
     // the host then carries on with the multi-launch kernels.
-    [[maybe_unused]] bool delta_stale = false;  // the mirrored delta_jsd of the members are older than the set
-    [[maybe_unused]] uint32_t n_local = 0;      // accepts whose lowest member was worked out inside the workgroup
     if constexpr (SMALL) {
         const uint32_t rows_cap = sync->small_rows;
         bool fits = B == 4096 && st.n <= rows_cap;
@@ -1086,18 +1086,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             t_prev = t_now;                                                \
         }                                                                  \
     } while (0)
-// (block 0 only, slots 9..15 of its array: the SMALL accept path in detail)
-#define P_STAMP2(k)                                                        \
-    do {                                                                   \
-        if (blockIdx.x == 0 && !lead && tid == 0) {                        \
-            const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); \
-            sync->dbg2[k] += t_now - t_prev;                               \
-            t_prev = t_now;                                                \
-        }                                                                  \
-    } while (0)
 #else
 #define P_STAMP(k) do { } while (0)
-#define P_STAMP2(k) do { } while (0)
 #endif
     for (;;) {
         // The loop body's view of the bin count and the thread index goes through an empty asm:
@@ -1110,13 +1100,19 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         asm volatile("" : "+v"(tid));
         const uint32_t lane = uint32_t(tid) & 63u, wave = uint32_t(tid) >> 6;
         unsigned long long *evs = &sync->ev[epoch % 3][0];            // the slot: eight group copies
-        unsigned long long *evp = evs + (blockIdx.x & 7u) * 32;       // this workgroup's copy
-        // the slot of the NEXT epoch is cleared now; an exchange (its result is consumed) has been
-        // performed before this thread's arrival at the barrier below can be
-        if (lead && tid < 17 &&
-            __hip_atomic_exchange(tid < 16 ? &sync->ev[(epoch + 1) % 3][tid * 16] : &sync->soft[(epoch + 1) % 3][0],
-                                  tid < 16 ? SEL_NONE : 0ull, RLX_AGENT) == 1ull)
-            sync->pad0[1] = 1;  // (consumes the results; position 1 is a seed, never an event or a count)
+        unsigned long long *evrec = evs + (blockIdx.x & 7u) * 32;    // this workgroup's copy of the record ...
+        unsigned long long *evp = evrec + 1;                          // ... and its event word
+        // the slot of the NEXT epoch is cleared now (event words, listed flags, the list's count -- not the
+        // generations); an exchange (its result is consumed) has been performed before this thread's
+        // arrival at the barrier below can be
+        if (lead && tid < 17) {
+            unsigned long long *nx = &sync->ev[(epoch + 1) % 3][0];
+            bool odd = false;
+            if (tid < 8) odd = __hip_atomic_exchange(nx + tid * 32 + 1, SEL_NONE, RLX_AGENT) == 3ull;
+            else if (tid < 16) odd = __hip_atomic_exchange(reinterpret_cast<uint32_t *>(nx + (tid - 8) * 32) + 1, 0u, RLX_AGENT) == 0xDEADBEEFu;
+            else odd = __hip_atomic_exchange(&sync->soft[(epoch + 1) % 3][0], 0ull, RLX_AGENT) == ~0ull;
+            if (odd) sync->pad0[1] = 1;  // (consumes the results; never: position 1 is a seed, the flag is 0 or 1)
+        }
 #ifdef DVS_PERSIST_STAMPS
         const unsigned long long t_window = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1141,26 +1137,113 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                                        nrows, lane, nread, nprecise, nmid, coarse_on,
                                        (sync->no_coarse & 8u) == 0);
         }
-        // SMALL: the counts of the candidate this window will most likely end with -- the event word as it
-        // stands when this workgroup leaves the scan -- are requested BEFORE the rendezvous, so that the
-        // row's memory round trip runs beside the barrier instead of behind it (an earlier event posted
-        // later only means the row is fetched again below).
+        // SMALL: the candidate this window will most likely end with -- the event word as it stands when
+        // this workgroup leaves the scan -- is taken up BEFORE the rendezvous has completed: its counts,
+        // total and entropy are requested ahead of the arrival (the row's memory round trip runs beside the
+        // barrier, not behind it), and between arrival and release the workgroup already converts them to
+        // frequencies and works out its own leave-one-out job for that candidate (the arithmetic an
+        // accept would start with after the release; nothing leaves the workgroup).  An earlier event
+        // posted later, an unsure one or a listed candidate ahead of it only means that the work is done
+        // again below.
+        double fr[P_J];  // the candidate's frequencies of this thread's bins (B <= P_J * 512)
         [[maybe_unused]] T craw[P_J];
-        [[maybe_unused]] uint64_t craw_pos = SEL_NONE;  // the position whose counts craw holds
+        [[maybe_unused]] uint64_t craw_pos = SEL_NONE;  // the position whose counts craw holds ...
+        [[maybe_unused]] uint32_t craw_tot = 1;         // ... its total and its entropy
+        [[maybe_unused]] double craw_H = 0.0;
+        [[maybe_unused]] uint64_t fr_pos = SEL_NONE;    // the position fr[] holds the frequencies of
+        [[maybe_unused]] uint64_t spec_job_pos = SEL_NONE;  // ... and the candidate spec_th / spec_ts were worked out for
+        [[maybe_unused]] double spec_th = 0.0, spec_ts = 0.0;
         [[maybe_unused]] auto fetch_raw = [&](uint64_t q) {
             if (craw_pos != q) {
                 const T *gp = mat + q * B;
 #pragma unroll
                 for (int j = 0; j < P_J; j++) craw[j] = gp[uint64_t(j) * P_THREADS + tid];
+                craw_tot = d.totals[q];
+                craw_H = d.rowH[q];
                 craw_pos = q;
             }
         };
+        // one leave-one-out job of an accept, SMALL form (everything from LDS and registers): member
+        // r of the NEW order over this thread's bins j with j % K == part -- the whole new set for
+        // r == n, the candidate itself for r == n - 1, else the member whose replica arrays sit at index
+        // `at` (before the order has been shifted that is r or r + 1, afterwards r); -> this workgroup's
+        // sums on threads 0..7 (updated_mean_freqs, records.rs:276-286)
+        [[maybe_unused]] auto small_job = [&](uint32_t r, uint32_t part_i, uint32_t at, uint32_t n_, double &th, double &ts) {
+            const double dn_ = double(n_), rn_ = 1.0 / dn_, rdiv_ = 1.0 / (dn_ - 1.0);
+            const bool is_new = r == n_ - 1;
+            uint4 q = make_uint4(0u, 0u, 0u, 0u);
+            double mtot = 1.0, mrt = 1.0;
+            if (r < n_ && !is_new) {
+                q = *reinterpret_cast<const uint4 *>(s_rows + uint64_t(s_slot[at]) * 4096 + uint32_t(tid) * 8);
+                mtot = s_tot[at];
+                mrt = s_rt[at];
+            }
+            const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+            double h = 0.0, sv = 0.0;
+#pragma unroll
+            for (int j = 0; j < P_J; j++) {
+                if ((uint32_t(j) & (K - 1)) == part_i) {
+                    double v = sl[uint64_t(j) * P_THREADS + tid];
+                    if (v <= DVS_EPS) v = 0.0;
+                    const double sn = v + fr[j];
+                    double u;
+                    if (r == n_) {
+                        u = sn * rn_;
+                    } else {
+                        const uint32_t c = (qw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                        u = (sn - (is_new ? fr[j] : exact_div_u32(double(c), mtot, mrt))) * rdiv_;
+                        if (u <= DVS_EPS) u = 0.0;
+                    }
+                    if (u > 0.0) h -= u * log2_tab(u, s_ltab);
+                    sv += u;
+                }
+            }
+            h = dvs_wave_sum_dpp(h);
+            sv = dvs_wave_sum_dpp(sv);
+            __syncthreads();  // (scratch[64..] of an earlier use has been read)
+            if (lane == 0) {
+                scratch[64 + wave] = h;
+                scratch[80 + wave] = sv;
+            }
+            __syncthreads();
+            th = ts = 0.0;
+            if (tid < 8) {
+                for (uint32_t w = 0; w < P_THREADS / 64; w++) {
+                    th += scratch[64 + w];
+                    ts += scratch[80 + w];
+                }
+            }
+        };
         if constexpr (SMALL) {
-            const uint64_t guess = __hip_atomic_load(evp, RLX_AGENT);
+            const uint64_t guess = p_ev_pos(__hip_atomic_load(evp, RLX_AGENT));
             if (guess != SEL_NONE) fetch_raw(guess);
+            // (the waves of a workgroup leave the scan at different times and may have read different
+            // words: each hands its own over through LDS, behind the barrier that opens the arrival)
+            if (lane == 0) scratch[112 + wave] = __longlong_as_double((long long)guess);
         }
         P_STAMP(0);
-        if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
+        grid_arrive(sync, G, gen, evs);
+        if constexpr (SMALL) {
+            {   // the workgroup's common view: the earliest event any of its waves saw
+                uint64_t g = SEL_NONE;
+#pragma unroll
+                for (uint32_t w = 0; w < P_THREADS / 64; w++) g = umin64(g, (uint64_t)__double_as_longlong(scratch[112 + w]));
+                if (g != SEL_NONE) fetch_raw(g);
+                else craw_pos = SEL_NONE;
+            }
+            if (craw_pos != SEL_NONE && (sync->no_coarse & 16u) == 0) {
+                const double t_ = double(craw_tot), rt_ = 1.0 / t_;
+#pragma unroll
+                for (int j = 0; j < P_J; j++) fr[j] = count_freq_x(craw[j], t_, rt_);
+                fr_pos = craw_pos;
+                if (one_job && has_job && !lead) {
+                    const uint32_t r = blockIdx.x / K;
+                    small_job(r, blockIdx.x % K, r < st.li ? r : r + 1, st.n, spec_th, spec_ts);
+                    spec_job_pos = craw_pos;
+                }
+            }
+        }
+        if (!grid_wait(sync, gen, s_flag, evrec, scratch + 121)) { exit_status = SEL_ERROR; break; }
         P_STAMP(1);
 #ifdef DVS_PERSIST_STAMPS
         if (lead && tid == 0) {  // scan + rendezvous time and window count by scan mode, rows per mode
@@ -1170,9 +1253,12 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             sync->dbg[wgmode ? 13 : 14] += nrows;
         }
 #endif
-        const uint64_t hard = __hip_atomic_load(evp, RLX_AGENT);
-        const uint64_t hard_sure = __hip_atomic_load(evp + 16, RLX_AGENT);  // same round trip
-        const uint64_t nlisted = __hip_atomic_load(&sync->soft[epoch % 3][0], RLX_AGENT);
+        // the window's outcome came with the release (grid_wait): no further round trip, except for the
+        // list of near-threshold candidates when there is one
+        const unsigned long long hard_w = (unsigned long long)__double_as_longlong(scratch[121]);
+        const uint64_t hard = p_ev_pos(hard_w);
+        const bool hard_is_sure = hard_w != SEL_NONE && (hard_w & 1ull) == 0;
+        const uint64_t nlisted = scratch[122] != 0.0 ? __hip_atomic_load(&sync->soft[epoch % 3][0], RLX_AGENT) : 0ull;
         st.n_windows++;
         // this workgroup's leave-one-out job, should the window end in an accept: the member's
         // counts are requested now (its row does not depend on the event), in the same memory
@@ -1200,14 +1286,19 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         uint64_t p = SEL_NONE;
         double tot = 1.0, rtot = 1.0, cand_H = 0.0;
         const T *rp = mat;
-        double fr[P_J];  // the candidate's frequencies of this thread's bins (B <= P_J * 512)
         double jsd = 0.0, sm = 1.0;
         auto evaluate = [&](uint64_t q) {  // exact score of candidate q, by the whole workgroup
-            tot = double(d.totals[q]);
+            if constexpr (SMALL) {
+                fetch_raw(q);
+                tot = double(craw_tot);
+                cand_H = craw_H;
+                fr_pos = q;
+            } else {
+                tot = double(d.totals[q]);
+                cand_H = d.rowH[q];
+            }
             rtot = 1.0 / tot;
-            cand_H = d.rowH[q];
             rp = mat + q * B;
-            if constexpr (SMALL) fetch_raw(q);
             Ent e;
             for (uint64_t b0 = 0; b0 < B; b0 += uint64_t(P_J) * P_THREADS) {
 #pragma unroll
@@ -1272,16 +1363,24 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             // thr + band) is accepted outright.  The sum-to-one guard needs no second look either:
             // the candidate's mean vector sums to the previous whole-set sum up to ~B u, and that
             // sum passed its guard at the last finalize.
-            const bool sure = hard_sure == p;
+            const bool sure = hard_is_sure;
             if (sure) {
-                tot = double(d.totals[p]);
-                cand_H = d.rowH[p];
+                if constexpr (SMALL) {
+                    fetch_raw(p);
+                    tot = double(craw_tot);
+                    cand_H = craw_H;
+                } else {
+                    tot = double(d.totals[p]);
+                    cand_H = d.rowH[p];
+                }
                 rp = mat + p * B;
                 rtot = 1.0 / tot;
                 if constexpr (SMALL) {
-                    fetch_raw(p);
+                    if (fr_pos != p) {  // (else: worked out while the rendezvous was completing)
 #pragma unroll
-                    for (int j = 0; j < P_J; j++) fr[j] = count_freq_x(craw[j], tot, rtot);
+                        for (int j = 0; j < P_J; j++) fr[j] = count_freq_x(craw[j], tot, rtot);
+                        fr_pos = p;
+                    }
                 } else if (CACHED) {
 #pragma unroll
                     for (int j = 0; j < P_J; j++) {
@@ -1513,8 +1612,23 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             }
         }
         // ================= replace_lowest (records.rs:94-147) + leave-one-out
-        const uint32_t acc_slot = st.n_loo % 3;  // (taken only when the grid-wide pass below runs)
+        const uint32_t acc_slot = st.n_loo % 3;
+        st.n_loo++;
         st.n_accepts++;
+        // SMALL: a leave-one-out job worked out for this very candidate while the rendezvous was completing
+        // goes out FIRST -- its memory-side additions travel while the member arrays are shifted below
+        [[maybe_unused]] bool job_published = false;
+        if constexpr (SMALL) {
+            if (one_job && has_job && !lead && spec_job_pos == p) {
+                if (tid < 8) {  // lane g adds the job's words to group g's replica
+                    unsigned long long *dst = part + uint64_t(acc_slot) * 8 * (maxn + 1) * 2 +
+                                              (uint64_t(tid) * (maxn + 1) + blockIdx.x / K) * 2;
+                    atomicAdd(dst, p_acc_word(spec_th));
+                    atomicAdd(dst + 1, p_acc_word(spec_ts));
+                }
+                job_published = true;
+            }
+        }
         const uint32_t n = st.n, li = st.li;
         const uint32_t slot_low = s_slot[li];
         const uint32_t old_lab = lead ? d.mLabel[slot_low] : 0;
@@ -1589,101 +1703,14 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         }
         __syncthreads();
         st.sumH = sh;
-        // ================= SMALL: the whole leave-one-out pass inside the workgroup (see the kernel's header)
-        bool local_done = false;
-        [[maybe_unused]] double l_tj = 0.0, l_min = 0.0, l_sec = 0.0;
-        [[maybe_unused]] uint32_t l_low = 0;
-        if constexpr (SMALL) {
-            const double rdiv_l = 1.0 / (dn - 1.0);
-            float sf[P_J];
-            Ent e;
-#pragma unroll
-            for (int j = 0; j < P_J; j++) {
-                double v = sl[uint64_t(j) * P_THREADS + tid];
-                if (v <= DVS_EPS) v = 0.0;           // drop_lowest's clamp (records.rs:105-107)
-                const double sn = v + fr[j];         // S' (push, records.rs:135-137)
-                e.add(sn * rn, s_ltab);              // H(S'/n), f64: the new total_jsd
-                sf[j] = float(sn * rdiv_l);
-            }
-            {   // the candidate's counts take the slot of the member it replaces
-                uint4 q;
-                q.x = uint32_t(craw[0]) | (uint32_t(craw[1]) << 16);
-                q.y = uint32_t(craw[2]) | (uint32_t(craw[3]) << 16);
-                q.z = uint32_t(craw[4]) | (uint32_t(craw[5]) << 16);
-                q.w = uint32_t(craw[6]) | (uint32_t(craw[7]) << 16);
-                *reinterpret_cast<uint4 *>(s_rows + uint64_t(slot_low) * 4096 + uint32_t(tid) * 8) = q;
-            }
-            P_STAMP2(9);
-            // members in the NEW order (the candidate is member n - 1); unrolled over the rows the replica
-            // can hold, so that the rows' LDS reads run ahead of the arithmetic and a thread's partial sums
-            // stay in registers until the wave adds them up
-            float part_f[P_SMALL_ROWS];
-#pragma unroll
-            for (uint32_t r = 0; r < P_SMALL_ROWS; r++) {
-                part_f[r] = 0.0f;
-                if (r < n) {
-                    const float nrho = -float(s_rt[r] * rdiv_l);
-                    const uint4 q = *reinterpret_cast<const uint4 *>(s_rows + uint64_t(s_slot[r]) * 4096 + uint32_t(tid) * 8);
-                    part_f[r] = p_loo8(q, sf, (dvs_f2){nrho, nrho});
-                }
-            }
-#pragma unroll
-            for (uint32_t r = 0; r < P_SMALL_ROWS; r++) {
-                if (r < n) {
-                    const float a = p_wave_sum_f32_lane63(part_f[r]);
-                    if (lane == 63) s_loo[r * 8 + wave] = double(a);
-                }
-            }
-            {
-                const double hw = dvs_wave_sum_dpp(e.h), sw = dvs_wave_sum_dpp(e.sum);
-                if (lane == 0) {
-                    s_loo[P_SMALLN * 16 + wave] = hw;
-                    s_loo[P_SMALLN * 16 + 8 + wave] = sw;
-                }
-            }
-            P_STAMP2(10);
-            __syncthreads();
-            if (wave == 0) {
-                double hm = 0.0, svn = 0.0, hr = 0.0;
-#pragma unroll
-                for (int w = 0; w < 8; w++) {
-                    hm += s_loo[P_SMALLN * 16 + w];
-                    svn += s_loo[P_SMALLN * 16 + 8 + w];
-                    if (lane < n) hr += s_loo[lane * 8 + w];
-                }
-                const double tj = hm - sh / dn;
-                const bool mem = lane < n;
-                // delta_jsd_r = total_jsd - (H(mean_r) - (sumH - H_r) / (n - 1)); H(mean_r) = -sum y log2 y
-                const double dl = mem ? tj - (-hr - (sh - s_mH[lane]) * rdiv_l) : 1e6;
-                const double mn = dvs_wave_min(dl);
-                const unsigned long long at = __ballot(mem && dl == mn && mn < 1e6);
-                const uint32_t lw = at ? uint32_t(__builtin_ctzll(at)) : 0u;
-                const double sec = dvs_wave_min((mem && lane != lw) ? dl : 1e6);
-                // the members' sum-to-one guards (sum_risky on each leave-one-out mean vector): every
-                // count row sums to 1 within 2e-16 (correctly rounded quotients of one total), so
-                // sum_i u_i = (sum_i S'_i - 1) / (n - 1) up to a few eps -- checked from the f64 sum of
-                // S'/n at an eighth of the reference's tolerance instead of per bin
-                const bool guard = sum_risky(svn, B) || !(hm == hm) ||
-                                   !(fabs((svn * dn - 1.0) * rdiv_l - 1.0) <= 0.125 * double(B) * DVS_EPS);
-                if (lane == 0) {
-                    scratch[100] = mn;
-                    scratch[101] = double(lw);
-                    scratch[102] = sec;
-                    scratch[103] = tj;
-                    scratch[104] = guard ? 1.0 : 0.0;
-                }
-            }
-            __syncthreads();
-            l_min = scratch[100];
-            l_low = uint32_t(scratch[101]);
-            l_sec = scratch[102];
-            l_tj = scratch[103];
-            const double need = 2.0 * p_loo_band(B, dn) + sel_band(l_tj + sh / dn, B);
-            local_done = scratch[104] == 0.0 && (sync->no_coarse & 16u) == 0 && l_min < 1e6 && l_sec - l_min > need;
-            __syncthreads();  // scratch[100..] is rewritten by the grid-wide pass below
-            P_STAMP2(11);
+        if constexpr (SMALL) {  // the candidate's counts take the LDS slot of the member it replaces
+            uint4 q;
+            q.x = uint32_t(craw[0]) | (uint32_t(craw[1]) << 16);
+            q.y = uint32_t(craw[2]) | (uint32_t(craw[3]) << 16);
+            q.z = uint32_t(craw[4]) | (uint32_t(craw[5]) << 16);
+            q.w = uint32_t(craw[6]) | (uint32_t(craw[7]) << 16);
+            *reinterpret_cast<uint4 *>(s_rows + uint64_t(slot_low) * 4096 + uint32_t(tid) * 8) = q;
         }
-        if (!local_done) st.n_loo++;
         // S_new_i = clamp(S_i - low_i) + f_i.  The mirror block writes it, and the new member's
         // row, to global memory (it takes no job below, so this overlaps the others' arithmetic).
         if (lead) {
@@ -1712,12 +1739,10 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             // accepts ago) before it arrived at this window's first barrier
             // (all eight group replicas; the stores are acknowledged before this block's next
             // barrier arrival, and nobody adds to that slot before that barrier has completed)
-            if (!local_done) {
-                unsigned long long *nx = part + uint64_t((acc_slot + 1) % 3) * 8 * (maxn + 1) * 2;
-                for (uint32_t i = tid; i < 8u * (n + 1) * 2u; i += P_THREADS) {
-                    const uint32_t g = i / ((n + 1) * 2u), w = i % ((n + 1) * 2u);
-                    __hip_atomic_store(nx + (uint64_t(g) * (maxn + 1)) * 2 + w, 0ull, RLX_AGENT);
-                }
+            unsigned long long *nx = part + uint64_t((acc_slot + 1) % 3) * 8 * (maxn + 1) * 2;
+            for (uint32_t i = tid; i < 8u * (n + 1) * 2u; i += P_THREADS) {
+                const uint32_t g = i / ((n + 1) * 2u), w = i % ((n + 1) * 2u);
+                __hip_atomic_store(nx + (uint64_t(g) * (maxn + 1)) * 2 + w, 0ull, RLX_AGENT);
             }
         }
         // ================= leave-one-out (get_lowest_record_index, records.rs:220-252, with
@@ -1731,7 +1756,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         unsigned long long *acc_all = part + uint64_t(acc_slot) * 8 * (maxn + 1) * 2;          // the slot's replicas
         const unsigned long long *acc = acc_all + uint64_t(blockIdx.x & 7u) * (maxn + 1) * 2;  // this group's
         bool first_job = true;
-        for (uint32_t job = blockIdx.x; job < jobs && has_job && !local_done; job += G) {
+        for (uint32_t job = blockIdx.x; job < jobs && has_job; job += G) {
             if (lead && one_job) break;
             const uint32_t r = job / K, part_i = job % K;
             const bool is_new = r == n - 1;
@@ -1755,7 +1780,20 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 if (u > 0.0) h -= u * log2_tab(u, s_ltab);
                 sv += u;
             };
-            if (CACHED) {
+            if constexpr (SMALL) {
+                // (from LDS and registers; the workgroup's one job may already be there, worked out for
+                // this very candidate while the rendezvous was completing)
+                if (job_published) continue;
+                double th, ts;
+                small_job(r, part_i, r, n, th, ts);
+                if (tid < 8) {  // lane g adds the job's words to group g's replica
+                    unsigned long long *dst = acc_all + (uint64_t(tid) * (maxn + 1) + r) * 2;
+                    atomicAdd(dst, p_acc_word(th));
+                    atomicAdd(dst + 1, p_acc_word(ts));
+                }
+                first_job = false;
+                continue;
+            } else if (CACHED) {
 #pragma unroll
                 for (int j = 0; j < P_J; j++) {
                     const uint64_t i = uint64_t(j) * P_THREADS + tid;
@@ -1830,17 +1868,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         uint32_t lowest;
         double dmin, dsecond;
         bool any_risky, ev_risky;
-        if (local_done) {
-            lowest = l_low;
-            dmin = l_min;
-            dsecond = l_sec;
-            st.total_jsd = l_tj;
-            any_risky = ev_risky = false;
-            delta_stale = true;  // (the mirror block refreshes the members' delta_jsd when the launch ends)
-            n_local++;
-            if (lead && tid == 0) ctl->total_jsd = l_tj;
-        } else if (n < 128) {
-            delta_stale = false;
+        if (n < 128) {
             // No barrier: one wave polls this group's replica (lane l holds members l and l + 64, entry
             // n is the whole set) until every word carries K contributions, takes the decisions and
             // hands them to the other waves through LDS.  Bounded like every other spin of the kernel.
@@ -2045,68 +2073,6 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         epoch++;
     }
 
-    // ---- SMALL: the members' delta_jsd as get_lowest_record_index leaves them (records.rs:220-252), in
-    // f64, by the mirror block alone from its LDS rows and the S it mirrored -- once per launch instead
-    // of once per accept.  Its argmin must be the member the f32 passes chose (their bands prove it): a
-    // disagreement, or a sum check that is not sure, ends the launch as a failed one and the selection
-    // starts over on the multi-launch engine.
-    if constexpr (SMALL) {
-        if (lead && delta_stale && exit_status != SEL_ERROR) {
-            const uint32_t n = st.n;
-            const double rdiv_x = 1.0 / (double(n) - 1.0);
-            double Sx[P_J];
-#pragma unroll
-            for (int j = 0; j < P_J; j++)  // (this workgroup's own stores of this launch, read past its L1)
-                Sx[j] = __longlong_as_double((long long)__hip_atomic_load(
-                    reinterpret_cast<unsigned long long *>(d.S) + uint64_t(j) * P_THREADS + tid, RLX_AGENT));
-            __syncthreads();
-            for (uint32_t r = 0; r < n; r++) {
-                const uint4 q = *reinterpret_cast<const uint4 *>(s_rows + uint64_t(s_slot[r]) * 4096 + uint32_t(tid) * 8);
-                const uint32_t cw[4] = {q.x, q.y, q.z, q.w};
-                const double mt = s_tot[r], mr = s_rt[r];
-                double h = 0.0, sv = 0.0;
-#pragma unroll
-                for (int j = 0; j < P_J; j++) {
-                    const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-                    double u = (Sx[j] - exact_div_u32(double(c), mt, mr)) * rdiv_x;  // updated_mean_freqs, records.rs:276-286
-                    if (u <= DVS_EPS) u = 0.0;
-                    if (u > 0.0) h -= u * log2_tab(u, s_ltab);
-                    sv += u;
-                }
-                h = dvs_wave_sum_dpp(h);
-                sv = dvs_wave_sum_dpp(sv);
-                if (lane == 0) {
-                    s_loo[r * 8 + wave] = h;
-                    s_loo[P_SMALLN * 8 + r * 8 + wave] = sv;
-                }
-            }
-            __syncthreads();
-            if (uint32_t(tid) < n) {
-                double h = 0.0, sv = 0.0;
-                for (int w = 0; w < 8; w++) {
-                    h += s_loo[tid * 8 + w];
-                    sv += s_loo[P_SMALLN * 8 + tid * 8 + w];
-                }
-                s_dl[tid] = st.total_jsd - (h - (st.sumH - s_mH[tid]) * rdiv_x);  // delta_jsd
-                s_ds[tid] = sv;
-            }
-            __syncthreads();
-            if (wave == 0) p_argmin<1>(s_dl, s_ds, n, B, lane, scratch);
-            __syncthreads();
-            if (uint32_t(scratch[101]) != st.li || scratch[105] != 0.0) exit_status = SEL_ERROR;
-            if (uint32_t(tid) < n) {
-                d.dtmp[tid] = s_dl[tid];
-                d.dsum[tid] = s_ds[tid];
-                d.mDelta[tid] = s_dl[tid];
-            }
-            if (tid == 0) {
-                ctl->mean_delta = scratch[103];
-                ctl->std_delta = scratch[104];
-                ctl->cov_delta = scratch[104] / scratch[103];
-            }
-        }
-        if (lead && tid == 0) ctl->n_local_loo += n_local;
-    }
     // ---- exit: counters, and the lead block's scalar mirror
     if (lane == 0 && nread) {
         atomicAdd(&ctl->rows_scored, (unsigned long long)nread);
@@ -2157,7 +2123,7 @@ static int persist_prepare(dvs_ctx *ctx, dvs_select *s, uint32_t head_stop, hipS
     init.seeded = s->persist_seeded ? 1u : 0u;  // (the first launch of a selection whose set-up kernels were skipped)
     init.seed_list = static_cast<const unsigned long long *>(s->d_seed_list);
     for (int i = 0; i < 3; i++)
-        for (int w = 0; w < 16; w++) init.ev[i][w * 16] = SEL_NONE;
+        for (int g = 0; g < 8; g++) init.ev[i][g * 32 + 1] = SEL_NONE;  // (event words; generations and flags 0)
     // a row per workgroup while a window is at most this many rounds of the grid (default policy only)
     init.wg_thresh = s->params.window ? 0u : 4u;
     init.wg_scale = 1.5f;
@@ -2165,7 +2131,7 @@ static int persist_prepare(dvs_ctx *ctx, dvs_select *s, uint32_t head_stop, hipS
     if (const char *e = getenv("DVS_PERSIST_WG_SCALE")) init.wg_scale = float(atof(e));
     init.no_coarse = (getenv("DVS_PERSIST_NO_COARSE") ? 1u : 0u) | (getenv("DVS_PERSIST_NO_EVENTS") ? 2u : 0u) |
                      (getenv("DVS_PERSIST_NO_BURST_DROP") ? 8u : 0u) |
-                     (getenv("DVS_PERSIST_NO_LOCAL_LOO") ? 16u : 0u);  // (SMALL: every accept takes the grid-wide f64 pass)
+                     (getenv("DVS_PERSIST_NO_SPECULATION") ? 16u : 0u);  // (SMALL: nothing is worked out ahead of the release)
     init.small_rows = s->persist_small ? s->persist_small_rows : 0u;
     DVS_HIP(ctx, hipMemcpyAsync(head_stop ? s->psync_head : s->psync, &init, sizeof init, hipMemcpyHostToDevice, on));
     DVS_HIP(ctx, hipMemsetAsync(head_stop ? s->ppart_head : s->ppart, 0, p_acc_bytes(s->persist_maxn), on));
@@ -2249,7 +2215,7 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     };
     size_t lds = lds_for(p_maxn(cached));
     if (s->persist_small) {
-        const size_t lds_small = lds_for(P_SMALLN) + P_SMALL_LOO * 8 + size_t(s->persist_small_rows) * B * 2 + 16;
+        const size_t lds_small = lds_for(P_SMALLN) + size_t(s->persist_small_rows) * B * 2 + 16;
         if (lds_small <= ctx->lds_per_block) lds = lds_small;
         else s->persist_small = false;
     }

@@ -28,7 +28,6 @@ struct SelCtl {
     uint32_t s_is_resum;  // S still equals the members' rows added up in member order (only pushes so far)
     uint32_t n_windows, n_events, n_accepts;
     uint32_t n_logged;  // entries of the event log (accepted set changes, for the arbiter)
-    uint32_t n_local_loo;  // accepts whose new lowest member the persistent engine's workgroups worked out locally (SMALL)
     double total_jsd, sum_entropy;      // records.rs: total_jsd, summed_entropies
     double thr, band;                   // total_jsd + eps ; width of the undecidable zone
     double he_base;                     // summed_entropies - H(lowest)

@@ -942,9 +942,6 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
                             dbg[2 + 16 * w] / 100.0, dbg[3 + 16 * w] / 100.0, dbg[4 + 16 * w] / 100.0,
                             dbg[6 + 16 * w] / 100.0, dbg[7 + 16 * w] / 100.0, dbg[8 + 16 * w] / 100.0,
                             dbg[5 + 16 * w] / 100.0);
-                if (dbg[9] + dbg[10] + dbg[11])
-                    fprintf(stderr, "[dvs persist block 0] local leave-one-out us: S' + H(S'/n) %.1f, members (f32) %.1f, decide %.1f\n",
-                            dbg[9] / 100.0, dbg[10] / 100.0, dbg[11] / 100.0);
                 if (dbg[16 + 10] + dbg[16 + 12])
                     fprintf(stderr, "[dvs persist] scan + rendezvous: row-per-workgroup windows %llu (%.1f us, %llu rows), "
                             "row-per-wave windows %llu (%.1f us, %llu rows)\n", dbg[16 + 10], dbg[16 + 9] / 100.0,
@@ -1414,7 +1411,6 @@ extern "C" int dvs_select_get_summary(dvs_ctx *ctx, const dvs_select *s, dvs_sel
     out->scan_launches = s->scan_launches;
     out->engine = s->persist ? 1u : 0u;
     out->rows_coarse_passed = uint32_t(std::min<unsigned long long>(c.rows_coarse_passed, 0xFFFFFFFFull));
-    out->n_local_loo = c.n_local_loo;
     return DVS_OK;
 }
 

@@ -183,7 +183,6 @@ typedef struct dvs_select_summary {
     uint64_t scan_launches;  /* scan-kernel launches the events bracket (no-op launches included) */
     uint32_t engine;         /* 0: one scan launch per window + state kernels; 1: persistent single launch */
     uint32_t rows_coarse_passed; /* persistent engine: rows its all-f32 tier could not decide (scored again by the f32-log tier) */
-    uint32_t n_local_loo;    /* persistent engine, small sets: accepts whose new lowest member every workgroup worked out from its own LDS (f32 leave-one-out inside proven bands) */
 } dvs_select_summary;
 
 int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t *order,
