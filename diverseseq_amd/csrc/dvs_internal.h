@@ -74,6 +74,9 @@ struct dvs_ctx {
         void *d_off = nullptr, *d_rows = nullptr, *d_tiles = nullptr;
         size_t d_off_cap = 0;
         size_t n_long = 0, n_tiles = 0;
+        // the last build's sequences all had one length and lay end to end: no offsets on the device
+        bool uniform = false;
+        uint64_t uni_base = 0, uni_stride = 0;
     } off_cache;
 };
 // hipFuncAttributeMaxDynamicSharedMemorySize >= bytes for kernel fn on this context's device

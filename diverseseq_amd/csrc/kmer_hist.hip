@@ -107,7 +107,7 @@ __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
     const uint8_t *__restrict__ seqs, uint64_t nbytes, const uint64_t *__restrict__ offsets,
     const KTile *__restrict__ tiles, uint32_t *__restrict__ counts, uint32_t *__restrict__ totals,
     double *__restrict__ entropy, const double *__restrict__ clog_tbl, uint32_t k, uint32_t ns,
-    uint64_t B, uint32_t hot_rows, uint32_t row0) {
+    uint64_t B, uint32_t hot_rows, uint32_t row0, uint64_t uni_base, uint64_t uni_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KTile t;
     if (tiles) {
@@ -116,7 +116,9 @@ __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
         // this launch builds rows row0 .. row0 + gridDim.x - 1; rows below hot_rows are built LAST and
         // with ordinary stores (the next reader comes soon)
         const uint32_t r = row0 + (hot_rows ? gridDim.x - 1 - blockIdx.x : blockIdx.x);
-        const uint64_t s0 = offsets[r], s1 = offsets[r + 1];
+        // (offsets == NULL: sequences of one length laid end to end -- nothing was uploaded)
+        const uint64_t s0 = offsets ? offsets[r] : uni_base + uint64_t(r) * uni_stride;
+        const uint64_t s1 = offsets ? offsets[r + 1] : s0 + uni_stride;
         t.row = r;
         t.single = 1;
         t.seq_begin = s0;
@@ -494,6 +496,32 @@ int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint3
                      size_t *n_long_out) {
     dvs_ctx::OffsetsCache &oc = ctx->off_cache;
     const size_t n_off = size_t(nseq) + 1;
+    // Sequences of ONE length laid end to end (fixed-length reads, amplicons, synthetic sets) need no
+    // offsets on the device at all: the kernel derives row r's span from (base, stride).  One read-only
+    // pass decides (it stops at the first span of another length), nothing is copied or uploaded.
+    oc.uniform = false;
+    if (nseq >= 1 && !getenv("DVS_NO_UNIFORM_OFFSETS")) {
+        const uint64_t base = offsets[0], stride = offsets[1] - offsets[0];
+        bool uni = offsets[1] >= offsets[0] && stride < uint64_t(TILE_LEN) + k;
+        uint64_t diff = 0;
+        for (uint32_t r = 0; r < nseq && uni; r += 4096) {  // (blocks: vectorised, with an early way out)
+            const uint32_t e = std::min<uint32_t>(nseq, r + 4096);
+            for (uint32_t q = r; q < e; q++) diff |= (offsets[q + 1] - offsets[q]) ^ stride;
+            uni = diff == 0;
+        }
+        if (uni && base + uint64_t(nseq) * stride <= nbytes) {
+            dvs_dev_free(ctx, oc.d_rows);
+            dvs_dev_free(ctx, oc.d_tiles);
+            oc.d_rows = oc.d_tiles = nullptr;
+            oc.n_long = oc.n_tiles = 0;
+            oc.n_off = 0;  // (no entry of the content cache: the next non-uniform build starts afresh)
+            oc.uniform = true;
+            oc.uni_base = base;
+            oc.uni_stride = stride;
+            *n_long_out = 0;
+            return DVS_OK;
+        }
+    }
     const bool hit = oc.d_off && oc.h_off && oc.k == k && oc.nbytes == nbytes && oc.n_off == n_off &&
                      !getenv("DVS_NO_OFFSETS_CACHE") && std::memcmp(oc.h_off, offsets, n_off * 8) == 0;
     if (!hit) {
@@ -617,7 +645,8 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
     const bool ns4 = ns == 4;
     (void)offsets;
     dvs_ctx::OffsetsCache &oc = ctx->off_cache;
-    uint64_t *d_off = static_cast<uint64_t *>(oc.d_off);
+    uint64_t *d_off = oc.uniform ? nullptr : static_cast<uint64_t *>(oc.d_off);
+    const uint64_t uni_base = oc.uni_base, uni_stride = oc.uni_stride;
     uint32_t *d_rows = static_cast<uint32_t *>(oc.d_rows);
     KTile *d_tiles = static_cast<KTile *>(oc.d_tiles);
     const size_t n_long = oc.n_long, n_tiles = oc.n_tiles;
@@ -650,7 +679,7 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
         if (!rc)                                                                                 \
             hipLaunchKernelGGL((kmer_hist_kernel<NS4, LH, false>), dim3(GRID), dim3(NTHR), lds,  \
                                ctx->stream, d_seqs, nbytes, d_off, TILES, m->d_counts,           \
-                               m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, HOT, 0u);   \
+                               m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, HOT, 0u, uni_base, uni_stride);   \
     } while (0)
 #define DVS_LAUNCH_HIST_ANY(GRID, TILES, NTHR, HOT)                            \
     do {                                                                  \
@@ -688,13 +717,13 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
                 if (!rc)
                     hipLaunchKernelGGL((kmer_hist_kernel<true, true, true, true>), dim3(count), dim3(128), lds16, on,
                                        d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), out16,
-                                       m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_end, row0);
+                                       m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_end, row0, uni_base, uni_stride);
             } else {
                 rc = set_dyn_lds(ctx, kmer_hist_kernel<false, true, true, true>, lds16);
                 if (!rc)
                     hipLaunchKernelGGL((kmer_hist_kernel<false, true, true, true>), dim3(count), dim3(128), lds16, on,
                                        d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), out16,
-                                       m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_end, row0);
+                                       m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_end, row0, uni_base, uni_stride);
             }
         };
         if (head_rows) {
@@ -756,13 +785,13 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
             if (!rc)
                 hipLaunchKernelGGL((kmer_hist_kernel<true, true, true>), dim3(nseq), dim3(128), lds16, ctx->stream,
                                    d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), m->d_counts,
-                                   m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_rows, 0u);
+                                   m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_rows, 0u, uni_base, uni_stride);
         } else {
             rc = set_dyn_lds(ctx, kmer_hist_kernel<false, true, true>, lds16);
             if (!rc)
                 hipLaunchKernelGGL((kmer_hist_kernel<false, true, true>), dim3(nseq), dim3(128), lds16, ctx->stream,
                                    d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), m->d_counts,
-                                   m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_rows, 0u);
+                                   m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_rows, 0u, uni_base, uni_stride);
         }
     } else
         DVS_LAUNCH_HIST_ANY(nseq, static_cast<const KTile *>(nullptr), nthreads, hot_rows);

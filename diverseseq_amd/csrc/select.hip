@@ -933,9 +933,12 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
             }
             s->ev_used = 0;
         }
-        if (s->persist && s->psync && getenv("DVS_PERSIST_DEBUG")) {
+        for (int which = 0; which < 2 && s->persist && getenv("DVS_PERSIST_DEBUG"); which++) {
             unsigned long long dbg[32];
-            if (hipMemcpy(dbg, static_cast<char *>(s->psync) + dvs_persist_dbg_offset(), sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
+            void *blk = which ? s->psync : s->psync_head;  // (the head phase's launch first, then the full grid's)
+            if (!blk) continue;
+            if (hipMemcpy(dbg, static_cast<char *>(blk) + dvs_persist_dbg_offset(), sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
+                fprintf(stderr, "[dvs persist] %s launch\n", which ? "full-grid" : "head-phase");
                 for (int w = 0; w < 2; w++)
                     fprintf(stderr, "[dvs persist %s] us: scan %.1f bar1 %.1f resolve %.1f loo %.1f bar2 %.1f | partials %.1f combine %.1f lowest-row fetch %.1f rebuild %.1f\n",
                             w ? "mirror block" : "block 0", dbg[0 + 16 * w] / 100.0, dbg[1 + 16 * w] / 100.0,

@@ -541,3 +541,26 @@ def test_stepwise_selection_without_an_order_array(ctx):
     _assert_selection(sel, exp)
     sel.close()
     m.close()
+
+
+def test_uniform_length_builds_need_no_offsets_on_the_device(ctx, monkeypatch):
+    """Sequences of one length laid end to end are built from (base, stride) with nothing uploaded; the
+    rows are those of the offsets path (and of count_kmers, src/record.rs:41-84), also with a leading gap
+    in front of the first sequence, a length below k, and a single sequence."""
+    rng = np.random.default_rng(2026)
+    for nseq, length, k, lead in ((700, 333, 5, 0), (64, 1000, 6, 48), (5, 3, 4, 0), (1, 900, 3, 16)):
+        data = rng.integers(0, 4, size=lead + nseq * length, dtype=np.uint8)
+        data[rng.integers(0, data.size, size=max(1, data.size // 500))] = 4
+        offs = (lead + np.arange(nseq + 1, dtype=np.uint64) * np.uint64(length)).astype(np.uint64)
+        m = ctx.build_matrix_concat(data, offs, k, 4)
+        got = m.counts()
+        m.close()
+        monkeypatch.setenv("DVS_NO_UNIFORM_OFFSETS", "1")
+        m2 = ctx.build_matrix_concat(data, offs, k, 4)
+        ref = m2.counts()
+        m2.close()
+        monkeypatch.delenv("DVS_NO_UNIFORM_OFFSETS")
+        assert (got == ref).all()
+        for i in (0, nseq // 2, nseq - 1):
+            a = lead + i * length
+            assert (got[i] == oracle.count_kmers(data[a:a + length], 4, k)).all()
