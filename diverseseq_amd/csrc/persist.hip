@@ -163,9 +163,9 @@ __device__ bool grid_barrier(PSync *sync, uint32_t G, uint32_t &gen, int *s_ok) 
     return *s_ok != 0;
 }
 
-// The same rendezvous in two halves, for work that can be done while the others are still on their
-// way: grid_arrive announces this workgroup (and releases everybody if it is the last), grid_wait
-// waits for the release.  s_ok[1] carries "released by this workgroup" between the two.
+// A window's rendezvous comes in two halves, for work that can be done while the others are still on their
+// way: grid_arrive announces this workgroup (and releases everybody if it is the last); the event loop
+// itself waits for the release (it has work to do meanwhile).
 // 16 bytes in one agent-scope load (one request: a consistent view of a record)
 __device__ __forceinline__ uint4 p_load16_agent(const void *ptr) {
     uint4 v;
@@ -188,32 +188,6 @@ __device__ void grid_arrive(PSync *sync, uint32_t G, uint32_t gen, unsigned long
         }
     }
 }
-// -> s_out[0] = the event word (bits), s_out[1] = the listed flag; false on timeout
-__device__ bool grid_wait(PSync *sync, uint32_t &gen, int *s_ok, const unsigned long long *rec, double *s_out) {
-    if (threadIdx.x == 0) {
-        const uint32_t target = gen + 1;
-        int ok = 1;
-        uint32_t spins = 0;
-        uint4 v = p_load16_agent(rec);
-        while (v.x < target) {
-            if ((++spins & 255u) == 0 &&
-                (spins > P_SPIN_LIMIT || __hip_atomic_load(&sync->timeout, RLX_AGENT))) {
-                __hip_atomic_store(&sync->timeout, 1u, RLX_AGENT);
-                ok = 0;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-            v = p_load16_agent(rec);
-        }
-        s_out[0] = __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z));
-        s_out[1] = double(v.y);
-        *s_ok = ok;
-    }
-    __syncthreads();
-    gen++;
-    return *s_ok != 0;
-}
-
 // publishing an event: every group copy of the slot (evs = its base)
 __device__ __forceinline__ unsigned long long p_ev_word(uint64_t p, bool sure) {
     return ((unsigned long long)p << 1) | (sure ? 0ull : 1ull);
@@ -748,6 +722,10 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                                                                     PSync *sync, unsigned long long *part, uint32_t G) {
     static_assert(!SMALL || (CACHED && !MAXM && sizeof(T) == 2), "SMALL: nmost, 16-bit rows, state in the register cache");
     constexpr uint32_t maxn = SMALL ? P_SMALLN : p_maxn(CACHED);
+    // SPEC: nmost over a count matrix whose rows fit the register cache -- the accept's first steps (the
+    // candidate's row, its frequencies, this workgroup's leave-one-out job) are taken while the window's
+    // rendezvous is still completing (see the event loop)
+    constexpr bool SPEC = CACHED && !MAXM && sizeof(T) <= 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint64_t B0 = d.B;
     const uint64_t B = B0;  // (the event loop below takes its own, laundered copy)
@@ -1137,7 +1115,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                                        nrows, lane, nread, nprecise, nmid, coarse_on,
                                        (sync->no_coarse & 8u) == 0);
         }
-        // SMALL: the candidate this window will most likely end with -- the event word as it stands when
+        // SPEC: the candidate this window will most likely end with -- the event word as it stands when
         // this workgroup leaves the scan -- is taken up BEFORE the rendezvous has completed: its counts,
         // total and entropy are requested ahead of the arrival (the row's memory round trip runs beside the
         // barrier, not behind it), and between arrival and release the workgroup already converts them to
@@ -1157,32 +1135,48 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             if (craw_pos != q) {
                 const T *gp = mat + q * B;
 #pragma unroll
-                for (int j = 0; j < P_J; j++) craw[j] = gp[uint64_t(j) * P_THREADS + tid];
+                for (int j = 0; j < P_J; j++) {
+                    const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                    craw[j] = i < B ? gp[i] : T(0);
+                }
                 craw_tot = d.totals[q];
                 craw_H = d.rowH[q];
                 craw_pos = q;
             }
         };
-        // one leave-one-out job of an accept, SMALL form (everything from LDS and registers): member
-        // r of the NEW order over this thread's bins j with j % K == part -- the whole new set for
-        // r == n, the candidate itself for r == n - 1, else the member whose replica arrays sit at index
-        // `at` (before the order has been shifted that is r or r + 1, afterwards r); -> this workgroup's
-        // sums on threads 0..7 (updated_mean_freqs, records.rs:276-286)
+        // one leave-one-out job of an accept, SPEC form: member r of the NEW order over this thread's
+        // bins j with j % K == part -- the whole new set for r == n, the candidate itself for r == n - 1,
+        // else the member whose replica arrays sit at index `at` (before the order has been shifted that
+        // is r or r + 1, afterwards r), its counts from LDS (SMALL) or from its matrix row; -> this
+        // workgroup's sums on threads 0..7 (updated_mean_freqs, records.rs:276-286)
         [[maybe_unused]] auto small_job = [&](uint32_t r, uint32_t part_i, uint32_t at, uint32_t n_, double &th, double &ts) {
             const double dn_ = double(n_), rn_ = 1.0 / dn_, rdiv_ = 1.0 / (dn_ - 1.0);
             const bool is_new = r == n_ - 1;
-            uint4 q = make_uint4(0u, 0u, 0u, 0u);
+            uint32_t mcv[P_J];
+#pragma unroll
+            for (int j = 0; j < P_J; j++) mcv[j] = 0u;
             double mtot = 1.0, mrt = 1.0;
             if (r < n_ && !is_new) {
-                q = *reinterpret_cast<const uint4 *>(s_rows + uint64_t(s_slot[at]) * 4096 + uint32_t(tid) * 8);
+                if constexpr (SMALL) {
+                    const uint4 q = *reinterpret_cast<const uint4 *>(s_rows + uint64_t(s_slot[at]) * 4096 + uint32_t(tid) * 8);
+                    const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int j = 0; j < P_J; j++) mcv[j] = (qw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                } else {
+                    const T *mrow = mat + s_pos[at] * B;
+#pragma unroll
+                    for (int j = 0; j < P_J; j++) {
+                        const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                        if ((uint32_t(j) & (K - 1)) == part_i && i < B) mcv[j] = uint32_t(mrow[i]);
+                    }
+                }
                 mtot = s_tot[at];
                 mrt = s_rt[at];
             }
-            const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
             double h = 0.0, sv = 0.0;
 #pragma unroll
             for (int j = 0; j < P_J; j++) {
-                if ((uint32_t(j) & (K - 1)) == part_i) {
+                if ((uint32_t(j) & (K - 1)) == part_i && uint64_t(j) * P_THREADS + tid < B) {
                     double v = sl[uint64_t(j) * P_THREADS + tid];
                     if (v <= DVS_EPS) v = 0.0;
                     const double sn = v + fr[j];
@@ -1190,8 +1184,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     if (r == n_) {
                         u = sn * rn_;
                     } else {
-                        const uint32_t c = (qw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-                        u = (sn - (is_new ? fr[j] : exact_div_u32(double(c), mtot, mrt))) * rdiv_;
+                        u = (sn - (is_new ? fr[j] : exact_div_u32(double(mcv[j]), mtot, mrt))) * rdiv_;
                         if (u <= DVS_EPS) u = 0.0;
                     }
                     if (u > 0.0) h -= u * log2_tab(u, s_ltab);
@@ -1214,36 +1207,63 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 }
             }
         };
-        if constexpr (SMALL) {
+        if constexpr (SPEC) {
             const uint64_t guess = p_ev_pos(__hip_atomic_load(evp, RLX_AGENT));
-            if (guess != SEL_NONE) fetch_raw(guess);
-            // (the waves of a workgroup leave the scan at different times and may have read different
-            // words: each hands its own over through LDS, behind the barrier that opens the arrival)
-            if (lane == 0) scratch[112 + wave] = __longlong_as_double((long long)guess);
+            if (guess != SEL_NONE) fetch_raw(guess);  // (per wave: whatever it saw when it left the scan)
         }
         P_STAMP(0);
         grid_arrive(sync, G, gen, evs);
-        if constexpr (SMALL) {
-            {   // the workgroup's common view: the earliest event any of its waves saw
-                uint64_t g = SEL_NONE;
-#pragma unroll
-                for (uint32_t w = 0; w < P_THREADS / 64; w++) g = umin64(g, (uint64_t)__double_as_longlong(scratch[112 + w]));
-                if (g != SEL_NONE) fetch_raw(g);
-                else craw_pos = SEL_NONE;
-            }
-            if (craw_pos != SEL_NONE && (sync->no_coarse & 16u) == 0) {
-                const double t_ = double(craw_tot), rt_ = 1.0 / t_;
-#pragma unroll
-                for (int j = 0; j < P_J; j++) fr[j] = count_freq_x(craw[j], t_, rt_);
-                fr_pos = craw_pos;
-                if (one_job && has_job && !lead) {
-                    const uint32_t r = blockIdx.x / K;
-                    small_job(r, blockIdx.x % K, r < st.li ? r : r + 1, st.n, spec_th, spec_ts);
-                    spec_job_pos = craw_pos;
+        // ---- wait for the release.  Thread 0 polls this group's record (16 bytes: generation, listed flag,
+        // first event) and hands every look to the workgroup; SPEC: as soon as the record names a
+        // candidate -- usually well before the last workgroup has arrived -- the workgroup takes it up.
+        unsigned long long hard_w = SEL_NONE;
+        bool any_listed = false, bar_ok = true;
+        {
+            const uint32_t target = gen + 1;
+            uint32_t spins = 0;
+            for (;;) {
+                if (tid == 0) {
+                    const uint4 v = p_load16_agent(evrec);
+                    int ok = 1;
+                    if (v.x < target && (++spins & 255u) == 0 &&
+                        (spins > P_SPIN_LIMIT || __hip_atomic_load(&sync->timeout, RLX_AGENT))) {
+                        __hip_atomic_store(&sync->timeout, 1u, RLX_AGENT);
+                        ok = 0;
+                    }
+                    scratch[121] = __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z));
+                    scratch[122] = double(v.y);
+                    scratch[123] = v.x >= target ? 1.0 : 0.0;
+                    s_flag[0] = ok;
                 }
+                __syncthreads();
+                hard_w = (unsigned long long)__double_as_longlong(scratch[121]);
+                any_listed = scratch[122] != 0.0;
+                const bool released = scratch[123] != 0.0;
+                bar_ok = s_flag[0] != 0;
+                __syncthreads();  // (thread 0 rewrites the slots in the next round)
+                if (released || !bar_ok) break;
+                bool worked = false;
+                if constexpr (SPEC) {
+                    const uint64_t seen = p_ev_pos(hard_w);
+                    if (seen != SEL_NONE && seen != fr_pos && (sync->no_coarse & 16u) == 0) {
+                        fetch_raw(seen);
+                        const double t_ = double(craw_tot), rt_ = 1.0 / t_;
+#pragma unroll
+                        for (int j = 0; j < P_J; j++) fr[j] = count_freq_x(craw[j], t_, rt_);
+                        fr_pos = seen;
+                        if (one_job && has_job && !lead && st.n < 128) {
+                            const uint32_t r = blockIdx.x / K;
+                            small_job(r, blockIdx.x % K, r < st.li ? r : r + 1, st.n, spec_th, spec_ts);
+                            spec_job_pos = seen;
+                        }
+                        worked = true;
+                    }
+                }
+                if (!worked) __builtin_amdgcn_s_sleep(1);
             }
+            gen++;
         }
-        if (!grid_wait(sync, gen, s_flag, evrec, scratch + 121)) { exit_status = SEL_ERROR; break; }
+        if (!bar_ok) { exit_status = SEL_ERROR; break; }
         P_STAMP(1);
 #ifdef DVS_PERSIST_STAMPS
         if (lead && tid == 0) {  // scan + rendezvous time and window count by scan mode, rows per mode
@@ -1255,10 +1275,9 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
 #endif
         // the window's outcome came with the release (grid_wait): no further round trip, except for the
         // list of near-threshold candidates when there is one
-        const unsigned long long hard_w = (unsigned long long)__double_as_longlong(scratch[121]);
         const uint64_t hard = p_ev_pos(hard_w);
         const bool hard_is_sure = hard_w != SEL_NONE && (hard_w & 1ull) == 0;
-        const uint64_t nlisted = scratch[122] != 0.0 ? __hip_atomic_load(&sync->soft[epoch % 3][0], RLX_AGENT) : 0ull;
+        const uint64_t nlisted = any_listed ? __hip_atomic_load(&sync->soft[epoch % 3][0], RLX_AGENT) : 0ull;
         st.n_windows++;
         // this workgroup's leave-one-out job, should the window end in an accept: the member's
         // counts are requested now (its row does not depend on the event), in the same memory
@@ -1267,7 +1286,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         const uint32_t job_r = one_job ? blockIdx.x / K : 0u, job_part = one_job ? blockIdx.x % K : 0u;
         T mc[P_J];
         double job_tot = 1.0, job_rt = 1.0;
-        if (CACHED && !SMALL && one_job && has_job && job_r + 1 < st.n) {
+        if (CACHED && !SPEC && one_job && has_job && job_r + 1 < st.n) {
             const uint32_t old = job_r < st.li ? job_r : job_r + 1;
             const T *mrow = mat + s_pos[old] * B;
             job_tot = s_tot[old];
@@ -1288,7 +1307,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         const T *rp = mat;
         double jsd = 0.0, sm = 1.0;
         auto evaluate = [&](uint64_t q) {  // exact score of candidate q, by the whole workgroup
-            if constexpr (SMALL) {
+            if constexpr (SPEC) {
                 fetch_raw(q);
                 tot = double(craw_tot);
                 cand_H = craw_H;
@@ -1306,7 +1325,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     const uint64_t i = b0 + uint64_t(j) * P_THREADS + tid;
                     if (i < B) {
                         double f;
-                        if constexpr (SMALL) f = count_freq_x(craw[j], tot, rtot);
+                        if constexpr (SPEC) f = count_freq_x(craw[j], tot, rtot);
                         else f = cand_freq_x(rp, i, tot, rtot);
                         if (CACHED) fr[j] = f;
                         e.add((sl[i] + f) * rn, s_ltab);
@@ -1365,7 +1384,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             // sum passed its guard at the last finalize.
             const bool sure = hard_is_sure;
             if (sure) {
-                if constexpr (SMALL) {
+                if constexpr (SPEC) {
                     fetch_raw(p);
                     tot = double(craw_tot);
                     cand_H = craw_H;
@@ -1375,7 +1394,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 }
                 rp = mat + p * B;
                 rtot = 1.0 / tot;
-                if constexpr (SMALL) {
+                if constexpr (SPEC) {
                     if (fr_pos != p) {  // (else: worked out while the rendezvous was completing)
 #pragma unroll
                         for (int j = 0; j < P_J; j++) fr[j] = count_freq_x(craw[j], tot, rtot);
@@ -1615,10 +1634,10 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         const uint32_t acc_slot = st.n_loo % 3;
         st.n_loo++;
         st.n_accepts++;
-        // SMALL: a leave-one-out job worked out for this very candidate while the rendezvous was completing
+        // SPEC: a leave-one-out job worked out for this very candidate while the rendezvous was completing
         // goes out FIRST -- its memory-side additions travel while the member arrays are shifted below
         [[maybe_unused]] bool job_published = false;
-        if constexpr (SMALL) {
+        if constexpr (SPEC) {
             if (one_job && has_job && !lead && spec_job_pos == p) {
                 if (tid < 8) {  // lane g adds the job's words to group g's replica
                     unsigned long long *dst = part + uint64_t(acc_slot) * 8 * (maxn + 1) * 2 +
@@ -1760,7 +1779,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             if (lead && one_job) break;
             const uint32_t r = job / K, part_i = job % K;
             const bool is_new = r == n - 1;
-            const bool pre = CACHED && !SMALL && one_job;  // member counts already requested above
+            const bool pre = CACHED && !SPEC && one_job;  // member counts already requested above
             const uint64_t mp = r < n ? s_pos[r] : 0;
             const T *mrow = mat + mp * B;
             const double mtot = pre ? job_tot : (r < n ? s_tot[r] : 1.0);
@@ -1780,9 +1799,9 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 if (u > 0.0) h -= u * log2_tab(u, s_ltab);
                 sv += u;
             };
-            if constexpr (SMALL) {
-                // (from LDS and registers; the workgroup's one job may already be there, worked out for
-                // this very candidate while the rendezvous was completing)
+            if constexpr (SPEC) {
+                // (the workgroup's one job may already be there, worked out for this very candidate while
+                // the rendezvous was completing)
                 if (job_published) continue;
                 double th, ts;
                 small_job(r, part_i, r, n, th, ts);
