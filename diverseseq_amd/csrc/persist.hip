@@ -1055,12 +1055,18 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     }
     if (sync->no_coarse & 2u) st.thr = 1e300;  // measurement aid: no row is ever an event (pure streaming)
 #ifdef DVS_PERSIST_STAMPS  // per-phase in-kernel timing (DVS_PERSIST_DEBUG prints it): costs registers
+    // (accumulated in LDS by thread 0 of block 0 and of the mirror block, written out when the launch
+    // ends: a stamp costs a clock read and an LDS add, not a memory round trip)
+    unsigned long long *s_dbg = SMALL ? reinterpret_cast<unsigned long long *>(s_rows + uint64_t(sync->small_rows) * 4096)
+                                      : reinterpret_cast<unsigned long long *>(s_ltab + 128);
+    if (tid < 16) s_dbg[tid] = 0ull;
+    __syncthreads();
     unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
 #define P_STAMP(k)                                                         \
     do {                                                                   \
         if ((lead || blockIdx.x == 0) && tid == 0) {                       \
             const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); \
-            (lead ? sync->dbg : sync->dbg2)[k] += t_now - t_prev;          \
+            s_dbg[k] += t_now - t_prev;                                    \
             t_prev = t_now;                                                \
         }                                                                  \
     } while (0)
@@ -1268,9 +1274,9 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
 #ifdef DVS_PERSIST_STAMPS
         if (lead && tid == 0) {  // scan + rendezvous time and window count by scan mode, rows per mode
             const unsigned long long t_w = __builtin_amdgcn_s_memrealtime();
-            sync->dbg[wgmode ? 9 : 11] += t_w - t_window;
-            sync->dbg[wgmode ? 10 : 12] += 1;
-            sync->dbg[wgmode ? 13 : 14] += nrows;
+            s_dbg[wgmode ? 9 : 11] += t_w - t_window;
+            s_dbg[wgmode ? 10 : 12] += 1;
+            s_dbg[wgmode ? 13 : 14] += nrows;
         }
 #endif
         // the window's outcome came with the release (grid_wait): no further round trip, except for the
@@ -2092,6 +2098,10 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         epoch++;
     }
 
+#ifdef DVS_PERSIST_STAMPS
+    if ((lead || blockIdx.x == 0) && tid == 0)
+        for (int k_ = 0; k_ < 16; k_++) (lead ? sync->dbg : sync->dbg2)[k_] += s_dbg[k_];
+#endif
     // ---- exit: counters, and the lead block's scalar mirror
     if (lane == 0 && nread) {
         atomicAdd(&ctl->rows_scored, (unsigned long long)nread);
@@ -2230,7 +2240,7 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     auto lds_for = [&](uint32_t maxn_) {
         return ((B + 1) & ~1ull) * 8 + (cached && s->mat_kind != 1 ? ((B + 3) & ~3ull) * 4 : 0) +
                (maxm ? ((B + 1) & ~1ull) * 8 : 0) + 128 * 8 + size_t(maxn_) * 52 + 8 + P_SOFT * 8 + 64 +
-               128 * 16;  // (+ log2_tab's table)
+               128 * 16 + 128;  // (+ log2_tab's table, + the stamps of a -DDVS_PERSIST_STAMPS build)
     };
     size_t lds = lds_for(p_maxn(cached));
     if (s->persist_small) {
