@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""The persistent kernel as a pure stream (bench.py's `persist_streaming` side run on its own): the
+north-star matrix, a threshold no row reaches, ONE launch over the whole stream -- for profiler passes
+in which every launch of the kernel is such a pass.  Prints the best launch-to-exit time (HIP events)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+os.environ.update({"DVS_PERSIST_NO_EVENTS": "1", "DVS_PERSIST_WG_ROUNDS": "0", "DVS_WINDOW_SCALE": "100000",
+                   "DVS_NO_HEAD_PHASE": "1", "DVS_PERSIST_NO_SEEDED": "1"})
+from diverseseq_amd import engine  # noqa: E402
+
+nseq, length, k, n = 100_000, 5_000, 6, int(sys.argv[1]) if len(sys.argv) > 1 else 10
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev)
+g.manual_seed(20260421)
+seqs = torch.randint(0, 4, (nseq * length,), dtype=torch.uint8, device=dev, generator=g)
+offsets = np.arange(nseq + 1, dtype=np.uint64) * np.uint64(length)
+torch.cuda.synchronize()
+ctx = engine.Context(0)
+ctx.set_timing(True)
+best = None
+for _ in range(6):
+    m = ctx.build_matrix_device(seqs.data_ptr(), offsets, k, 4)
+    sel = m.nmost(n)
+    s = sel.summary()
+    if s.engine == 1 and s.scan_launches == 1 and (best is None or s.scan_ms < best[0]):
+        best = (s.scan_ms, s.rows_scored)
+    sel.close()
+    m.close()
+print({"persist_stream_ms": best[0], "rows": best[1], "GBps": best[1] * 4096 * 2 / best[0] / 1e6})
