@@ -183,11 +183,13 @@ def main():
     # does.  The headline is therefore timed with that cache OFF: every step validates and uploads
     # its offsets as a first build would; the cached number is reported beside it.
     os.environ["DVS_NO_OFFSETS_CACHE"] = "1"
+    ctx.refresh_knobs()  # (the library reads its switches once per context, and on this call)
     for _ in range(a.warmup):
         step(False)
     ctx.set_timing(True)  # HIP-event pairs around every scan launch, read after the run
     elapsed = timed_loop(True)
     del os.environ["DVS_NO_OFFSETS_CACHE"]
+    ctx.refresh_knobs()
     step(False)
     elapsed_cached = timed_loop(False)
 
@@ -204,6 +206,7 @@ def main():
                  "DVS_NO_HEAD_PHASE": "1", "DVS_PERSIST_NO_SEEDED": "1"}  # (ONE launch over the whole stream, set up by the set-up kernels)
         saved = {k_: os.environ.get(k_) for k_ in knobs}
         os.environ.update(knobs)
+        ctx.refresh_knobs()
         try:
             best = None
             for _ in range(3):
@@ -222,6 +225,7 @@ def main():
                     os.environ.pop(k_, None)
                 else:
                     os.environ[k_] = v_
+            ctx.refresh_knobs()
         if world == 1:
             # also outside the timed region: the same workload through the drop-in module, as a caller of
             # the reference's API sees it (diverse_seq._dvs.nmost_divergent(store, n, k), src/lib.rs:59-73):

@@ -28,7 +28,7 @@ ROW_REMOTE = 0xFFFFFFFF
 # every symbol include/dvs_hip.h declares (tests/test_boundary.py checks the .so exports them)
 EXPORTS = (
     "dvs_abi_version", "dvs_ctx_create", "dvs_ctx_destroy", "dvs_last_error", "dvs_ctx_sync",
-    "dvs_ctx_trim", "dvs_ctx_device_info", "dvs_ctx_set_timing", "dvs_matrix_build", "dvs_matrix_from_freqs", "dvs_matrix_from_device_freqs", "dvs_matrix_get_source_rows", "dvs_matrix_count_bytes",
+    "dvs_ctx_trim", "dvs_ctx_device_info", "dvs_ctx_set_timing", "dvs_ctx_refresh_knobs", "dvs_matrix_build", "dvs_matrix_from_freqs", "dvs_matrix_from_device_freqs", "dvs_matrix_get_source_rows", "dvs_matrix_count_bytes",
     "dvs_matrix_destroy", "dvs_matrix_nrows", "dvs_matrix_nbins", "dvs_matrix_dev_counts",
     "dvs_matrix_dev_totals", "dvs_matrix_dev_entropy", "dvs_matrix_get_counts",
     "dvs_matrix_get_totals", "dvs_matrix_get_entropy", "dvs_kmer_counts", "dvs_select_run",
@@ -118,6 +118,7 @@ def load() -> C.CDLL:
         L.dvs_ctx_sync.argtypes = [vp]
         L.dvs_ctx_trim.argtypes = [vp]
         L.dvs_ctx_set_timing.argtypes = [vp, C.c_int]
+        L.dvs_ctx_refresh_knobs.argtypes = [vp]
         L.dvs_ctx_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), u64p]
         L.dvs_matrix_build.argtypes = [vp, vp, C.c_int, u64p, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.POINTER(vp)]

@@ -11,7 +11,7 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs, u
                            const uint64_t *offsets, bool no_wait);
 int dvs_matrix_fill_freq_entropy(dvs_ctx *ctx, dvs_matrix *m);
 int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint32_t k, uint64_t nbytes, size_t *n_long_out);
-bool dvs_hist_rows_fit_u16(uint64_t B, size_t n_long);
+bool dvs_hist_rows_fit_u16(const dvs_ctx *ctx, uint64_t B, size_t n_long);
 int dvs_matrix_fill_freq_totals(dvs_ctx *ctx, dvs_matrix *m, const double *d_meta);
 int dvs_matrix_fill_compacted(dvs_ctx *ctx, dvs_matrix *m, const double *d_in, const double *d_meta);
 
@@ -108,9 +108,59 @@ void dvs_dev_trim(dvs_ctx *ctx) {
     ctx->pool_bytes = 0;
 }
 
+// the environment's switches, parsed once per context (dvs_internal.h dvs_knobs)
+void dvs_knobs_from_env(dvs_knobs *k) {
+    auto on = [](const char *name) { return getenv(name) != nullptr; };
+    auto num = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    auto real = [](const char *name) { const char *e = getenv(name); return e ? atof(e) : 0.0; };
+    *k = dvs_knobs();
+    k->no_uniform_offsets = on("DVS_NO_UNIFORM_OFFSETS");
+    k->no_offsets_cache = on("DVS_NO_OFFSETS_CACHE");
+    k->counts_u32 = on("DVS_COUNTS_U32");
+    k->hist_no_pk16 = on("DVS_HIST_NO_PK16");
+    k->hist_threads = num("DVS_HIST_THREADS", 0);
+    k->hist_tile_threads = num("DVS_HIST_TILE_THREADS", 0);
+    k->hist_hot_rows = num("DVS_HIST_HOT_ROWS", -1);
+    k->hist_no_split = on("DVS_HIST_NO_SPLIT");
+    k->head_rows = num("DVS_HEAD_ROWS", 0);
+    k->build_wait = on("DVS_BUILD_WAIT");
+    k->no_cu_split = on("DVS_NO_CU_SPLIT");
+    k->head_cus = num("DVS_HEAD_CUS", 0);
+    k->cu_mask_set = on("HSA_CU_MASK") || on("ROC_GLOBAL_CU_MASK");
+    k->no_persist = on("DVS_NO_PERSIST");
+    k->no_persist_max = on("DVS_NO_PERSIST_MAX");
+    k->no_head_phase = on("DVS_NO_HEAD_PHASE");
+    k->no_side_stream = on("DVS_NO_SIDE_STREAM");
+    k->keep_labels = on("DVS_KEEP_LABELS");
+    k->persist_no_seeded = on("DVS_PERSIST_NO_SEEDED");
+    k->persist_seeded_any = on("DVS_PERSIST_SEEDED");
+    k->persist_no_small = on("DVS_PERSIST_NO_SMALL");
+    k->persist_coop = on("DVS_PERSIST_COOP");
+    k->persist_debug = on("DVS_PERSIST_DEBUG");
+    k->persist_no_coarse = on("DVS_PERSIST_NO_COARSE");
+    k->persist_no_events = on("DVS_PERSIST_NO_EVENTS");
+    k->persist_no_burst_drop = on("DVS_PERSIST_NO_BURST_DROP");
+    k->persist_no_speculation = on("DVS_PERSIST_NO_SPECULATION");
+    k->persist_grid = num("DVS_PERSIST_GRID", 0);
+    k->persist_wg_rounds = num("DVS_PERSIST_WG_ROUNDS", -1);
+    k->persist_wg_scale = real("DVS_PERSIST_WG_SCALE");
+    k->scan_wg_per_cu = num("DVS_SCAN_WG_PER_CU", 0);
+    k->window_scale = real("DVS_WINDOW_SCALE");
+    k->mash_bytewise = on("DVS_MASH_BYTEWISE");
+    k->mash_big_table = on("DVS_MASH_BIG_TABLE");
+    k->ingest_no_stream = on("DVS_INGEST_NO_STREAM");
+    k->test_persist_fake_error = on("DVS_TEST_KNOBS") && on("DVS_PERSIST_FAKE_ERROR");
+}
+
 extern "C" {
 
 int dvs_abi_version(void) { return DVS_ABI_VERSION; }
+
+int dvs_ctx_refresh_knobs(dvs_ctx *ctx) {
+    if (!ctx) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    dvs_knobs_from_env(&ctx->knobs);
+    return DVS_OK;
+}
 
 int dvs_ctx_create(int device, void *stream, dvs_ctx **out) {
     if (!out) return dvs_set_error(nullptr, DVS_ERR_VALUE, "null argument");
@@ -133,6 +183,7 @@ int dvs_ctx_create(int device, void *stream, dvs_ctx **out) {
     e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) return dvs_hip_fail(nullptr, e, "hipGetDeviceProperties");
     dvs_ctx *ctx = new dvs_ctx();
+    dvs_knobs_from_env(&ctx->knobs);
     ctx->device = device;
     ctx->n_cu = prop.multiProcessorCount;
     ctx->lds_per_block = prop.sharedMemPerBlockOptin ? prop.sharedMemPerBlockOptin
@@ -183,10 +234,10 @@ hipStream_t dvs_ctx_stream2(dvs_ctx *ctx) {
 bool dvs_ctx_cu_split(dvs_ctx *ctx) {
     if (ctx->cu_split_tried) return ctx->stream_head != nullptr;
     ctx->cu_split_tried = true;
-    if (getenv("DVS_NO_CU_SPLIT") || ctx->n_cu < 128 || ctx->n_cu % 8) return false;
-    if (getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK")) return false;  // (the bit layout below assumes every CU)
+    if (ctx->knobs.no_cu_split || ctx->n_cu < 128 || ctx->n_cu % 8) return false;
+    if (ctx->knobs.cu_mask_set) return false;  // (the bit layout below assumes every CU)
     int head = 64;
-    if (const char *e = getenv("DVS_HEAD_CUS")) head = atoi(e);
+    if (ctx->knobs.head_cus) head = ctx->knobs.head_cus;
     head = std::max(16, std::min(ctx->n_cu / 2, head)) & ~7;
     const uint32_t words = uint32_t(ctx->n_cu + 31) / 32;
     std::vector<uint32_t> lo(words, 0u), hi(words, 0u);
@@ -308,7 +359,7 @@ int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, cons
         if (prc) return prc;
     }
     dvs_matrix *m = new dvs_matrix();
-    m->kind = (nseq && dvs_hist_rows_fit_u16(B, n_long)) ? 2 : 0;
+    m->kind = (nseq && dvs_hist_rows_fit_u16(ctx, B, n_long)) ? 2 : 0;
     m->nrows = nseq;
     m->nbins = B;
     m->k = k;
@@ -347,7 +398,7 @@ int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, cons
     // (a device-resident input needs no host wait: the kernels' completion is an event the consumers
     // of the matrix wait on when they need host-side data, dvs_matrix_settle)
     rc = nseq ? dvs_matrix_fill_counts(ctx, m, d_seqs, readable, offsets,
-                                       seqs_on_device != 0 && !getenv("DVS_BUILD_WAIT"))
+                                       seqs_on_device != 0 && !ctx->knobs.build_wait)
               : DVS_OK;
     if (d_tmp) {
         (void)hipStreamSynchronize(ctx->stream);

@@ -15,7 +15,44 @@
 #define DVS_EPS 2.220446049250313e-16  // f64::EPSILON
 #define DVS_HEAD_ROWS 1024u            // rows of a split build's first launch (kmer_hist.hip)
 
+// Every switch the library takes from the environment, read ONCE when a context is made (and again
+// only on dvs_ctx_refresh_knobs, a measurement / test aid): nothing on a per-call path calls getenv.
+// All of them are measurement aids or escape hatches; the defaults are the product.
+struct dvs_knobs {
+    // histogram (kmer_hist.hip)
+    bool no_uniform_offsets = false;  // DVS_NO_UNIFORM_OFFSETS: offsets uploaded even for one length laid end to end
+    bool no_offsets_cache = false;    // DVS_NO_OFFSETS_CACHE: every build validates + uploads its offsets
+    bool counts_u32 = false;          // DVS_COUNTS_U32: never 16-bit rows
+    bool hist_no_pk16 = false;        // DVS_HIST_NO_PK16
+    int hist_threads = 0;             // DVS_HIST_THREADS (0: default)
+    int hist_tile_threads = 0;        // DVS_HIST_TILE_THREADS
+    int hist_hot_rows = -1;           // DVS_HIST_HOT_ROWS (-1: default)
+    bool hist_no_split = false;       // DVS_HIST_NO_SPLIT
+    int head_rows = 0;                // DVS_HEAD_ROWS (0: default)
+    bool build_wait = false;          // DVS_BUILD_WAIT: device-resident builds wait for their kernels
+    // context (api.cpp)
+    bool no_cu_split = false;         // DVS_NO_CU_SPLIT
+    int head_cus = 0;                 // DVS_HEAD_CUS
+    bool cu_mask_set = false;         // HSA_CU_MASK / ROC_GLOBAL_CU_MASK present: the device reports CUs it will not give
+    // selection engines (select.hip, persist.hip)
+    bool no_persist = false, no_persist_max = false, no_head_phase = false, no_side_stream = false;
+    bool keep_labels = false, persist_no_seeded = false, persist_seeded_any = false, persist_no_small = false;
+    bool persist_coop = false, persist_debug = false;
+    bool persist_no_coarse = false, persist_no_events = false, persist_no_burst_drop = false, persist_no_speculation = false;
+    int persist_grid = 0;             // DVS_PERSIST_GRID
+    int persist_wg_rounds = -1;       // DVS_PERSIST_WG_ROUNDS (-1: default)
+    double persist_wg_scale = 0.0;    // DVS_PERSIST_WG_SCALE (0: default)
+    int scan_wg_per_cu = 0;           // DVS_SCAN_WG_PER_CU
+    double window_scale = 0.0;        // DVS_WINDOW_SCALE (0: default)
+    // mash / ingest
+    bool mash_bytewise = false, mash_big_table = false, ingest_no_stream = false;
+    // test-only: honoured only when DVS_TEST_KNOBS=1 is ALSO set (a release run cannot trip over them)
+    bool test_persist_fake_error = false;  // DVS_PERSIST_FAKE_ERROR
+};
+void dvs_knobs_from_env(dvs_knobs *k);
+
 struct dvs_ctx {
+    dvs_knobs knobs;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;

@@ -359,7 +359,7 @@ extern "C" int dvs_seqbatch_from_fasta(dvs_ctx *ctx, const uint8_t *raw, int raw
     // chunks: the whole file at once when it is already in HBM (or small), else 32 MiB pieces
     uint64_t chunk_blocks = nb ? nb : 1;
     const uint64_t CH_BLOCKS = (32ull << 20) / ING_BLOCK;
-    const bool streamed = !raw_on_device && nb >= 3 * CH_BLOCKS && !getenv("DVS_INGEST_NO_STREAM");
+    const bool streamed = !raw_on_device && nb >= 3 * CH_BLOCKS && !ctx->knobs.ingest_no_stream;
     constexpr int NSLOT = 4;
     if (raw_on_device) {
         d_raw = const_cast<uint8_t *>(raw);

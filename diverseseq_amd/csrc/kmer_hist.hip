@@ -500,7 +500,7 @@ int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint3
     // offsets on the device at all: the kernel derives row r's span from (base, stride).  One read-only
     // pass decides (it stops at the first span of another length), nothing is copied or uploaded.
     oc.uniform = false;
-    if (nseq >= 1 && !getenv("DVS_NO_UNIFORM_OFFSETS")) {
+    if (nseq >= 1 && !ctx->knobs.no_uniform_offsets) {
         const uint64_t base = offsets[0], stride = offsets[1] - offsets[0];
         bool uni = offsets[1] >= offsets[0] && stride < uint64_t(TILE_LEN) + k;
         uint64_t diff = 0;
@@ -523,7 +523,7 @@ int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint3
         }
     }
     const bool hit = oc.d_off && oc.h_off && oc.k == k && oc.nbytes == nbytes && oc.n_off == n_off &&
-                     !getenv("DVS_NO_OFFSETS_CACHE") && std::memcmp(oc.h_off, offsets, n_off * 8) == 0;
+                     !ctx->knobs.no_offsets_cache && std::memcmp(oc.h_off, offsets, n_off * 8) == 0;
     if (!hit) {
         // the pinned block: no upload may still be reading it, and it must be large enough
         if (oc.ev_up) (void)hipEventSynchronize(oc.ev_up);
@@ -628,9 +628,9 @@ int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint3
 // Up to 4096 bins only: beyond that the selection engines score rows with the f32-log tier alone,
 // which is bound by its arithmetic, not by the bytes of a row, and their per-event paths read counts
 // one per lane -- measured at 4^7 bins: 22.8 ms per selection with 16-bit rows, 18.3 with 32-bit.
-bool dvs_hist_rows_fit_u16(uint64_t B, size_t n_long) {
-    return n_long == 0 && B <= 4096 && (B & 3) == 0 && !getenv("DVS_COUNTS_U32") &&
-           !getenv("DVS_HIST_NO_PK16") && !getenv("DVS_HIST_THREADS");
+bool dvs_hist_rows_fit_u16(const dvs_ctx *ctx, uint64_t B, size_t n_long) {
+    return n_long == 0 && B <= 4096 && (B & 3) == 0 && !ctx->knobs.counts_u32 &&
+           !ctx->knobs.hist_no_pk16 && !ctx->knobs.hist_threads;
 }
 
 // Launches the histogram build for sequences already in HBM (d_seqs, nbytes
@@ -670,8 +670,8 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
     // 256 threads for whole sequences: with 16-18 KB of LDS each, 8 workgroups (32 waves) fill a CU;
     // measured on 100k x 5 kb: 0.67 ms at 256 threads, 0.78 at 320, 0.86 at 384 and 512
     int nthreads = HIST_THREADS, tile_threads = HIST_THREADS;  // (genome tiles: 256 and 512 measure the same)
-    if (const char *e = getenv("DVS_HIST_THREADS")) nthreads = atoi(e);
-    if (const char *e = getenv("DVS_HIST_TILE_THREADS")) tile_threads = atoi(e);
+    if (ctx->knobs.hist_threads) nthreads = ctx->knobs.hist_threads;
+    if (ctx->knobs.hist_tile_threads) tile_threads = ctx->knobs.hist_tile_threads;
     const size_t lds = (lds_hist ? ((B * 4 + 15) & ~15ull) : 0) + (CLOG_TBL + 32) * sizeof(double);
 #define DVS_LAUNCH_HIST(NS4, LH, GRID, TILES, NTHR, HOT)                                                  \
     do {                                                                                         \
@@ -693,17 +693,17 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
     // when the selection starts; every other row is a streaming store.  Measured on 100k x 4^6:
     // streaming stores -0.04 ms per build + selection, the hot head another -0.01 ms.
     uint32_t hot_rows = uint32_t(std::min<uint64_t>(nseq, (192ull << 20) / (B * (m->kind == 2 ? 2 : 4))));
-    if (const char *e = getenv("DVS_HIST_HOT_ROWS")) hot_rows = uint32_t(atoi(e));
+    if (ctx->knobs.hist_hot_rows >= 0) hot_rows = uint32_t(ctx->knobs.hist_hot_rows);
     // whole sequences: the packed histogram at 128 threads when the row layout allows it
-    const bool pk16 = lds_hist && (B & 3) == 0 && !getenv("DVS_HIST_NO_PK16") && !getenv("DVS_HIST_THREADS");
+    const bool pk16 = lds_hist && (B & 3) == 0 && !ctx->knobs.hist_no_pk16 && !ctx->knobs.hist_threads;
     // A build that does not wait for its kernels is cut in two launches: the head of the matrix first
     // (what a selection reads first: its seeds), the totals of those rows on their way to the host right
     // behind it, then everything else.  The selection's set-up kernels run on the context's second
     // stream beside the second launch (select.hip sel_start).
     uint32_t head_rows = 0;
-    if (m->kind == 2 && no_wait && !getenv("DVS_HIST_NO_SPLIT")) {
+    if (m->kind == 2 && no_wait && !ctx->knobs.hist_no_split) {
         uint32_t want = DVS_HEAD_ROWS;
-        if (const char *e = getenv("DVS_HEAD_ROWS")) want = std::max(64, atoi(e));  // (measurement knob)
+        if (ctx->knobs.head_rows) want = uint32_t(std::max(64, ctx->knobs.head_rows));  // (measurement knob)
         head_rows = std::min<uint32_t>(nseq, want);
     }
     if (head_rows == nseq) head_rows = 0;  // (nothing left to run beside)

@@ -587,9 +587,9 @@ static int mash_sketch_core(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_devic
         DVS_HIP(ctx, hipMemcpyAsync(d_active.p, active.data(), nseq, hipMemcpyHostToDevice, ctx->stream));
         DVS_HIP(ctx, hipMemcpyAsync(d_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         DVS_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, nseq * 4, ctx->stream));
-        if (num_states == 4 && k <= 32 && !getenv("DVS_MASH_BYTEWISE")) {  // 2-bit packed windows
+        if (num_states == 4 && k <= 32 && !ctx->knobs.mash_bytewise) {  // 2-bit packed windows
             // the small hash set when no active sequence lets more than ~512 windows of a tile through
-            bool small = !getenv("DVS_MASH_BIG_TABLE");
+            bool small = !ctx->knobs.mash_big_table;
             for (uint32_t q : list) {
                 const long double frac = ((long double)hi[q] - (long double)lo[q]) / 4294967296.0L;
                 if (frac * MASH_TILE > 512.0L) small = false;

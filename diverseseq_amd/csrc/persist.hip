@@ -2156,11 +2156,11 @@ static int persist_prepare(dvs_ctx *ctx, dvs_select *s, uint32_t head_stop, hipS
     // a row per workgroup while a window is at most this many rounds of the grid (default policy only)
     init.wg_thresh = s->params.window ? 0u : 4u;
     init.wg_scale = 1.5f;
-    if (const char *e = getenv("DVS_PERSIST_WG_ROUNDS")) init.wg_thresh = uint32_t(atoi(e));
-    if (const char *e = getenv("DVS_PERSIST_WG_SCALE")) init.wg_scale = float(atof(e));
-    init.no_coarse = (getenv("DVS_PERSIST_NO_COARSE") ? 1u : 0u) | (getenv("DVS_PERSIST_NO_EVENTS") ? 2u : 0u) |
-                     (getenv("DVS_PERSIST_NO_BURST_DROP") ? 8u : 0u) |
-                     (getenv("DVS_PERSIST_NO_SPECULATION") ? 16u : 0u);  // (SMALL: nothing is worked out ahead of the release)
+    if (ctx->knobs.persist_wg_rounds >= 0) init.wg_thresh = uint32_t(ctx->knobs.persist_wg_rounds);
+    if (ctx->knobs.persist_wg_scale > 0.0) init.wg_scale = float(ctx->knobs.persist_wg_scale);
+    init.no_coarse = (ctx->knobs.persist_no_coarse ? 1u : 0u) | (ctx->knobs.persist_no_events ? 2u : 0u) |
+                     (ctx->knobs.persist_no_burst_drop ? 8u : 0u) |
+                     (ctx->knobs.persist_no_speculation ? 16u : 0u);  // (nothing is worked out ahead of the release)
     init.small_rows = s->persist_small ? s->persist_small_rows : 0u;
     DVS_HIP(ctx, hipMemcpyAsync(head_stop ? s->psync_head : s->psync, &init, sizeof init, hipMemcpyHostToDevice, on));
     DVS_HIP(ctx, hipMemsetAsync(head_stop ? s->ppart_head : s->ppart, 0, p_acc_bytes(s->persist_maxn), on));
@@ -2224,19 +2224,19 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat, uint32_t gr
 int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     const uint64_t B = s->dev.B;
     s->persist = false;
-    if (getenv("DVS_NO_PERSIST") || ctx->persist_timeouts >= 3) return DVS_OK;
+    if (ctx->knobs.no_persist || ctx->persist_timeouts >= 3) return DVS_OK;
     // a process-wide CU mask hides CUs the device still reports: the grid below could never be resident
-    if (getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK")) return DVS_OK;
-    const bool maxm = s->params.mode == DVS_MODE_MAX && !getenv("DVS_NO_PERSIST_MAX");
+    if (ctx->knobs.cu_mask_set) return DVS_OK;
+    const bool maxm = s->params.mode == DVS_MODE_MAX && !ctx->knobs.no_persist_max;
     if ((s->params.mode != DVS_MODE_NMOST && !maxm) || !s->h_order.empty() || !s->h_labels.empty()) return DVS_OK;
     s->persist_grid = uint32_t(ctx->n_cu);  // one 512-thread workgroup per CU: all resident
-    if (const char *e = getenv("DVS_PERSIST_GRID")) s->persist_grid = std::max(2, std::min(ctx->n_cu, atoi(e)));  // (measurement knob)
+    if (ctx->knobs.persist_grid) s->persist_grid = uint32_t(std::max(2, std::min(ctx->n_cu, ctx->knobs.persist_grid)));  // (measurement knob)
     const bool cached = B <= uint64_t(P_J) * P_THREADS;
     if (maxm && !cached) return DVS_OK;  // (the growth phase wants the candidate in registers and S in LDS)
     // SMALL sets (see the kernel): nmost, 16-bit rows of 4096 bins, every member's row in LDS
     s->persist_small_rows = s->params.n_seed;
     s->persist_small = !maxm && s->params.mode == DVS_MODE_NMOST && s->mat_kind == 2 && B == 4096 &&
-                       s->params.n_seed >= 2 && s->params.n_seed <= P_SMALL_ROWS && !getenv("DVS_PERSIST_NO_SMALL");
+                       s->params.n_seed >= 2 && s->params.n_seed <= P_SMALL_ROWS && !ctx->knobs.persist_no_small;
     auto lds_for = [&](uint32_t maxn_) {
         return ((B + 1) & ~1ull) * 8 + (cached && s->mat_kind != 1 ? ((B + 3) & ~3ull) * 4 : 0) +
                (maxm ? ((B + 1) & ~1ull) * 8 : 0) + 128 * 8 + size_t(maxn_) * 52 + 8 + P_SOFT * 8 + 64 +
@@ -2273,7 +2273,7 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
         if (!hit->second) return DVS_OK;
     }
     s->persist_coop = false;
-    if (getenv("DVS_PERSIST_COOP")) {
+    if (ctx->knobs.persist_coop) {
         int coop = 0;
         (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, ctx->device);
         s->persist_coop = coop != 0;

@@ -933,7 +933,7 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
             }
             s->ev_used = 0;
         }
-        for (int which = 0; which < 2 && s->persist && getenv("DVS_PERSIST_DEBUG"); which++) {
+        for (int which = 0; which < 2 && s->persist && ctx->knobs.persist_debug; which++) {
             unsigned long long dbg[32];
             void *blk = which ? s->psync : s->psync_head;  // (the head phase's launch first, then the full grid's)
             if (!blk) continue;
@@ -951,7 +951,7 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
                             dbg[16 + 13], dbg[16 + 12], dbg[16 + 11] / 100.0, dbg[16 + 14]);
             }
         }
-        const bool fake_error = getenv("DVS_PERSIST_FAKE_ERROR") != nullptr;  // (test knob)
+        const bool fake_error = ctx->knobs.test_persist_fake_error;  // (test knob: needs DVS_TEST_KNOBS=1 as well)
         if (s->persist && persist_launches && (c.status == SEL_ERROR || (fake_error && persist_launches == 1))) {
             // The persistent kernel gave up at a grid barrier: its workgroups were not all resident
             // (a CU mask, a partitioned device, another stream's kernels holding CUs).  The
@@ -1043,7 +1043,7 @@ static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat) {
     hipStream_t side = nullptr;
     bool head_phase = false;
     if (s->mat->head_rows_built && s->params.n_seed <= s->mat->head_rows_built && s->h_order.empty() &&
-        !(s->params.flags & DVS_SELECT_STEPWISE) && !getenv("DVS_NO_SIDE_STREAM")) {
+        !(s->params.flags & DVS_SELECT_STEPWISE) && !ctx->knobs.no_side_stream) {
         // HEAD PHASE: that launch runs on the context's stream_rest and leaves the head CUs alone (CU
         // split), so the persistent engine starts on them right behind the set-up kernels and walks
         // the rows that are already built -- the event-dense head of the stream, a chain of
@@ -1053,7 +1053,7 @@ static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat) {
         head_phase = s->mat->rest_beside_head && ctx->stream_head && s->persist &&
                      s->params.mode == DVS_MODE_NMOST && s->params.window == 0 &&
                      s->cap + 2 <= uint32_t(ctx->head_cus) && s->npos > 4ull * s->mat->head_rows_built &&
-                     s->params.n_seed + 64 <= s->mat->head_rows_built && !getenv("DVS_NO_HEAD_PHASE");
+                     s->params.n_seed + 64 <= s->mat->head_rows_built && !ctx->knobs.no_head_phase;
         side = head_phase ? ctx->stream_head : dvs_ctx_stream2(ctx);
     }
     hipStream_t st = side ? side : ctx->stream;
@@ -1145,7 +1145,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     // label-free (label = position: the persistent engine qualifies) and the caller's values are
     // put back on the way out (dvs_select_get_members, dvs_select_delta_jsd).
     const uint32_t *caller_labels = nullptr;
-    if (labels && !order && params->mode != DVS_MODE_SET && !getenv("DVS_KEEP_LABELS")) {
+    if (labels && !order && params->mode != DVS_MODE_SET && !ctx->knobs.keep_labels) {
         bool distinct = true;
         std::vector<uint32_t> sorted(labels, labels + npos);
         std::sort(sorted.begin(), sorted.end());
@@ -1227,7 +1227,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     s->scan_lds = 16 + (s->base_in_lds ? B * 8 : 0);
     const uint32_t wg_fit = s->base_in_lds ? std::max<uint32_t>(1, uint32_t((160 * 1024) / (B * 8 + 512))) : 4;
     uint32_t wg_per_cu = std::min<uint32_t>(wg_fit, 2);  // 16 waves per CU, 16 KB of loads in flight each
-    if (const char *e = getenv("DVS_SCAN_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
+    if (ctx->knobs.scan_wg_per_cu) wg_per_cu = uint32_t(std::max(1, ctx->knobs.scan_wg_per_cu));
     s->scan_grid = std::max<uint32_t>(1, uint32_t(ctx->n_cu) * wg_per_cu);
     s->loo_grid = cap;
     // measured slower than three launches (one CU does the whole leave-one-out pass): opt-in only
@@ -1307,7 +1307,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     // what the launches cost; DVS_PERSIST_SEEDED=1 forces it for any size, DVS_PERSIST_NO_SEEDED=1 turns it off)
     // (a STEPWISE selection never launches the persistent kernel: its set-up kernels must run)
     s->seeded_start = s->persist && params->mode == DVS_MODE_NMOST && B <= 4096 && !order && !labels &&
-                      !(s->params.flags & DVS_SELECT_STEPWISE) && n_seed >= 2 && (n_seed <= 32 || getenv("DVS_PERSIST_SEEDED")) && !getenv("DVS_PERSIST_NO_SEEDED");
+                      !(s->params.flags & DVS_SELECT_STEPWISE) && n_seed >= 2 && (n_seed <= 32 || ctx->knobs.persist_seeded_any) && !ctx->knobs.persist_no_seeded;
     s->persist_seeded = s->seeded_start;
     if (s->seeded_start) {
         int arc = dvs_dev_alloc(ctx, &s->d_seed_list, size_t(n_seed) * sizeof(uint64_t), "seed list");
@@ -1377,7 +1377,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     // measured on the north-star shape: {2, 3, 4} x window_min {256..2048}, and power laws
     // wc * gap^0.5..0.75 for the early stream, are all within 3 % of each other
     c.wscale = 4.0;
-    if (const char *e = getenv("DVS_WINDOW_SCALE")) c.wscale = atof(e);
+    if (ctx->knobs.window_scale > 0.0) c.wscale = ctx->knobs.window_scale;
     s->ctl0 = c;  // (sel_seed adds the window policy of the engine in charge and uploads it)
     s->seed_positions = seeds;
 

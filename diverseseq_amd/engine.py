@@ -6,6 +6,7 @@ Host-side plumbing only; every number comes out of libdvs_hip.so.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -69,6 +70,16 @@ def genbank_to_fasta(raw: bytes) -> bytes:
     return b"".join(out)
 
 
+_live_contexts = weakref.WeakSet()
+
+
+def refresh_all_knobs():
+    """every live Context re-reads the DVS_* environment switches (tests / A-B runs that flip one)"""
+    for c in list(_live_contexts):
+        if c._h:
+            c.refresh_knobs()
+
+
 class Context:
     """one per process per GPU (dvs_ctx)"""
 
@@ -79,6 +90,7 @@ class Context:
         if rc:
             _lib.raise_for(rc, None)
         self._h = h
+        _live_contexts.add(self)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -96,6 +108,10 @@ class Context:
 
     def sync(self):
         self.check(self._L.dvs_ctx_sync(self._h))
+
+    def refresh_knobs(self):
+        """re-read the DVS_* environment switches (they are otherwise read once, when the context is made)"""
+        self.check(self._L.dvs_ctx_refresh_knobs(self._h))
 
     def set_timing(self, on: bool):
         self.check(self._L.dvs_ctx_set_timing(self._h, int(on)))

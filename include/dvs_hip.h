@@ -228,6 +228,10 @@ int dvs_select_step_poll(dvs_ctx *ctx, dvs_select *s, uint32_t *status, uint64_t
  * ctx stream (no extra host sync); they are read once the selection has finished
  * and summed into dvs_select_summary.scan_ms / scan_launches */
 int dvs_ctx_set_timing(dvs_ctx *ctx, int on);
+/* The library's environment switches (DVS_*: measurement aids and escape hatches) are
+ * read once, when a context is created; nothing on a per-call path looks at the environment.  This
+ * re-reads them for an existing context (tests and A/B measurements that flip a switch in between). */
+int dvs_ctx_refresh_knobs(dvs_ctx *ctx);
 /* measurement aid: average duration of ONE scan_kernel launch over every streamed row of
  * the selection's stream against its current state, with an unreachable threshold (no
  * events, state untouched): the steady-state streaming rate of the scan arithmetic */

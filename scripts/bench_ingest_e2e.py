@@ -53,6 +53,7 @@ def run(stream: bool):
         os.environ.pop("DVS_INGEST_NO_STREAM", None)
     else:
         os.environ["DVS_INGEST_NO_STREAM"] = "1"
+    ctx.refresh_knobs()
     best = None
     for _ in range(3):
         t0 = time.perf_counter()

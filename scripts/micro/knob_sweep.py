@@ -13,6 +13,7 @@ ctx.set_timing(True)
 for spec in sys.argv[1:]:
     env = dict(kv.split("=") for kv in spec.split(",") if kv and kv != "-")
     os.environ.update(env)
+    ctx.refresh_knobs()
     best = None
     for it in range(6):
         t0 = time.perf_counter()
@@ -25,3 +26,4 @@ for spec in sys.argv[1:]:
         sel.close(); m.close()
     print(f"{spec:50s} step {best[0]*1e3:.3f} ms persist {best[1]:.3f} rows {best[2]} windows {best[3]} accepts {best[4]}", flush=True)
     for k_ in env: os.environ.pop(k_, None)
+    ctx.refresh_knobs()

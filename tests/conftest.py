@@ -112,3 +112,36 @@ def clades(newick_or_tuple) -> set[frozenset]:
 
     walk(tree)
     return out
+
+
+@pytest.fixture(autouse=True)
+def _knobs_follow_the_environment(monkeypatch):
+    """The library reads its DVS_* switches once per context (dvs_ctx_create).  Tests flip them with
+    monkeypatch.setenv / delenv in the middle of a module-scoped context's life: every such change, and its
+    undoing at the end of the test, is followed by a re-read in every live context."""
+    def refresh(name):
+        if str(name).startswith(("DVS_", "HSA_CU_MASK", "ROC_GLOBAL_CU_MASK")):
+            try:
+                from diverseseq_amd import engine
+            except Exception:  # (CPU-only runs: nothing to refresh)
+                return
+            engine.refresh_all_knobs()
+
+    touched = []
+    orig_set, orig_del = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, prepend=None):
+        orig_set(name, value, prepend)
+        touched.append(name)
+        refresh(name)
+
+    def delenv(name, raising=True):
+        orig_del(name, raising)
+        touched.append(name)
+        refresh(name)
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield
+    monkeypatch.undo()
+    for name in touched[:1]:
+        refresh(name)

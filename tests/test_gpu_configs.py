@@ -123,6 +123,7 @@ def test_persistent_engine_falls_back_to_the_multi_launch_engine(ctx, monkeypatc
     sel = m.nmost(11)
     assert sel.summary().engine == 1
     _assert_selection(sel, exp)
+    monkeypatch.setenv("DVS_TEST_KNOBS", "1")  # (test-only switches are honoured only with this one set as well)
     monkeypatch.setenv("DVS_PERSIST_FAKE_ERROR", "1")  # the first launch's outcome is read as SEL_ERROR
     sel = m.nmost(11)
     assert sel.summary().engine == 0
@@ -342,10 +343,12 @@ def test_config_c3_full_size_properties(ctx):
     assert ma.positions.tolist() == mb.positions.tolist()
     np.testing.assert_allclose(ma.delta_jsd, mb.delta_jsd, rtol=1e-9)
     os.environ["DVS_NO_PERSIST"] = "1"
+    ctx.refresh_knobs()
     try:
         c = m.max_divergent(100, N, "stdev")  # the other engine: the same answer
     finally:
         del os.environ["DVS_NO_PERSIST"]
+        ctx.refresh_knobs()
     assert c.summary().engine == 0 and sa.engine == 1
     mc = c.members(False)
     assert ma.positions.tolist() == mc.positions.tolist()
