@@ -87,7 +87,8 @@ class ZarrStoreWrapper:
         self._lens: list[int] = []
         self._keys: list[bytes] = []       # content digest per entry (the reference names content by its xxh3)
         self._meta: dict[str, dict] = {}
-        self._spans = None                 # (starts, lens) as arrays, rebuilt after writes
+        self._spans = None                 # (starts, lens, offsets, laid end to end?) as arrays, rebuilt after writes
+        self._ids: list[str] = []          # the ids in insertion order (a list: `ids == self._ids` is one C-level pass)
         self._disk = None
         self.source = ""
         if path is not None:
@@ -147,6 +148,7 @@ class ZarrStoreWrapper:
         import xxhash
 
         self._index[seqid] = len(self._starts)
+        self._ids.append(seqid)
         self._starts.append(len(self._arena))
         self._lens.append(len(data))
         self._keys.append(xxhash.xxh3_128_digest(data))
@@ -182,15 +184,23 @@ class ZarrStoreWrapper:
             return self._disk.seqid_to_hash.items()
         return zip(self._index, self._keys)
 
-    def _concat(self, ids):
+    def _concat(self, ids, own: bool | None = None):
         """in-memory store: (uint8 data, uint64 offsets[n+1]) of the sequences of `ids`, in that order.
         Ids that follow one another in the arena (the usual call: the store's own id list) come back
         as a VIEW of the arena; anything else is gathered."""
         if self._spans is None:
-            self._spans = (np.array(self._starts, dtype=np.int64), np.array(self._lens, dtype=np.int64))
+            st, ln = np.array(self._starts, dtype=np.int64), np.array(self._lens, dtype=np.int64)
+            off = np.zeros(len(ln) + 1, dtype=np.uint64)
+            np.cumsum(ln, out=off[1:], dtype=np.uint64)
+            self._spans = (st, ln, off, bool(np.array_equal(st[1:], st[:-1] + ln[:-1])))
         index = self._index
-        if len(ids) == len(index) and all(map(operator.eq, ids, index)):  # the store's own id list
-            starts, lens = self._spans
+        if own is None:
+            own = ids is self._ids or ids == self._ids
+        if own:  # the store's own id list: everything is already there
+            starts, lens, offsets, contiguous = self._spans
+            if len(ids) and contiguous:
+                arena = np.frombuffer(self._arena, dtype=np.uint8)
+                return arena[starts[0]:starts[0] + int(offsets[-1])], offsets
         else:
             try:
                 idx = np.fromiter((index[sid] for sid in ids), dtype=np.int64, count=len(ids))
@@ -276,7 +286,12 @@ def _gather(store: ZarrStoreWrapper, seqids):
     """the sequences of `seqids` as one stream (uint8 data, uint64 offsets[n+1]) + identity labels"""
     ids = list(store.unique_seqids) if seqids is None else list(seqids)
     if store._disk is None:
-        data, offsets = store._concat(ids)
+        # (the store's own id list -- one C-level list comparison -- needs no look-ups, and its ids are
+        # distinct by construction: the labels are the positions)
+        own = ids == store._ids
+        data, offsets = store._concat(ids, own)
+        if own:
+            return ids, data, offsets, np.arange(len(ids), dtype=np.uint32)
     else:
         for sid in ids:
             if sid not in store:

@@ -11,9 +11,11 @@
 // written back as a forced decision.  Degenerate inputs (identical sequences,
 // k = 1 toy sets) are where this runs; on the benchmark workloads it never does
 // (dvs_select_summary.n_arbitrated counts it).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <thread>
 
 #include "select.h"
 
@@ -37,7 +39,8 @@ class ExactSet {
     std::string err;
 
     // src/record.rs:86-106
-    bool entropy(const double *f, size_t n, double &out) {
+    bool entropy(const double *f, size_t n, double &out) { return entropy_into(f, n, out, err); }
+    static bool entropy_into(const double *f, size_t n, double &out, std::string &err) {
         if (n == 0) {
             err = "cannot calculate entropy as frequency vector empty";
             return false;
@@ -65,28 +68,55 @@ class ExactSet {
         return false;
     }
 
-    // src/records.rs:220-252 (+ updated_mean_freqs :276-286)
+    // src/records.rs:220-252 (+ updated_mean_freqs :276-286).  Every member's pass is the reference's,
+    // term by term in its order; the members are independent of one another, so large sets spread them
+    // over host threads (a genome-scale `max` set: 100+ members x 4^k libm logarithms per arbitration).
+    // The argmin is taken afterwards in member order (strict '<' from 1e6: the earliest wins ties).
     bool lowest_index() {
         const double div = double(recs.size()) - 1.0;
         if (div <= 0.0) {
             err = "must have > 1 KmerSeq";
             return false;
         }
-        double min_delta = 1e6;
-        uint32_t low = 0;
-        for (size_t i = 0; i < recs.size(); i++) {
+        const size_t n = recs.size();
+        std::vector<std::string> errs(n);
+        auto member = [&](size_t i, std::vector<double> &buf) {
             ExactRow &r = recs[i];
             const double mean_entropy = (sumH - r.H) / div;
             for (size_t j = 0; j < B; j++) {
-                work[j] = (S[j] - r.f[j]) / div;
-                if (work[j] <= DVS_EPS) work[j] = 0.0;
+                buf[j] = (S[j] - r.f[j]) / div;
+                if (buf[j] <= DVS_EPS) buf[j] = 0.0;
             }
             double eom;
-            if (!entropy(work.data(), B, eom)) return false;
-            const double jsd = eom - mean_entropy;
-            r.delta = total_jsd - jsd;
-            if (r.delta < min_delta) {
-                min_delta = r.delta;
+            std::string e;
+            if (!entropy_into(buf.data(), B, eom, e)) {
+                errs[i] = e;
+                return;
+            }
+            r.delta = total_jsd - (eom - mean_entropy);
+        };
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const size_t nthr = (n * B >= (size_t(1) << 18)) ? std::min<size_t>({n, size_t(hw), size_t(16)}) : 1;
+        if (nthr <= 1) {
+            for (size_t i = 0; i < n; i++) member(i, work);
+        } else {
+            std::vector<std::thread> pool;
+            for (size_t t = 0; t < nthr; t++)
+                pool.emplace_back([&, t]() {
+                    std::vector<double> buf(B);
+                    for (size_t i = t; i < n; i += nthr) member(i, buf);
+                });
+            for (std::thread &th : pool) th.join();
+        }
+        double min_delta = 1e6;
+        uint32_t low = 0;
+        for (size_t i = 0; i < n; i++) {
+            if (!errs[i].empty()) {  // (the reference would have panicked at the first such member)
+                err = errs[i];
+                return false;
+            }
+            if (recs[i].delta < min_delta) {
+                min_delta = recs[i].delta;
                 low = uint32_t(i);
             }
         }
@@ -95,7 +125,7 @@ class ExactSet {
     }
 
     // src/records.rs:27-68
-    bool init(std::vector<ExactRow> &&rows, size_t nbins) {
+    bool init(std::vector<ExactRow> &&rows, size_t nbins, bool with_lowest = true) {
         B = nbins;
         recs = std::move(rows);
         if (recs.empty()) {
@@ -114,7 +144,7 @@ class ExactSet {
         double eom;
         if (!entropy(work.data(), B, eom)) return false;
         total_jsd = eom - sumH / n;
-        return lowest_index();
+        return with_lowest ? lowest_index() : true;
     }
 
     // src/records.rs:70-84
@@ -172,11 +202,13 @@ class ExactSet {
         return push(std::move(c));
     }
 
-    // src/records.rs:182-189: clone re-runs new()
-    bool clone_from(const ExactSet &o) {
+    // src/records.rs:182-189: clone re-runs new().  for_push: the clone is pushed to at once
+    // (records.rs:438-440) and push's own leave-one-out pass overwrites every delta and the argmin, so
+    // the clone's pass -- n x 4^k logarithms whose results nobody reads -- is left out.
+    bool clone_from(const ExactSet &o, bool for_push = false) {
         std::vector<ExactRow> rows = o.recs;
         for (ExactRow &r : rows) r.delta = 0.0;
-        return init(std::move(rows), o.B);
+        return init(std::move(rows), o.B, !for_push);
     }
 
     // src/records.rs:156-172
@@ -275,7 +307,7 @@ int dvs_select_arbitrate(dvs_ctx *ctx, dvs_select *s) {
                 ok = set.replace_lowest(std::move(r));
             } else {  // records.rs:438-450: the kept object is clone + push
                 ExactSet grown;
-                ok = grown.clone_from(set) && grown.push(std::move(r));
+                ok = grown.clone_from(set, true) && grown.push(std::move(r));
                 if (ok) set = std::move(grown);
                 else set.err = grown.err;
             }
@@ -304,7 +336,7 @@ int dvs_select_arbitrate(dvs_ctx *ctx, dvs_select *s) {
     ExactRow cand;
     if ((rc = fetch_row(ctx, s, c.arb_pos, set, cand))) return rc;
     ExactSet grown;
-    if (!grown.clone_from(set) || !grown.push(std::move(cand)))
+    if (!grown.clone_from(set, true) || !grown.push(std::move(cand)))
         return dvs_set_error(ctx, DVS_ERR_VALUE, "%s", grown.err.c_str());
     const bool better = (c.stat == DVS_STAT_STDEV) ? (grown.std_delta() > set.std_delta())
                                                    : (grown.cov_delta() > set.cov_delta());

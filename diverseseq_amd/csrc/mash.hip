@@ -748,8 +748,13 @@ static int mash_pairs_device(dvs_ctx *ctx, const uint32_t *d_sk, const uint32_t 
         dvs_dev_free(ctx, d_dist);
         return rc;
     }
-    // (cells this call does not visit keep the caller's values: the matrix starts as its copy)
-    hipError_t e = hipMemcpyAsync(d_dist, dist, size_t(nseq) * nseq * 8, hipMemcpyHostToDevice, ctx->stream);
+    // Cells this call does not visit keep the caller's values.  A call over the whole triangle that
+    // mirrors its cells (the usual one) visits everything but the diagonal: only those nseq cells travel
+    // up (one strided copy); any other call starts from a copy of the caller's matrix.
+    const bool whole = row_start == 0 && row_stride == 1 && symmetric;
+    hipError_t e = whole ? hipMemcpy2DAsync(d_dist, (size_t(nseq) + 1) * 8, dist, (size_t(nseq) + 1) * 8, 8, nseq,
+                                            hipMemcpyHostToDevice, ctx->stream)
+                         : hipMemcpyAsync(d_dist, dist, size_t(nseq) * nseq * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, 4, ctx->stream);
     const uint32_t nrows = (nseq - 1 - row_start) / row_stride + 1;
     uint32_t flag = 0;

@@ -779,8 +779,14 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     st.mean_d = ctl->mean_delta;
     st.std_d = ctl->std_delta;
     st.cov_d = ctl->cov_delta;
-    if (ctl->status != SEL_RUN || ctl->ev_kind != 0 || st.n > maxn || st.n < 2) return;
-    if (MAXM && st.n < st.max_size && (ctl->s_is_resum == 0 || st.n + 2 > maxn)) return;  // (multi-launch kernels)
+    if (ctl->status != SEL_RUN || ctl->ev_kind != 0 || st.n > maxn || st.n < 2) {
+        if (lead && tid == 0 && ctl->status == SEL_RUN) ctl->why[7]++;  // (a pending event or a set the replica cannot hold)
+        return;
+    }
+    if (MAXM && st.n < st.max_size && (ctl->s_is_resum == 0 || st.n + 2 > maxn)) {  // (multi-launch kernels)
+        if (lead && tid == 0) ctl->why[6]++;
+        return;
+    }
     // SEEDED start (nmost, the state in the register cache): nothing but the control block and the
     // seed positions exists yet -- no seed / rebuild / loo / finalize launches ran; the initial set
     // (SummedRecords::new, records.rs:27-68) is worked out further down by the grid itself.
@@ -1431,6 +1437,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         }
         if (to_arbiter) {
             st.n_windows--;  // the multi-launch resolve will count this window
+            if (lead && tid == 0) ctl->why[4]++;
             exit_status = SEL_ARBITER;
             arb_stage = ARB_RESOLVE;
             arb_pos = p;
@@ -1442,6 +1449,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 // ================= tentative push (records.rs:427-451): clone + push, keep iff the stat rose
                 const uint32_t n = st.n, n1 = n + 1;
                 if (n1 + 1 > maxn) {  // the LDS replica holds no more members: the multi-launch kernels go on
+                    if (lead && tid == 0) ctl->why[0]++;
                     bail = true;
                     st.n_windows--;
                     break;
@@ -1553,6 +1561,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                                          ? 4.0 * band1
                                          : 4.0 * band1 * (1.0 + fmax(fabs(a), fabs(b))) / fmax(mm, 1e-300);
                 if (anyr || evr || (dsec1 - dmin1 <= band1 && dsec1 < 1e6) || !(fabs(a - b) > sband)) {
+                    if (lead && tid == 0) ctl->why[(anyr || evr) ? 1 : (dsec1 - dmin1 <= band1 && dsec1 < 1e6) ? 2 : 3]++;
                     bail = true;  // too close to call (or NaN): the event stays unconsumed
                     st.n_windows--;
                     st.n_events--;
@@ -2030,6 +2039,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         const double band = sel_band(st.total_jsd + st.sumH / dn, B);
         if (any_risky || ev_risky || (n > 1 && dsecond - dmin <= band && dsecond < 1e6)) {
             if (lead && tid == 0) ctl->ev_risky = ev_risky ? 1 : 0;
+            if (lead && tid == 0) ctl->why[5]++;
             exit_status = SEL_ARBITER;  // argmin too close to call: loo + finalize kernels resume
             arb_stage = ARB_FINALIZE;
             arb_pos = p;

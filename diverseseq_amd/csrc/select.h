@@ -35,6 +35,10 @@ struct SelCtl {
     double t_total_jsd, t_sum_entropy;  // tentative (MODE_MAX push) values
     double last_jsd;
     double wscale;  // next window = cursor * wscale / size (expected rows to the next accept ~ cursor / size)
+    // why persistent launches ended early (DVS_PERSIST_DEBUG prints them): 0 replica full, 1 a sum check not
+    // sure, 2 argmin of a tentative push too close, 3 stat comparison too close, 4 candidate test in band,
+    // 5 argmin after a replace too close, 6 state not taken (s_is_resum / pending event)
+    uint32_t why[8];
 };
 
 // Device pointers of one selection (passed to kernels by value).

@@ -898,6 +898,7 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
     unsigned long long persist_cursor = 0;
     unsigned persist_launches = 0;
     bool persist_was_last = false;  // nothing but the poll happened since the last persistent launch
+    unsigned persist_idle = 0;      // persistent launches in a row that came back where they started
     if (s->persist && first_unpolled) {
         // straight behind the set-up kernels, no host round trip in between: the kernel itself
         // returns at once unless the control block says RUN
@@ -988,6 +989,10 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
             continue;
         }
         if (c.status == SEL_DONE) {
+            if (ctx->knobs.persist_debug)
+                fprintf(stderr, "[dvs persist] launches ended early: replica full %u, sum check %u, push argmin %u, stat comparison %u, "
+                        "candidate in band %u, replace argmin %u, state not taken %u / %u\n", c.why[0], c.why[1], c.why[2], c.why[3],
+                        c.why[4], c.why[5], c.why[6], c.why[7]);
             if (s->persist && persist_launches) ctx->persist_timeouts = 0;
             return DVS_OK;
         }
@@ -1013,8 +1018,10 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
             // not take the state it found (e.g. an event left pending by the arbiter's hand-off):
             // the multi-launch kernels, which take any state, carry on -- never a relaunch loop
             if (persist_launches && persist_was_last && c.cursor == persist_cursor) {
-                persist_was_last = false;  // one batch of multi-launch iterations, then the engine again
+                persist_was_last = false;  // multi-launch iterations, then the engine again
+                persist_idle++;
             } else {
+                if (persist_launches && c.cursor != persist_cursor) persist_idle = 0;
                 persist_cursor = c.cursor;
                 persist_launches++;
                 persist_was_last = true;
@@ -1029,7 +1036,11 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
                 }
             }
         }
-        for (int i = 0; i < s->batch; i++) launch_iteration<T>(ctx, s, mat, 0);
+        // (behind a persistent launch that left ONE event for these kernels -- a decision inside its band --
+        // a single iteration takes that event; the engine is launched again right after)
+        // (an engine that keeps coming back where it started -- a set its replica cannot hold -- gets whole batches)
+        const int iters = (s->persist && persist_launches && !persist_was_last && persist_idle < 2) ? 1 : s->batch;
+        for (int i = 0; i < iters; i++) launch_iteration<T>(ctx, s, mat, 0);
         DVS_HIP(ctx, hipGetLastError());
     }
 }

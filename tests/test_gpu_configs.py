@@ -300,11 +300,15 @@ def test_candidates_inside_the_fast_band_k7(ctx, band_k7, env, monkeypatch):
 
 
 # ---------------------------------------------------------------- stated configurations
-def test_config_c3_scaled_1050_genomes_vs_oracle(ctx):
-    """C3 at N = 1050 (SURVEY 8d's CI variant): genomes of 2.5-3.5 Mb with their own base composition,
-    k=6, `max` min_size=100, max_size=N, stdev -- select_max_divergent (records.rs:390-454) in full
-    against the oracle (~10 s of CPU: 3.15 Gbases counted, ~1000 tentative pushes)"""
-    seqs, offs = synth_device(1050, 2_500_000, 3_500_000, 20260430, composition=True)
+@pytest.mark.parametrize("composition", [True, False])
+def test_config_c3_scaled_1050_genomes_vs_oracle(ctx, composition):
+    """C3 at N = 1050 (SURVEY 8d's CI variant): genomes of 2.5-3.5 Mb, k=6, `max` min_size=100,
+    max_size=N, stdev -- select_max_divergent (records.rs:390-454) in full against the oracle (~10 s of
+    CPU: 3.15 Gbases counted, ~1000 tentative pushes).  composition=True: every genome with its own base
+    composition; False: i.i.d. uniform genomes, whose k-mer spectra agree to 1e-3 -- every tentative push
+    is a near-tie (thousands of rows through the f64 tier, a handful of decisions through the host
+    arbiter, records.rs:86-92,427-451)."""
+    seqs, offs = synth_device(1050, 2_500_000, 3_500_000, 20260430, composition=composition)
     total = int(offs[-1])
     m = ctx.build_matrix_device(seqs.data_ptr(), offs, 6, 4)
     sel = m.max_divergent(100, 1050, "stdev")
