@@ -71,6 +71,10 @@ __device__ __forceinline__ unsigned long long p_acc_word(double v) {
 __device__ __forceinline__ double p_acc_value(unsigned long long w) { return double((long long)w >> 6) * 0x1p-50; }
 __device__ __forceinline__ uint32_t p_acc_count(unsigned long long w) { return uint32_t(w & 63ull); }
 constexpr uint32_t P_SPIN_LIMIT = 1u << 22;  // ~0.5 s of polling
+#ifndef DVS_P_FLAT_GRID
+#define DVS_P_FLAT_GRID 64
+#endif
+constexpr uint32_t P_FLAT_GRID = DVS_P_FLAT_GRID;  // grids of up to this many workgroups rendezvous on one counter
 constexpr uint32_t P_SOFT = 64;              // uncertain candidates listed per window (more become plain events)
 
 struct PLine {  // a polled word on a cache line of its own (256 B apart)
@@ -139,8 +143,11 @@ __device__ bool grid_barrier(PSync *sync, uint32_t G, uint32_t &gen, int *s_ok) 
         const uint32_t gsz = (G - x + 7u) >> 3;  // workgroups with blockIdx % 8 == x
         int ok = 1;
         bool released = false;
-        if (__hip_atomic_fetch_add(&sync->gcount[x].v, 1u, RLX_AGENT) == gsz * target - 1 &&
-            __hip_atomic_fetch_add(&sync->count, 1u, RLX_AGENT) == ng * target - 1) {
+        const bool last = G <= P_FLAT_GRID
+                              ? __hip_atomic_fetch_add(&sync->count, 1u, RLX_AGENT) == G * target - 1
+                              : (__hip_atomic_fetch_add(&sync->gcount[x].v, 1u, RLX_AGENT) == gsz * target - 1 &&
+                                 __hip_atomic_fetch_add(&sync->count, 1u, RLX_AGENT) == ng * target - 1);
+        if (last) {
             for (uint32_t g = 0; g < ng; g++) __hip_atomic_store(&sync->ggen[g].v, target, RLX_AGENT);
             released = true;
         }
@@ -181,8 +188,13 @@ __device__ void grid_arrive(PSync *sync, uint32_t G, uint32_t gen, unsigned long
         const uint32_t target = gen + 1;
         const uint32_t x = blockIdx.x & 7u, ng = G < 8u ? G : 8u;
         const uint32_t gsz = (G - x + 7u) >> 3;
-        if (__hip_atomic_fetch_add(&sync->gcount[x].v, 1u, RLX_AGENT) == gsz * target - 1 &&
-            __hip_atomic_fetch_add(&sync->count, 1u, RLX_AGENT) == ng * target - 1) {
+        // (small grids -- the head phase's 64 workgroups -- arrive on ONE counter: 64 same-address
+        // atomics cost less than the second level's round trip; its words are the top counter's)
+        const bool last = G <= P_FLAT_GRID
+                              ? __hip_atomic_fetch_add(&sync->count, 1u, RLX_AGENT) == G * target - 1
+                              : (__hip_atomic_fetch_add(&sync->gcount[x].v, 1u, RLX_AGENT) == gsz * target - 1 &&
+                                 __hip_atomic_fetch_add(&sync->count, 1u, RLX_AGENT) == ng * target - 1);
+        if (last) {
             for (uint32_t g = 0; g < 8u; g++)
                 __hip_atomic_store(reinterpret_cast<uint32_t *>(evs + g * 32), target, RLX_AGENT);
         }

@@ -146,7 +146,21 @@ def merge_nmost(ctx, sel, n: int, rank: int, world: int, chunk_start: int, devic
 
 
 def merge_max(ctx, sel, min_size: int, max_size: int, stat: str, chunk_start: int, world: int,
-              device, cap: int):
+              device, cap: int, chunk_starts=None, *, shared_stream: bool = False, buffers: dict | None = None):
+    """exchange the winners and run final_max (select_max_divergent_final, src/records.rs:456-507) on
+    the device.  `cap`: the largest set any rank may bring (every rank passes the same value; a rank
+    with fewer members pads).  With `chunk_starts` on a GPU the winners never leave HBM -- gathered
+    into the all_gather's send buffer, wrapped as a frequency matrix (padding rows moved behind the
+    real ones) and merged there, as merge_nmost does."""
+    if chunk_starts is not None and getattr(device, "type", str(device)) == "cuda":
+        all_rows, all_meta = gather_winners_device(ctx, sel, world, device, cap=cap, shared_stream=shared_stream,
+                                                   buffers=buffers)
+        m = ctx.matrix_from_device_freqs(all_rows.data_ptr(), world * cap, sel.matrix.nbins,
+                                         all_meta.data_ptr())
+        merged = m.max_divergent(min_size, max_size, stat)
+        merged._lazy_gids = _LazyGlobalIds(all_meta, chunk_starts, cap, m)
+        merged._keep = m
+        return merged
     mem = sel.members(with_freqs=True)
     ids = mem.positions.astype(np.int64) + chunk_start
     rows, gids = gather_winners(mem.kfreqs, ids, world, device, cap=cap)

@@ -998,6 +998,45 @@ def test_device_side_chunk_merge_short_first_chunk(ctx, brca1):
     np.testing.assert_allclose(gm.delta_jsd, exp.members()[1], rtol=RTOL, atol=1e-13)
 
 
+@pytest.mark.parametrize("stat", ["stdev", "cov"])
+def test_device_side_chunk_merge_max(ctx, brca1, stat):
+    """final_max (select_max_divergent_final, records.rs:456-507) over winners that never leave HBM:
+    three chunks' `max` sets of different sizes gathered into padded device buffers, wrapped by
+    dvs_matrix_from_device_freqs and merged on the device -- against the oracle's final_max over the same rows"""
+    import torch
+
+    from diverseseq_amd.parallel import _global_ids
+
+    seqs = list(brca1.values())
+    bounds = [(0, 20), (20, 24), (24, 55)]  # the middle chunk is smaller than min_size
+    lo, hi, cap, k = 5, 9, 9, 4
+    B = 4 ** k
+    dev = torch.device("cuda:0")
+    all_rows = torch.full((3 * cap, B), -3.0, dtype=torch.float64, device=dev)
+    all_meta = torch.full((3 * cap, 2), -3.0, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    erows, eids = [], []
+    for r, (a, b) in enumerate(bounds):
+        m = ctx.build_matrix(seqs[a:b], k, 4)
+        sel = m.max_divergent(min(lo, b - a), hi, stat)
+        sel.gather_members(all_rows[r * cap:].data_ptr(), all_meta[r * cap:].data_ptr(), cap)
+        ctx.sync()
+        o = oracle.max_divergent(seqs[a:b], min(lo, b - a), hi, k, 4, stat)
+        l, _, _, f = o.members(with_freqs=True)
+        erows.append(f)
+        eids.append(l + a)
+    erows, eids = np.vstack(erows), np.concatenate(eids)
+    mm = ctx.matrix_from_device_freqs(all_rows.data_ptr(), 3 * cap, B, all_meta.data_ptr())
+    gids = _global_ids(all_meta, [a for a, _ in bounds], cap, src_rows=mm.source_rows())
+    got = mm.max_divergent(lo, hi, stat)
+    exp = oracle.final_max(erows, lo, hi, stat, labels=eids)
+    gm = got.members()
+    assert got.summary().size == exp.size
+    assert [int(gids[p]) for p in gm.positions] == exp.members()[0].tolist()
+    np.testing.assert_allclose(gm.delta_jsd, exp.members()[1], rtol=RTOL, atol=1e-13)
+    np.testing.assert_allclose(got.summary().total_jsd, exp.total_jsd, rtol=RTOL)
+
+
 def test_merge_nmost_over_rccl_world1(ctx, brca1):
     """parallel.merge_nmost end to end on the RCCL backend (world 1): device path == host path"""
     import torch
