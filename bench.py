@@ -247,16 +247,21 @@ def main():
             t0 = time.perf_counter()
             _, data_, offs_, _ = _dvs._gather(store, ids)
             t_gather = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            m_ = ctx.build_matrix_concat(data_, offs_, a.k, 4)
-            ctx.sync()
-            t_build = time.perf_counter() - t0
-            m_.close()
+            t_build = None
+            for _ in range(2):  # (the first call makes the context's pinned staging block)
+                t0 = time.perf_counter()
+                m_ = ctx.build_matrix_concat(data_, offs_, a.k, 4)
+                ctx.sync()
+                dt = time.perf_counter() - t0
+                t_build = dt if t_build is None or dt < t_build else t_build
+                m_.close()
             stats["dvs_module"] = {
                 "what": "diverseseq_amd._dvs.nmost_divergent(store, n, k, seqids) on the same sequences held in an "
                         "in-memory store on the host (the reference's call, src/lib.rs:59-73)",
                 "ms": best * 1e3, "sequences_per_s": a.nseq / best, "engine": r_.stats["engine"],
                 "host_gather_ms": t_gather * 1e3, "upload_and_histogram_ms": t_build * 1e3,
+                "upload": "four-state sequences cross PCIe packed (2 + 1 bits per base, packed by host threads chunk by "
+                          "chunk beside the copies, expanded on the device: csrc/pack.hip)",
             }
             del data_, store, host_all
             # BASELINE.json configs[1] (10k x 2 kb, k=6, nmost n=10) as a

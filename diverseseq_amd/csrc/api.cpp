@@ -12,6 +12,8 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs, u
 int dvs_matrix_fill_freq_entropy(dvs_ctx *ctx, dvs_matrix *m);
 int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint32_t k, uint64_t nbytes, size_t *n_long_out);
 bool dvs_hist_rows_fit_u16(const dvs_ctx *ctx, uint64_t B, size_t n_long);
+bool dvs_packed_upload_wanted(const dvs_ctx *ctx, uint32_t num_states, uint64_t nbytes);  // pack.hip
+int dvs_upload_packed(dvs_ctx *ctx, const uint8_t *seqs, uint64_t nbytes, uint8_t *d_out);
 int dvs_matrix_fill_freq_totals(dvs_ctx *ctx, dvs_matrix *m, const double *d_meta);
 int dvs_matrix_fill_compacted(dvs_ctx *ctx, dvs_matrix *m, const double *d_in, const double *d_meta);
 
@@ -124,6 +126,7 @@ void dvs_knobs_from_env(dvs_knobs *k) {
     k->hist_no_split = on("DVS_HIST_NO_SPLIT");
     k->head_rows = num("DVS_HEAD_ROWS", 0);
     k->build_wait = on("DVS_BUILD_WAIT");
+    k->no_packed_upload = on("DVS_NO_PACKED_UPLOAD");
     k->no_cu_split = on("DVS_NO_CU_SPLIT");
     k->head_cus = num("DVS_HEAD_CUS", 0);
     k->cu_mask_set = on("HSA_CU_MASK") || on("ROC_GLOBAL_CU_MASK");
@@ -267,6 +270,8 @@ void dvs_ctx_release(dvs_ctx *ctx) {
     dvs_dev_free(ctx, ctx->off_cache.d_tiles);
     if (ctx->off_cache.ev_up) (void)hipEventDestroy(ctx->off_cache.ev_up);
     if (ctx->off_cache.h_off) (void)hipHostFree(ctx->off_cache.h_off);
+    if (ctx->pack_ev) (void)hipEventDestroy(ctx->pack_ev);
+    if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
     dvs_dev_free(ctx, ctx->d_clog_tbl);
     dvs_dev_trim(ctx);
     for (void *p : ctx->pinned_pool) (void)hipHostFree(p);
@@ -381,7 +386,18 @@ int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, cons
             return rc;
         }
         hipError_t ue = hipMemsetAsync(d_tmp + (nbytes & ~15ull), 0xFF, padded - (nbytes & ~15ull), ctx->stream);
-        if (ue == hipSuccess && nbytes) ue = hipMemcpyAsync(d_tmp, seqs, nbytes, hipMemcpyHostToDevice, ctx->stream);
+        if (ue == hipSuccess && nbytes && dvs_packed_upload_wanted(ctx, num_states, nbytes)) {
+            // four-state sequences: 3 bits per base across PCIe, expanded again on the device (pack.hip)
+            rc = dvs_upload_packed(ctx, seqs, nbytes, d_tmp);
+            if (rc) {
+                dvs_dev_free(ctx, d_tmp);
+                dvs_matrix_free_fields(m);
+                delete m;
+                return rc;
+            }
+        } else if (ue == hipSuccess && nbytes) {
+            ue = hipMemcpyAsync(d_tmp, seqs, nbytes, hipMemcpyHostToDevice, ctx->stream);
+        }
         if (ue != hipSuccess) {  // a failed upload must not become a silently wrong matrix
             (void)hipStreamSynchronize(ctx->stream);
             dvs_dev_free(ctx, d_tmp);

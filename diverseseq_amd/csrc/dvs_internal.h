@@ -30,6 +30,7 @@ struct dvs_knobs {
     bool hist_no_split = false;       // DVS_HIST_NO_SPLIT
     int head_rows = 0;                // DVS_HEAD_ROWS (0: default)
     bool build_wait = false;          // DVS_BUILD_WAIT: device-resident builds wait for their kernels
+    bool no_packed_upload = false;    // DVS_NO_PACKED_UPLOAD: host sequences cross PCIe one byte per base
     // context (api.cpp)
     bool no_cu_split = false;         // DVS_NO_CU_SPLIT
     int head_cus = 0;                 // DVS_HEAD_CUS
@@ -115,6 +116,11 @@ struct dvs_ctx {
         bool uniform = false;
         uint64_t uni_base = 0, uni_stride = 0;
     } off_cache;
+    // packed upload of host sequences (pack.hip): the pinned staging block, kept between calls, and the
+    // event behind the last copy that read it
+    void *h_pack = nullptr;
+    size_t h_pack_cap = 0;
+    hipEvent_t pack_ev = nullptr;
 };
 // hipFuncAttributeMaxDynamicSharedMemorySize >= bytes for kernel fn on this context's device
 int dvs_raise_dyn_lds(dvs_ctx *ctx, const void *fn, size_t bytes);

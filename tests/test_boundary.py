@@ -156,3 +156,27 @@ def test_concat():
     assert data.tolist() == [0, 1, 2, 3, 0] and offs.tolist() == [0, 2, 5, 5]
     data, offs = engine.concat([])
     assert offs.tolist() == [0]
+
+
+def test_host_packer_of_the_packed_upload():
+    """csrc/pack_host.cpp (AVX2 + BMI2 when the CPU has them, scalar otherwise): 2 bits per base + 1
+    invalid bit per base, positions behind the end of a ragged tail marked invalid -- against a numpy
+    restatement, at every length around the 32-base groups"""
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    f = lib.dvs_pack_bases
+    f.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    f.restype = None
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 31, 32, 33, 63, 64, 65, 1000, 4099, 1 << 16):
+        src = rng.integers(0, 4, size=n, dtype=np.uint8)
+        if n:
+            src[rng.integers(0, n, size=n // 10 + 1)] = rng.integers(4, 256, size=n // 10 + 1, dtype=np.uint8)
+        n32 = (n + 31) // 32
+        codes = np.zeros(max(1, n32 * 8), np.uint8)
+        mask = np.zeros(max(1, n32 * 4), np.uint8)
+        f(src.ctypes.data, n, codes.ctypes.data, mask.ctypes.data)
+        pad = np.full(n32 * 32, 255, np.uint8)
+        pad[:n] = src
+        ec = ((pad & 3).reshape(-1, 4).astype(np.uint32) << (2 * np.arange(4, dtype=np.uint32))).sum(axis=1).astype(np.uint8)
+        em = np.packbits((pad > 3).astype(np.uint8), bitorder="little")
+        assert (codes[: n32 * 8] == ec).all() and (mask[: n32 * 4] == em).all(), n

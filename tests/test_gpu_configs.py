@@ -571,3 +571,30 @@ def test_uniform_length_builds_need_no_offsets_on_the_device(ctx, monkeypatch):
         for i in (0, nseq // 2, nseq - 1):
             a = lead + i * length
             assert (got[i] == oracle.count_kmers(data[a:a + length], 4, k)).all()
+
+
+def test_packed_upload_builds_the_same_matrix(ctx, monkeypatch):
+    """A host buffer of four-state sequences crosses PCIe as 2 + 1 bits per base and is expanded on the
+    device (csrc/pack.hip); the count matrix is the one the plain one-byte-per-base upload gives and
+    count_kmers' (src/record.rs:41-84) -- with invalid symbols of every value, a ragged total length and
+    several 4 MiB chunks."""
+    rng = np.random.default_rng(808)
+    nseq = 9000
+    lens = rng.integers(3000, 4500, size=nseq)
+    offs = np.zeros(nseq + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    total = int(offs[-1])
+    assert total > (32 << 20) and total % 32 != 0
+    data = rng.integers(0, 4, size=total, dtype=np.uint8)
+    bad = rng.integers(0, total, size=total // 700)
+    data[bad] = rng.integers(4, 256, size=bad.size, dtype=np.uint8)
+    m = ctx.build_matrix_concat(data, offs, 6, 4)
+    got = m.counts()
+    m.close()
+    monkeypatch.setenv("DVS_NO_PACKED_UPLOAD", "1")
+    m2 = ctx.build_matrix_concat(data, offs, 6, 4)
+    ref = m2.counts()
+    m2.close()
+    assert (got == ref).all()
+    for i in (0, 4321, nseq - 1):
+        assert (got[i] == oracle.count_kmers(data[int(offs[i]):int(offs[i + 1])], 4, 6)).all()
