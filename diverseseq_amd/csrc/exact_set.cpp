@@ -63,6 +63,7 @@ class ExactSet {
     }
 
     bool contains(uint32_t label) const {
+        if (label == 0xFFFFFFFFu) return false;  // (no identity: a row that lives on another rank)
         for (const ExactRow &r : recs)
             if (r.label == label) return true;
         return false;
@@ -264,6 +265,19 @@ int fetch_row(dvs_ctx *ctx, const dvs_select *s, uint64_t p, ExactSet &scratch, 
     return DVS_OK;
 }
 
+// the same from a frequency row already on the device (stepwise selections: the row log, the pending
+// candidate in d.cand, a tentative member's row) -- the row itself may live on another rank
+int fetch_dev_row(dvs_ctx *ctx, const dvs_select *s, uint64_t p, const double *d_row, ExactSet &scratch, ExactRow &out) {
+    const uint64_t B = s->mat->nbins;
+    const uint32_t row = s->h_order.empty() ? uint32_t(p) : s->h_order[p];
+    out.pos = p;
+    out.label = row == DVS_ROW_REMOTE ? 0xFFFFFFFFu : (s->h_labels.empty() ? row : s->h_labels[p]);
+    out.f.resize(B);
+    DVS_HIP(ctx, hipMemcpy(out.f.data(), d_row, B * 8, hipMemcpyDeviceToHost));
+    if (!scratch.entropy(out.f.data(), B, out.H)) return dvs_set_error(ctx, DVS_ERR_VALUE, "%s", scratch.err.c_str());
+    return DVS_OK;
+}
+
 int write_forced(dvs_ctx *ctx, dvs_select *s, uint32_t forced, uint32_t forced_lowest) {
     SelCtl *d = s->dev.ctl;
     const uint32_t run = SEL_RUN;
@@ -284,6 +298,7 @@ int dvs_select_arbitrate(dvs_ctx *ctx, dvs_select *s) {
     set.B = B;
     if (set.work.size() != B) set.work.assign(B, 0.0);
     int rc;
+    const bool stepwise = (s->params.flags & DVS_SELECT_STEPWISE) != 0;
     if (!a.built) {  // SummedRecords::new over the usable seeds (records.rs:288-308)
         std::vector<ExactRow> rows(s->seed_positions.size());
         for (size_t i = 0; i < rows.size(); i++)
@@ -301,7 +316,16 @@ int dvs_select_arbitrate(dvs_ctx *ctx, dvs_select *s) {
         DVS_HIP(ctx, hipMemcpy(kind.data(), s->dev.evlog_kind + a.replayed, size_t(cnt) * 4, hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < cnt; i++) {
             ExactRow r;
-            if ((rc = fetch_row(ctx, s, pos[i], set, r))) return rc;
+            if (stepwise) {
+                const uint32_t at = a.replayed + i;
+                if (at >= s->dev.rowlog_cap)
+                    return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "tie arbitration in the stepwise mode: more than %u "
+                                         "accepted events, the row log is full", s->dev.rowlog_cap);
+                rc = fetch_dev_row(ctx, s, pos[i], s->dev.rowlog + uint64_t(at) * B, set, r);
+            } else {
+                rc = fetch_row(ctx, s, pos[i], set, r);
+            }
+            if (rc) return rc;
             bool ok;
             if (kind[i] == 1) {
                 ok = set.replace_lowest(std::move(r));
@@ -319,7 +343,8 @@ int dvs_select_arbitrate(dvs_ctx *ctx, dvs_select *s) {
 
     if (c.arb_stage == ARB_RESOLVE) {
         ExactRow cand;
-        if ((rc = fetch_row(ctx, s, c.arb_pos, set, cand))) return rc;
+        rc = stepwise ? fetch_dev_row(ctx, s, c.arb_pos, s->dev.cand, set, cand) : fetch_row(ctx, s, c.arb_pos, set, cand);
+        if (rc) return rc;
         bool inc;
         if (!set.increases(cand, inc)) return dvs_set_error(ctx, DVS_ERR_VALUE, "%s", set.err.c_str());
         return write_forced(ctx, s, inc ? FORCE_ACCEPT : FORCE_REJECT, 0xFFFFFFFFu);
@@ -334,7 +359,9 @@ int dvs_select_arbitrate(dvs_ctx *ctx, dvs_select *s) {
     }
     // tentative push of the candidate at arb_pos (records.rs:438-450)
     ExactRow cand;
-    if ((rc = fetch_row(ctx, s, c.arb_pos, set, cand))) return rc;
+    rc = stepwise ? fetch_dev_row(ctx, s, c.arb_pos, s->dev.M + uint64_t(c.ev_n - 1) * B, set, cand)
+                  : fetch_row(ctx, s, c.arb_pos, set, cand);
+    if (rc) return rc;
     ExactSet grown;
     if (!grown.clone_from(set, true) || !grown.push(std::move(cand)))
         return dvs_set_error(ctx, DVS_ERR_VALUE, "%s", grown.err.c_str());

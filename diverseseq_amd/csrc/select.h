@@ -34,6 +34,7 @@ struct SelCtl {
     double mean_delta, std_delta, cov_delta;
     double t_total_jsd, t_sum_entropy;  // tentative (MODE_MAX push) values
     double last_jsd;
+    double arb_H;   // entropy of the candidate a resolve stopped at (stepwise re-entry takes it from here)
     double wscale;  // next window = cursor * wscale / size (expected rows to the next accept ~ cursor / size)
     // why persistent launches ended early (DVS_PERSIST_DEBUG prints them): 0 replica full, 1 a sum check not
     // sure, 2 argmin of a tentative push too close, 3 stat comparison too close, 4 candidate test in band,
@@ -72,6 +73,10 @@ struct SelDev {
     // the earliest event itself and takes the candidate from there instead of the local matrix
     const double *gather_all = nullptr;
     uint32_t gather_world = 0;
+    // ... and the frequency row of every accepted event, in event-log order (rowlog_cap rows): what the
+    // tie arbiter replays from when the rows themselves live on other ranks
+    double *rowlog = nullptr;
+    uint32_t rowlog_cap = 0;
 };
 
 struct dvs_select {

@@ -329,7 +329,11 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, double *scrat
         ext_H = src + 1;
         gathered_p = s_best < 0 ? SEL_NONE : (unsigned long long)src[0];
     }
-    const uint64_t p = d.gather_all ? gathered_p : ctl->event_pos;
+    // (stepwise re-entry behind the arbiter: the slots have been gathered anew since the decision was left
+    // open -- the candidate is the one resolve stopped at, still in d.cand)
+    const bool reentry = d.gather_all && (ctl->forced == FORCE_ACCEPT || ctl->forced == FORCE_REJECT);
+    const uint64_t p = reentry ? ctl->arb_pos : d.gather_all ? gathered_p : ctl->event_pos;
+    if (reentry && tid == 0) ctl->event_pos = p;
     if (ctl->ev_kind != 0) return;  // a finalize is pending (arbiter re-entry)
     if (p == SEL_NONE) {
         if (tid == 0) {
@@ -344,7 +348,10 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, double *scrat
     const uint32_t row = d.order ? d.order[p] : uint32_t(p);
     uint32_t lab;
     double cand_H;
-    if (ext_row) {  // exchanged candidate (its row may live on another rank)
+    if (reentry) {
+        lab = (row == DVS_ROW_REMOTE) ? DVS_ROW_REMOTE : (d.labels ? d.labels[p] : row);
+        cand_H = ctl->arb_H;
+    } else if (ext_row) {  // exchanged candidate (its row may live on another rank)
         lab = (row == DVS_ROW_REMOTE) ? DVS_ROW_REMOTE : (d.labels ? d.labels[p] : row);
         cand_H = *ext_H;
         for (uint64_t i = tid; i < d.B; i += WIDE) d.cand[i] = ext_row[i];
@@ -370,6 +377,7 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, double *scrat
             ctl->status = SEL_ARBITER;
             ctl->arb_stage = ARB_RESOLVE;
             ctl->arb_pos = p;
+            ctl->arb_H = cand_H;
             action = 3;
         } else {
             action = (jsd > ctl->thr) ? 1 : 0;  // NaN -> reject (records.rs:91)
@@ -394,6 +402,9 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, double *scrat
         const uint32_t li = ctl->lowest, n = ctl->size;
         const uint32_t s = d.ord[li];
         double *mrow = d.M + uint64_t(s) * d.B;
+        const uint32_t log_at = ctl->n_logged;  // (read by every thread before thread 0 moves it on, below)
+        double *logrow = (d.rowlog && log_at < d.rowlog_cap) ? d.rowlog + uint64_t(log_at) * d.B : nullptr;
+        __syncthreads();
         if (tid == 0) ctl->s_is_resum = 0;
         for (uint64_t i = tid; i < d.B; i += WIDE) {
             double v = d.S[i] - mrow[i];
@@ -401,6 +412,7 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, double *scrat
             const double f = d.cand[i];
             d.S[i] = v + f;
             mrow[i] = f;
+            if (logrow) logrow[i] = f;
         }
         __syncthreads();
         if (tid == 0) {
@@ -687,6 +699,11 @@ __device__ void finalize_body(SelDev &d, double *scratch, int &s_go) {
     const int go = s_go;
     if (go < 0) return;
     if (go == 1) {
+        if (kind == 2 && d.rowlog && ctl->n_logged && ctl->n_logged - 1 < d.rowlog_cap) {  // the kept push's row
+            const double *src = d.M + uint64_t(n - 1) * d.B;
+            double *dst = d.rowlog + uint64_t(ctl->n_logged - 1) * d.B;
+            for (uint64_t i = tid; i < d.B; i += WIDE) dst[i] = src[i];
+        }
         for (uint32_t r = tid; r < n; r += WIDE) d.mDelta[r] = d.dtmp[r];
         if (kind == 2)
             for (uint64_t i = tid; i < d.B; i += WIDE) d.S[i] = d.Stmp[i];
@@ -832,7 +849,7 @@ static void sel_free(dvs_select *s) {
     }
     void *ptrs[] = {s->dev.ctl, s->dev.S, s->dev.Stmp, s->dev.base, s->dev.cand, s->dev.M,
                     s->dev.mH, s->dev.mDelta, s->dev.dtmp, s->dev.dsum, s->dev.mLabel, s->dev.mPos,
-                    s->dev.ord, s->dev.inset, s->dev.wg_rows, s->dev.evlog_pos, s->dev.evlog_kind,
+                    s->dev.ord, s->dev.inset, s->dev.wg_rows, s->dev.evlog_pos, s->dev.evlog_kind, s->dev.rowlog,
                     (void *)s->dev.order, (void *)s->dev.labels};
     for (void *p : ptrs)
         dvs_dev_free(s->ctx, p);
@@ -1211,7 +1228,6 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     s->params = *params;
     s->params.n_seed = n_seed;
     s->params.max_size = max_size;
-    if (s->params.flags & DVS_SELECT_STEPWISE) s->params.flags |= DVS_SELECT_NO_ARBITER;
     s->mat = m;
     s->mat_kind = m->kind;
     s->npos = npos;
@@ -1283,6 +1299,13 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     SEL_ALLOC(d.wg_rows, size_t(s->scan_grid) * 8);
     SEL_ALLOC(d.evlog_pos, size_t(npos - n_seed + 2) * 8);
     SEL_ALLOC(d.evlog_kind, size_t(npos - n_seed + 2) * 4);
+    if (s->params.flags & DVS_SELECT_STEPWISE) {
+        // the arbiter's row log (rows of accepted candidates may live on other ranks): every event a
+        // selection of this size can be expected to accept, at most 256 MB
+        const uint64_t want = std::min<uint64_t>(npos - n_seed + 2, std::max<uint64_t>(64, (uint64_t(256) << 20) / (B * 8)));
+        d.rowlog_cap = uint32_t(want);
+        SEL_ALLOC(d.rowlog, size_t(want) * B * 8);
+    }
     if (order) {
         SEL_ALLOC(d.order, size_t(npos) * 4);
         SEL_HIP(hipMemcpyAsync((void *)d.order, order, size_t(npos) * 4, hipMemcpyHostToDevice,
@@ -1666,11 +1689,25 @@ extern "C" int dvs_select_step_poll(dvs_ctx *ctx, dvs_select *s, uint32_t *statu
     if (rc) return rc;
     if (status) *status = s->h_ctl->status;
     if (cursor) *cursor = s->h_ctl->cursor;
-    if (s->h_ctl->status == SEL_ARBITER)
-        return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED,
-                             "ambiguous decision at stream position %llu: the stepwise (distributed) "
-                             "mode has no tie arbitration",
-                             (unsigned long long)s->h_ctl->arb_pos);
+    if (s->h_ctl->status == SEL_ARBITER) {
+        // A decision inside the rounding band: every rank holds the same replicated state, the same row
+        // log and the same pending candidate, so every rank's arbiter reaches the same verdict on its own
+        // -- no exchange.  The steps enqueued since the engine stopped were no-ops on every rank alike.
+        if (s->params.flags & DVS_SELECT_NO_ARBITER)
+            return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED,
+                                 "ambiguous decision at stream position %llu (stage %u): "
+                                 "|score - threshold| within the rounding band",
+                                 (unsigned long long)s->h_ctl->arb_pos, s->h_ctl->arb_stage);
+        const uint32_t stage = s->h_ctl->arb_stage;
+        rc = dvs_select_arbitrate(ctx, s);
+        if (rc) return rc;
+        dvs_mat_dispatch(s->mat, [&](auto *mp) {
+            launch_iteration(ctx, s, mp, stage == ARB_RESOLVE ? 1 : 2);
+            return 0;
+        });
+        DVS_HIP(ctx, hipGetLastError());
+        if (status) *status = SEL_RUN;
+    }
     return DVS_OK;
 }
 

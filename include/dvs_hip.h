@@ -219,7 +219,11 @@ int dvs_select_delta_jsd(dvs_ctx *ctx, const dvs_select *s, const dvs_matrix *qu
  *                          step's event (a position is scored by one rank only): resolve +
  *                          leave-one-out + finalize with that candidate, identical arithmetic on
  *                          every rank so the replicas stay bit-identical
- * dvs_select_step_poll syncs and returns the status (0 running, 1 done) / cursor. */
+ * dvs_select_step_poll syncs and returns the status (0 running, 1 done) / cursor.  When the engine has
+ * stopped at a decision inside the rounding band (src/records.rs:86-92,231,246-249) the poll runs the host
+ * tie arbiter -- on every rank alike: same seeds, same row log of accepted candidates, same pending
+ * candidate, hence the same verdict with no exchange -- and re-enters the step kernels; steps enqueued in
+ * between were no-ops.  (DVS_SELECT_NO_ARBITER turns that into an error.) */
 int dvs_select_step_pack(dvs_ctx *ctx, dvs_select *s, double *d_slot);
 int dvs_select_step_apply(dvs_ctx *ctx, dvs_select *s, const double *d_all, uint32_t world);
 int dvs_select_step_poll(dvs_ctx *ctx, dvs_select *s, uint32_t *status, uint64_t *cursor);

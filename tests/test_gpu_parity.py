@@ -784,7 +784,24 @@ def test_persistent_engine_odd_bin_counts(ctx):
 
 
 # ------------------------------------------------------ exact row-sharded mode
-def _exact_worker(rank, world, port, q):
+def _degenerate_seqs():
+    """sequences in which exact ties abound: blocks of identical copies and near-copies (one base changed)
+    of a few short sequences, a handful of unrelated ones in between"""
+    rng = np.random.default_rng(77)
+    base = [rng.integers(0, 4, size=int(rng.integers(150, 260)), dtype=np.uint8) for _ in range(6)]
+    seqs = []
+    for i in range(420):
+        b = base[int(rng.integers(0, len(base)))].copy()
+        r = rng.random()
+        if r < 0.35:
+            b[int(rng.integers(0, b.size))] = (b[0] + 1) % 4  # a near-copy
+        elif r < 0.45:
+            b = rng.integers(0, 4, size=int(rng.integers(150, 260)), dtype=np.uint8)
+        seqs.append(b)
+    return seqs
+
+
+def _exact_worker(rank, world, port, q, degenerate=False):
     import os
     import sys
 
@@ -802,8 +819,8 @@ def _exact_worker(rank, world, port, q):
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         ctx = engine.Context(0, stream=stream.cuda_stream)
-        seqs = synth_seqs(1500, 600, 123, invalid_frac=0.001, ragged=True)
-        n, k = 12, 5
+        seqs = _degenerate_seqs() if degenerate else synth_seqs(1500, 600, 123, invalid_frac=0.001, ragged=True)
+        n, k = (7, 3) if degenerate else (12, 5)
         owned, order = parallel.shard_order(len(seqs), n, rank, world, block=32)
         local = seqs[:n] + [seqs[int(p)] for p in owned]
         m = ctx.build_matrix(local, k, 4)
@@ -817,6 +834,7 @@ def _exact_worker(rank, world, port, q):
             mem = sel.members(with_freqs=False)
             s = sel.summary()
             out.append((mem.positions.tolist(), mem.delta_jsd.tolist(), s.total_jsd))
+            out.append(int(s.n_arbitrated))
         q.put(tuple(out))
     if world > 1:
         dist.destroy_process_group()
@@ -847,12 +865,47 @@ def test_exact_row_sharded_mode(world):
     exps = [oracle.nmost(seqs, 12, 5, 4), oracle.max_divergent(seqs, 12, 40, 5, 4, "stdev"),
             oracle.max_divergent(seqs, 12, 40, 5, 4, "cov")]
     for r in res:
-        for (pos, delta, total), exp in zip(r[1:], exps):
+        for (pos, delta, total), exp in zip((r[1], r[2], r[4]), exps):
             elab, edelta, _, _ = exp.members()
             assert pos == elab.tolist()
             np.testing.assert_allclose(delta, edelta, rtol=RTOL, atol=1e-13)
             np.testing.assert_allclose(total, exp.total_jsd, rtol=RTOL)
     assert res[0][1:] == res[-1][1:]  # replicas are bit-identical
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_exact_row_sharded_mode_arbitrates_ties(world):
+    """Degenerate input (identical and near-identical sequences: decisions inside the rounding band) in
+    the exact row-sharded mode: every rank's host arbiter replays the same event log -- from the row log
+    the step kernels keep, since the rows themselves may live on another rank -- and reaches the same
+    verdict with no exchange; the answer is the one-process oracle's (records.rs:86-92,231,246-249)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_exact_worker, args=(r, world, port, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seqs = _degenerate_seqs()
+    exps = [oracle.nmost(seqs, 7, 3, 4), oracle.max_divergent(seqs, 7, 40, 3, 4, "stdev"),
+            oracle.max_divergent(seqs, 7, 40, 3, 4, "cov")]
+    for r in res:
+        for (pos, delta, total), exp in zip((r[1], r[2], r[4]), exps):
+            elab, edelta, _, _ = exp.members()
+            assert pos == elab.tolist()
+            np.testing.assert_allclose(delta, edelta, rtol=RTOL, atol=1e-13)
+            np.testing.assert_allclose(total, exp.total_jsd, rtol=RTOL)
+        assert r[3] + r[5] > 0, "no decision went to the arbiter: the input is not degenerate enough"
+    assert res[0][1:] == res[-1][1:]
 
 
 def _mash_shard_worker(rank, world, port, q):
