@@ -246,6 +246,18 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
         const unsigned long long ev = p_ev_pos(__hip_atomic_load(evp, RLX_AGENT));
         const uint32_t tot = totals[p];
         const double hrow = rowH[p];
+        // 16-bit rows of 4096 bins: the row is requested TOGETHER with the look at the event word, not behind
+        // it (the word is a device-scope round trip of its own; a row requested for nothing -- an earlier
+        // event exists -- costs 8 KiB of traffic once per wave and window)
+        [[maybe_unused]] uint4 raw8[8];
+        constexpr bool ROW16 = COARSE && sizeof(T) == 2;
+        const bool early16 = ROW16 && B == 4096 && vec && coarse_on;
+        if constexpr (ROW16) {
+            if (early16) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) raw8[j] = *reinterpret_cast<const uint4 *>(rp + j * 512 + lane * 8);
+            }
+        }
         if (ev < p) break;
         if (tot == 0) continue;
         const double rt = 1.0 / double(tot);
@@ -259,11 +271,8 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                 bool done16 = false;
                 if constexpr (sizeof(T) == 2) {
                     // 16-bit rows of 4096 bins: eight 16-byte loads per lane (lane l owns bins
-                    // 512 j + 8 l .. + 7), the whole 8 KiB row requested at once
+                    // 512 j + 8 l .. + 7), the whole 8 KiB row requested at once (above)
                     if (B == 4096) {
-                        uint4 raw8[8];
-#pragma unroll
-                        for (int j = 0; j < 8; j++) raw8[j] = *reinterpret_cast<const uint4 *>(rp + j * 512 + lane * 8);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
@@ -545,7 +554,8 @@ __device__ __forceinline__ void p_scan_rows_wg_stream(const T *__restrict__ mat,
                                                       unsigned long long *evp, unsigned long long *evs,
                                                       unsigned long long *softp, uint64_t first,
                                                       uint64_t stride, uint64_t nrows, double *red,
-                                                      uint32_t &nread, uint32_t &nprecise, uint32_t &nmid) {
+                                                      uint32_t &nread, uint32_t &nprecise, uint32_t &nmid,
+                                                      bool no_first_poll = true) {
     constexpr uint64_t B = 4096;
     constexpr int D = 4;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -560,7 +570,10 @@ __device__ __forceinline__ void p_scan_rows_wg_stream(const T *__restrict__ mat,
         double hrow;
         unsigned long long ev;
     };
-    auto issue = [&](Row &w, uint64_t r) {
+    // poll: also look at the event word (a device-scope round trip, longer than an L2 hit on the row).  The
+    // window's first rows go without it -- the window has only just begun, and a row scored for nothing
+    // changes no answer -- so the first score waits for its row alone.
+    auto issue = [&](Row &w, uint64_t r, bool poll) {
         const uint64_t p = st.cursor + r;
         const T *rp = mat + p * B;
         if constexpr (W16) {
@@ -572,7 +585,7 @@ __device__ __forceinline__ void p_scan_rows_wg_stream(const T *__restrict__ mat,
         w.tot = totals[p];
         if (wave == 0) {  // the row's entropy and the event word travel through LDS with the partial sums
             w.hrow = rowH[p];
-            w.ev = p_ev_pos(__hip_atomic_load(evp, RLX_AGENT));
+            w.ev = poll ? p_ev_pos(__hip_atomic_load(evp, RLX_AGENT)) : SEL_NONE;
         }
     };
     uint32_t par = 0;
@@ -627,14 +640,14 @@ __device__ __forceinline__ void p_scan_rows_wg_stream(const T *__restrict__ mat,
     Row w[D];
 #pragma unroll
     for (int d = 0; d < D; d++)
-        if (first + uint64_t(d) * stride < nrows) issue(w[d], first + uint64_t(d) * stride);
+        if (first + uint64_t(d) * stride < nrows) issue(w[d], first + uint64_t(d) * stride, no_first_poll ? d >= 2 : true);
     for (uint64_t base = first; base < nrows; base += uint64_t(D) * stride) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
             const uint64_t r = base + uint64_t(d) * stride;
             if (r >= nrows) return;
             if (!process(w[d], r)) return;
-            if (r + uint64_t(D) * stride < nrows) issue(w[d], r + uint64_t(D) * stride);
+            if (r + uint64_t(D) * stride < nrows) issue(w[d], r + uint64_t(D) * stride, true);
         }
     }
 }
