@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     const double nv = Sreg[j] - count_freq_x(lv[j], ltot, lrt);
                     sl[i] = nv;
                     if (COARSE) slf[i] = coarse_sl(nv, rn0);
-                    if (lead) d.base[i] = nv / dn0;
+                    (void)dn0;
                 }
             }
         }
@@ -1120,13 +1120,14 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // the slot of the NEXT epoch is cleared now (event words, listed flags, the list's count -- not the
         // generations); an exchange (its result is consumed) has been performed before this thread's
         // arrival at the barrier below can be
+        // (plain stores, nobody waits for them: this wave's arrival at the window's rendezvous below is a
+        // returning atomic issued behind them, and a wave's memory operations are acknowledged in order --
+        // they have been performed before anybody can leave that rendezvous and post to the slot)
         if (lead && tid < 17) {
             unsigned long long *nx = &sync->ev[(epoch + 1) % 3][0];
-            bool odd = false;
-            if (tid < 8) odd = __hip_atomic_exchange(nx + tid * 32 + 1, SEL_NONE, RLX_AGENT) == 3ull;
-            else if (tid < 16) odd = __hip_atomic_exchange(reinterpret_cast<uint32_t *>(nx + (tid - 8) * 32) + 1, 0u, RLX_AGENT) == 0xDEADBEEFu;
-            else odd = __hip_atomic_exchange(&sync->soft[(epoch + 1) % 3][0], 0ull, RLX_AGENT) == ~0ull;
-            if (odd) sync->pad0[1] = 1;  // (consumes the results; never: position 1 is a seed, the flag is 0 or 1)
+            if (tid < 8) __hip_atomic_store(nx + tid * 32 + 1, SEL_NONE, RLX_AGENT);
+            else if (tid < 16) __hip_atomic_store(reinterpret_cast<uint32_t *>(nx + (tid - 8) * 32) + 1, 0u, RLX_AGENT);
+            else __hip_atomic_store(&sync->soft[(epoch + 1) % 3][0], 0ull, RLX_AGENT);
         }
 #ifdef DVS_PERSIST_STAMPS
         const unsigned long long t_window = __builtin_amdgcn_s_memrealtime();
@@ -1623,7 +1624,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                             if (lead) {
                                 d.S[i] = stv;
                                 d.M[uint64_t(n) * B + i] = f;
-                                d.base[i] = nv / dn1;
+                                (void)dn1;
                             }
                         }
                     }
@@ -2114,7 +2115,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                         sl[i] = nv;
                         if (MAXM) Sl[i] = sn;
                         if (COARSE) slf[i] = coarse_sl(nv, rn);
-                        if (lead) d.base[i] = nv / dn;
+                        (void)dn;
                     }
                 }
             }
@@ -2137,6 +2138,13 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     if ((lead || blockIdx.x == 0) && tid == 0)
         for (int k_ = 0; k_ < 16; k_++) (lead ? sync->dbg : sync->dbg2)[k_] += s_dbg[k_];
 #endif
+    // ---- exit: the scan vector of the multi-launch kernels, base = (S - lowest) / size -- sl / n, bin by bin
+    // the value their finalize kernel forms -- once per launch instead of once per accept.  (Not behind an
+    // argmin left to the arbiter: the kernels that take over rewrite it before anything scans.)
+    if (lead && exit_status != SEL_ERROR && !(exit_status == SEL_ARBITER && arb_stage == ARB_FINALIZE)) {
+        const double dn_x = double(st.n);
+        for (uint64_t i = tid; i < B; i += P_THREADS) d.base[i] = sl[i] / dn_x;
+    }
     // ---- exit: counters, and the lead block's scalar mirror
     if (lane == 0 && nread) {
         atomicAdd(&ctl->rows_scored, (unsigned long long)nread);
