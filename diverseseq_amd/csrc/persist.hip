@@ -246,18 +246,6 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
         const unsigned long long ev = p_ev_pos(__hip_atomic_load(evp, RLX_AGENT));
         const uint32_t tot = totals[p];
         const double hrow = rowH[p];
-        // 16-bit rows of 4096 bins: the row is requested TOGETHER with the look at the event word, not behind
-        // it (the word is a device-scope round trip of its own; a row requested for nothing -- an earlier
-        // event exists -- costs 8 KiB of traffic once per wave and window)
-        [[maybe_unused]] uint4 raw8[8];
-        constexpr bool ROW16 = COARSE && sizeof(T) == 2;
-        const bool early16 = ROW16 && B == 4096 && vec && coarse_on;
-        if constexpr (ROW16) {
-            if (early16) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) raw8[j] = *reinterpret_cast<const uint4 *>(rp + j * 512 + lane * 8);
-            }
-        }
         if (ev < p) break;
         if (tot == 0) continue;
         const double rt = 1.0 / double(tot);
@@ -271,8 +259,13 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                 bool done16 = false;
                 if constexpr (sizeof(T) == 2) {
                     // 16-bit rows of 4096 bins: eight 16-byte loads per lane (lane l owns bins
-                    // 512 j + 8 l .. + 7), the whole 8 KiB row requested at once (above)
+                    // 512 j + 8 l .. + 7), the whole 8 KiB row requested at once.  (Requesting it beside the
+                    // look at the event word instead of behind it -- all of it, half, a quarter -- measured
+                    // the same step and event-free pass, and half again as much traffic for rows dropped.)
                     if (B == 4096) {
+                        uint4 raw8[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) raw8[j] = *reinterpret_cast<const uint4 *>(rp + j * 512 + lane * 8);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
