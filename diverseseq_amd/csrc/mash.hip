@@ -34,7 +34,6 @@ constexpr int MASH_THREADS = 256;
 constexpr uint32_t MASH_TILE = 8192;       // windows per workgroup
 constexpr uint32_t SORT_CAP = 16384;       // candidates one workgroup sorts in LDS (64 KB)
 constexpr int MAX_K = 64;
-constexpr uint32_t MASH_PAIR_LDS = 8192;   // hashes of the shared row a pairs block stages in LDS (32 KB)
 
 struct MTile {
     uint64_t begin;  // first window START (absolute byte offset)
@@ -366,50 +365,162 @@ __global__ __launch_bounds__(1024) void sort_select_kernel(
     }
 }
 
-// mash_distance for the pair (i, j < i); one thread per pair
-__global__ __launch_bounds__(256) void mash_pairs_kernel(
+// mash_distance for the pair (i, j < i); one thread per pair (distance.py:230-291).  A lane's merge takes
+// one hash of either sketch per step, so what decides the kernel's speed is how the two sketches reach the
+// lane.  Row i is shared by the block's 256 pairs: staged once in LDS and read in place (the lanes of a
+// wave stand within a few dozen hashes of each other, so their reads fall into different banks or onto the
+// same word).  Row j differs per lane: 64 lanes walk 64 different rows, and the texture path serves one
+// lane's 16 bytes per clock however the loads are arranged -- so every byte of row j must be requested
+// exactly once.  Each lane keeps a circular WINDOW of 16-byte blocks of its row in LDS, stored word-major
+// (word w of lane t at [w][t]: a wave's 64 reads always fall into 64 different banks), and every PAIR_W
+// steps -- wave-uniform control flow -- the blocks requested a trip earlier are written into it and the
+// ones the lane has used up since are requested (so no step ever waits for memory); the step itself is two
+// LDS reads and some fifteen integer instructions, no branch.  The windows are private to their lane: no
+// barrier in the loop.
+//   geometry: a lane at word ri needs blocks [b, b + AHEAD), b = ri >> 2, for PAIR_W steps; it moves on by at
+//   most ADV blocks per trip; so blocks up to b + AHEAD + ADV are requested at every trip and a window of
+//   SLOTS >= AHEAD + ADV blocks never overwrites a block at or ahead of the lane's position.
+#ifndef DVS_PAIR_W
+#define DVS_PAIR_W 4
+#endif
+constexpr int PAIR_W = DVS_PAIR_W;               // merge steps per trip
+constexpr int PAIR_AHEAD = (PAIR_W + 3 + 3) / 4;  // blocks a trip may read
+constexpr int PAIR_ADV = (PAIR_W + 3) / 4;        // blocks a trip may leave behind
+constexpr int PAIR_SLOTS = PAIR_AHEAD + PAIR_ADV <= 4 ? 4 : 8;  // blocks of the circular window
+static_assert(PAIR_AHEAD + PAIR_ADV <= PAIR_SLOTS, "window too small for PAIR_W");
+constexpr int PAIR_THREADS = 256;
+constexpr uint32_t PAIR_ROW_LDS = 8192;  // hashes of row i staged in LDS at most (longer sketches are read through L1)
+
+__global__ __launch_bounds__(PAIR_THREADS) void mash_pairs_kernel(
     const uint32_t *__restrict__ sketches, const uint32_t *__restrict__ lens, uint32_t nseq,
     uint32_t k, uint32_t s, uint32_t stride, uint32_t row_start, uint32_t row_stride, int symmetric,
-    double *__restrict__ dist, uint32_t *__restrict__ zerodiv) {
-    // The block's 256 pairs share row i: its sketch is staged once in LDS (when it fits), and a
-    // thread's walk over row j takes four hashes per 16-byte load instead of one per 4-byte load.
-    extern __shared__ uint32_t s_left[];
-    const uint32_t i = row_start + blockIdx.y * row_stride;
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nseq) return;
-    const uint32_t nl = lens[i];
+    uint32_t row_lds, double *__restrict__ dist, uint32_t *__restrict__ zerodiv) {
+    __shared__ uint32_t s_win[PAIR_SLOTS * 4][PAIR_THREADS];
+    extern __shared__ uint32_t s_left[];  // row_lds + 4 words
+    // grid = (rows, blocks of 256 columns), rows fastest: workgroups go to the XCDs round-robin by their linear
+    // index, so with the columns fastest XCD x would get column block x % 4 only -- and column block 0 has
+    // work in every row, block 3 in a quarter of them (measured: 3 rounds on two XCDs, half a round on two
+    // others).  Longest rows first.
+    const uint32_t i = row_start + (gridDim.x - 1 - blockIdx.x) * row_stride;
+    const uint32_t j = blockIdx.y * PAIR_THREADS + threadIdx.x;
+    if (i >= nseq || blockIdx.y * PAIR_THREADS >= i) return;
+    const bool mine = j < i;
     const uint32_t *Lg = sketches + uint64_t(i) * stride;
-    const bool staged = nl <= MASH_PAIR_LDS;
+    const uint32_t *R = sketches + uint64_t(mine ? j : 0u) * stride;
+    const uint32_t nl = lens[i], nr = mine ? lens[j] : 0u;
+    const bool staged = nl <= row_lds;
     if (staged) {
-        for (uint32_t x = threadIdx.x; x < nl; x += blockDim.x) s_left[x] = Lg[x];
+        for (uint32_t x = threadIdx.x; x < nl; x += PAIR_THREADS) s_left[x] = Lg[x];
         __syncthreads();
     }
-    if (j >= i) return;
-    const uint32_t *L = staged ? s_left : Lg;
-    const uint32_t *R = sketches + uint64_t(j) * stride;
-    const uint32_t nr = lens[j];
     const bool vec = (stride & 3u) == 0;  // rows 16-byte aligned
+    uint32_t *win = &s_win[0][threadIdx.x];
     uint32_t inter = 0, uni = 0, li = 0, ri = 0;
-    uint4 rb = make_uint4(0, 0, 0, 0);
-    uint32_t rb_at = 0xFFFFFFFFu;  // block of four of R held in rb
-    while (uni < s && li < nl && ri < nr) {  // distance.py:260-274
-        uint32_t r;
-        if (vec) {
-            if ((ri >> 2) != rb_at) {
-                rb_at = ri >> 2;
-                rb = *reinterpret_cast<const uint4 *>(R + (ri & ~3u));
-            }
-            const uint32_t q = ri & 3u;
-            r = q == 0 ? rb.x : q == 1 ? rb.y : q == 2 ? rb.z : rb.w;
+    bool run = mine && s > 0 && nl > 0 && nr > 0;
+    auto fetch = [&](uint32_t blk) {
+        const uint32_t at = blk * 4u;
+        uint4 v;
+        if (vec && at < stride) {
+            v = *reinterpret_cast<const uint4 *>(R + at);
         } else {
-            r = R[ri];
+            v.x = at + 0u < stride ? R[at + 0u] : 0u;
+            v.y = at + 1u < stride ? R[at + 1u] : 0u;
+            v.z = at + 2u < stride ? R[at + 2u] : 0u;
+            v.w = at + 3u < stride ? R[at + 3u] : 0u;
         }
-        const uint32_t l = L[li];
-        li += (l <= r);
-        ri += (r <= l);
-        inter += (l == r);
-        uni++;
+        return v;
+    };
+    auto land = [&](uint32_t blk, const uint4 &v) {
+        uint32_t *slot = win + (blk & (PAIR_SLOTS - 1)) * 4u * PAIR_THREADS;
+        slot[0 * PAIR_THREADS] = v.x;
+        slot[1 * PAIR_THREADS] = v.y;
+        slot[2 * PAIR_THREADS] = v.z;
+        slot[3 * PAIR_THREADS] = v.w;
+    };
+    // PAIR_W steps.  Row i in LDS: no branch, a lane that has finished keeps reading where it stands and adds
+    // zeros (s_left has slack behind the row); row i through L1 (longer than the staging area): reads only while running.
+    auto steps_lds = [&]() {
+        uint32_t on = run;
+#pragma unroll
+        for (int t = 0; t < PAIR_W; t++) {
+            const uint32_t l = s_left[li];
+            const uint32_t r = win[(ri & (PAIR_SLOTS * 4 - 1)) * PAIR_THREADS];
+            const uint32_t a = on & uint32_t(l <= r), b = on & uint32_t(r <= l);
+            li += a;
+            ri += b;
+            inter += a & b;
+            uni += on;
+            on &= uint32_t(uni < s) & uint32_t(li < nl) & uint32_t(ri < nr);
+        }
+        run = on != 0;
+    };
+    auto steps_l1 = [&]() {
+#pragma unroll
+        for (int t = 0; t < PAIR_W; t++) {
+            if (run) {
+                const uint32_t l = Lg[li];
+                const uint32_t r = win[(ri & (PAIR_SLOTS * 4 - 1)) * PAIR_THREADS];
+                li += (l <= r);
+                ri += (r <= l);
+                inter += (l == r);
+                uni++;
+                run = uni < s && li < nl && ri < nr;
+            }
+        }
+    };
+    // blocks [0, have) of row j have been through the window, [have, pf_hi) are on their way in pf[]
+    uint32_t have = PAIR_AHEAD, pf_hi = PAIR_AHEAD;
+    uint4 pf[PAIR_ADV];
+    if (run) {
+#pragma unroll
+        for (int q = 0; q < PAIR_AHEAD; q++) land(q, fetch(q));
     }
+    auto trip_head = [&]() {  // the blocks requested a trip ago into the window, the next ones requested
+#pragma unroll
+        for (int q = 0; q < PAIR_ADV; q++)
+            if (have + q < pf_hi) land(have + q, pf[q]);
+        have = pf_hi;
+        pf_hi = run ? max(have, (ri >> 2) + PAIR_AHEAD + PAIR_ADV) : have;
+#pragma unroll
+        for (int q = 0; q < PAIR_ADV; q++)
+            if (have + q < pf_hi) pf[q] = fetch(have + q);
+    };
+    if (staged && __all(!run || (nl >= s && nr >= s))) {
+        // Full sketches (the usual case): a pair takes exactly s steps -- li <= uni <= s <= nl, and the same for
+        // ri, so neither sketch can run out first -- and a step needs no "still running" mask: two reads, three
+        // compares, three adds-with-carry and the two addresses.  (Lanes without a pair idle through it.)
+        for (uint32_t done = 0; done < s; done += PAIR_W) {
+            trip_head();
+            if (run) {
+                if (s - done >= uint32_t(PAIR_W)) {
+#pragma unroll
+                    for (int t = 0; t < PAIR_W; t++) {
+                        const uint32_t l = s_left[li];
+                        const uint32_t r = win[(ri & (PAIR_SLOTS * 4 - 1)) * PAIR_THREADS];
+                        li += (l <= r);
+                        ri += (r <= l);
+                        inter += (l == r);
+                    }
+                } else {
+                    for (uint32_t t = done; t < s; t++) {
+                        const uint32_t l = s_left[li];
+                        const uint32_t r = win[(ri & (PAIR_SLOTS * 4 - 1)) * PAIR_THREADS];
+                        li += (l <= r);
+                        ri += (r <= l);
+                        inter += (l == r);
+                    }
+                }
+            }
+        }
+        uni = run ? s : 0u;  // (= li + ri - inter)
+    } else {
+        while (__any(run)) {  // distance.py:260-274, PAIR_W steps per trip
+            trip_head();
+            if (staged) steps_lds();
+            else steps_l1();
+        }
+    }
+    if (!mine) return;
     if (uni < s) {  // :276-281
         if (li < nl) uni += nl - li;
         if (ri < nr) uni += nr - ri;
@@ -759,9 +870,10 @@ static int mash_pairs_device(dvs_ctx *ctx, const uint32_t *d_sk, const uint32_t 
     const uint32_t nrows = (nseq - 1 - row_start) / row_stride + 1;
     uint32_t flag = 0;
     if (e == hipSuccess) {
-        const dim3 grid((nseq + 255) / 256, nrows);
-        hipLaunchKernelGGL(mash_pairs_kernel, grid, dim3(256), MASH_PAIR_LDS * 4, ctx->stream, d_sk, d_lens, nseq, k,
-                           sketch_size, stride, row_start, row_stride, symmetric, d_dist, d_flag);
+        const dim3 grid(nrows, (nseq + PAIR_THREADS - 1) / PAIR_THREADS);
+        const uint32_t row_lds = std::min(stride, PAIR_ROW_LDS);  // (no sketch is longer than the stride)
+        hipLaunchKernelGGL(mash_pairs_kernel, grid, dim3(PAIR_THREADS), (row_lds + 4) * 4, ctx->stream, d_sk, d_lens, nseq, k,
+                           sketch_size, stride, row_start, row_stride, symmetric, row_lds, d_dist, d_flag);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(dist, d_dist, size_t(nseq) * nseq * 8, hipMemcpyDeviceToHost, ctx->stream);

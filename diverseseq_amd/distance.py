@@ -115,8 +115,9 @@ class Sketches:
         self.ctx.check(self.ctx._L.dvs_sketches_get(self.ctx._h, self._h, _lib.ptr(sk, C.c_uint32), _lib.ptr(lens, C.c_uint32)))
         return sk, lens
 
-    def distances(self, *, row_start: int = 0, row_stride: int = 1, symmetric: bool = True) -> np.ndarray:
-        dist = np.zeros((self.n, self.n), dtype=np.float64)
+    def distances(self, *, row_start: int = 0, row_stride: int = 1, symmetric: bool = True,
+                  out: np.ndarray | None = None) -> np.ndarray:
+        dist = np.zeros((self.n, self.n), dtype=np.float64) if out is None else out
         self.ctx.check(self.ctx._L.dvs_sketches_distances(self.ctx._h, self._h, self.k, min(self.sketch_size, _U32_MAX),
                                                           row_start, row_stride, int(symmetric), _lib.ptr(dist, C.c_double)))
         return dist

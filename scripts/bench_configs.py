@@ -105,9 +105,17 @@ def mash_case(name, nseq, lo, hi, k, s, canonical, reps=2, composition=False):
 
     dt_s, _ = timed(sketch, reps)
     dt_p, d = timed(lambda: distance.distances_from_sketches(sk, lens, k, s, ctx=ctx), reps)
+    # the ctree path: the sketches stay in HBM between the two stages (distance.mash_distances)
+    res = distance.Sketches(None, k, s, 4, canonical, ctx=ctx, dev_ptr=seqs.data_ptr(), offsets=offsets)
+    dt_r, d_r = timed(lambda: res.distances(), max(reps, 3))
+    out = np.zeros((nseq, nseq))
+    dt_o, _ = timed(lambda: res.distances(out=out), max(reps, 3))
+    res.close()
+    assert np.array_equal(d, d_r) and np.array_equal(d, out)
     rec = dict(config=name, nseq=nseq, length=[lo, hi], k=k, sketch_size=s, canonical=canonical,
                sketch_ms=round(dt_s * 1e3, 2), gbases_per_s=round(float(offsets[-1]) / dt_s / 1e9, 2),
-               pairs=nseq * (nseq - 1) // 2, pairs_ms=round(dt_p * 1e3, 2),
+               pairs=nseq * (nseq - 1) // 2, pairs_ms=round(dt_r * 1e3, 2),
+               pairs_ms_from_host_sketches=round(dt_p * 1e3, 2), pairs_ms_into_a_kept_matrix=round(dt_o * 1e3, 2),
                mean_distance=float(d[np.tril_indices(nseq, -1)].mean()))
     print(json.dumps(rec), flush=True)
     del seqs

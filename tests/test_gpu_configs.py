@@ -401,6 +401,62 @@ def test_config_c5_100_genomes_sketches_and_matrix_vs_oracle(ctx):
         assert (d == d.T).all() and (np.diag(d) == 0).all()
 
 
+def _random_sketches(rng, n, s, pool):
+    """n sorted rows of s distinct hashes out of a pool of `pool` values (pairs share about s^2 / pool)"""
+    space = np.sort(rng.choice(2**32 - 1, size=pool, replace=False).astype(np.uint32))
+    sk = np.zeros((n, s), dtype=np.uint32)
+    for i in range(n):
+        sk[i] = np.sort(rng.choice(space, size=s, replace=False))
+    return sk
+
+
+def test_config_c5_pairs_at_1000_sketches_vs_oracle(ctx):
+    """C5's distance stage at its stated size -- 1000 sketches of 3000 hashes, k=12, 499 500 pairs -- against the
+    oracle's mash_distance (distance.py:230-291) on 5000 sampled pairs and on every pair of the rows that are
+    not full (shorter sketches, an empty one: the waves holding them take the kernel's general path, all others
+    the exactly-s-steps path), then the strided row subsets of cluster.py:640-644."""
+    from diverseseq_amd import distance
+
+    rng = np.random.default_rng(20260434)
+    N, S, K = 1000, 3000, 12
+    sk = _random_sketches(rng, N, S, 24_000)
+    lens = np.full(N, S, dtype=np.uint32)
+    short = {5: 2990, 63: 100, 64: 0, 300: 1, 777: 2999, 999: 1500}
+    for i, n in short.items():
+        lens[i] = n
+        sk[i, n:] = 0
+    d = distance.distances_from_sketches(sk, lens, K, S, ctx=ctx)
+    assert (d == d.T).all() and (np.diag(d) == 0).all()
+    pairs = {(int(i), int(j)) for i, j in zip(rng.integers(1, N, 5000), rng.integers(0, N, 5000)) if j < i}
+    pairs |= {(max(i, j), min(i, j)) for i in short for j in range(N) if i != j}
+    inter = 0
+    for i, j in pairs:
+        e = oracle.mash_distance(sk[i, :lens[i]], sk[j, :lens[j]], K, S)
+        assert d[i, j] == e or abs(d[i, j] - e) <= RTOL * abs(e), (i, j, d[i, j], e)
+        inter += 0.0 < e < 1.0
+    assert inter > 4000  # (the sample is not all zeros and ones)
+    acc = np.zeros((N, N))
+    for start in range(3):
+        distance.distances_from_sketches(sk, lens, K, S, row_start=start, row_stride=3, symmetric=False, out=acc, ctx=ctx)
+    np.testing.assert_array_equal(acc + acc.T, d)
+
+
+def test_pairs_of_sketches_longer_than_the_staged_row(ctx):
+    """sketches of more than 8192 hashes: the shared row is read through L1 instead of LDS"""
+    from diverseseq_amd import distance
+
+    rng = np.random.default_rng(20260435)
+    N, S = 70, 9000
+    sk = _random_sketches(rng, N, S, 40_000)
+    lens = np.full(N, S, dtype=np.uint32)
+    lens[3], lens[69] = 8000, 8193
+    d = distance.distances_from_sketches(sk, lens, 16, S, ctx=ctx)
+    for i in range(1, N):
+        for j in range(i):
+            e = oracle.mash_distance(sk[i, :lens[i]], sk[j, :lens[j]], 16, S)
+            assert d[i, j] == e or abs(d[i, j] - e) <= RTOL * abs(e), (i, j, d[i, j], e)
+
+
 # ---------------------------------------------------------------- head phase (CU split)
 def _device_build(ctx, seqs, k):
     import torch
