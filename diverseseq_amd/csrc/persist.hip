@@ -76,6 +76,11 @@ constexpr uint32_t P_SPIN_LIMIT = 1u << 22;  // ~0.5 s of polling
 #endif
 constexpr uint32_t P_FLAT_GRID = DVS_P_FLAT_GRID;  // grids of up to this many workgroups rendezvous on one counter
 constexpr uint32_t P_SOFT = 64;              // uncertain candidates listed per window (more become plain events)
+// MODE_MAX, growth phase: consecutive rows evaluated against the same set in one go (see the kernel)
+constexpr uint32_t P_BATCH = 32;             // rows per batch at most
+constexpr uint32_t P_BATCH_MEMBERS = 256;    // set size + 2 up to which batches are formed (4 members per lane)
+constexpr size_t p_batch_bytes() { return size_t(P_BATCH) * (P_BATCH_MEMBERS + 2) * 4 * sizeof(double); }
+constexpr size_t p_batch_lds() { return size_t(P_BATCH) * (2 + 12 + 24) * sizeof(double); }
 
 struct PLine {  // a polled word on a cache line of its own (256 B apart)
     uint32_t v;
@@ -766,6 +771,11 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     static_assert(maxn % 4 == 0 && P_SOFT % 2 == 0, "s_ltab below must sit on a 16-byte boundary");
     double2 *s_ltab = reinterpret_cast<double2 *>(s_soft + P_SOFT + 2);  // log2_tab's 128 entries
     [[maybe_unused]] uint16_t *s_rows = reinterpret_cast<uint16_t *>(s_ltab + 128);  // SMALL: member count rows by slot
+    // MAXM: a batch's row totals, row entropies and decisions (12 doubles per row)
+    [[maybe_unused]] double *s_bt = reinterpret_cast<double *>(s_ltab + 128);
+    [[maybe_unused]] double *s_bH = s_bt + P_BATCH;
+    [[maybe_unused]] double *s_bev = s_bH + P_BATCH;
+    [[maybe_unused]] double *s_bpart = s_bev + 12 * P_BATCH;  // a batch job's sums by wave: [row][3][8 waves]
     if (threadIdx.x < 128) log2_tab_fill(s_ltab, threadIdx.x);
     SelCtl *ctl = d.ctl;
     const int tid0 = threadIdx.x;
@@ -839,6 +849,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     uint64_t arb_pos = 0;
     uint32_t pend_kind = 0;  // ev_kind left pending for the multi-launch kernels (finalize tie)
     bool bail = false;       // leave with the state as it stands and status RUN (MAXM: an undecidable push)
+    [[maybe_unused]] uint32_t mx_batch = 1;  // MAXM: rows the next tentative push takes along (identical in every workgroup)
     const uint64_t wpb = P_THREADS / 64;
     const uint32_t nwg = G > 1 ? G - 1 : 1;           // scanning workgroups
     const uint64_t nwaves = uint64_t(nwg) * wpb;      // scanning waves
@@ -1082,7 +1093,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     // (accumulated in LDS by thread 0 of block 0 and of the mirror block, written out when the launch
     // ends: a stamp costs a clock read and an LDS add, not a memory round trip)
     unsigned long long *s_dbg = SMALL ? reinterpret_cast<unsigned long long *>(s_rows + uint64_t(sync->small_rows) * 4096)
-                                      : reinterpret_cast<unsigned long long *>(s_ltab + 128);
+                                      : reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(s_ltab + 128) +
+                                                                               (MAXM ? p_batch_lds() : 0));
     if (tid < 16) s_dbg[tid] = 0ull;
     __syncthreads();
     unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
@@ -1473,9 +1485,332 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     st.n_windows--;
                     break;
                 }
+                const double rn1 = 1.0 / double(n1), rdiv1 = 1.0 / double(n);
+                // what the decision needs, whichever way it was reached
+                double sumH_t = st.sumH + cand_H, tj = 0.0, band1 = 0.0, mean1 = 0.0, sd1 = 0.0, cov1 = 0.0;
+                uint32_t low1 = 0;
+                bool unclear = false, grow = false;
+                uint32_t why_i = 0;
+                auto decide = [&](double hm, double svm, double dmin1, double dsec1, double mean_, double sd_, bool anyr) {
+                    tj = hm - sumH_t * rn1;
+                    mean1 = mean_;
+                    sd1 = sd_;
+                    const bool evr = sum_risky(svm, B) || !(hm == hm);
+                    band1 = sel_band(tj + sumH_t * rn1, B);
+                    cov1 = sd1 / mean1;
+                    const double a = st.stat == DVS_STAT_STDEV ? sd1 : cov1;
+                    const double b = st.stat == DVS_STAT_STDEV ? st.std_d : st.cov_d;
+                    // every delta_jsd carries an error <= band, so std moves by <= ~band and cov = std / mean
+                    // by ~ band (1 + |cov|) / |mean| (finalize_kernel); NaN compares false
+                    const double mm = fmin(fabs(mean1), fabs(st.mean_d));
+                    const double sband = st.stat == DVS_STAT_STDEV
+                                             ? 4.0 * band1
+                                             : 4.0 * band1 * (1.0 + fmax(fabs(a), fabs(b))) / fmax(mm, 1e-300);
+                    const bool tie = dsec1 - dmin1 <= band1 && dsec1 < 1e6;
+                    unclear = anyr || evr || tie || !(fabs(a - b) > sband);
+                    why_i = (anyr || evr) ? 1 : tie ? 2 : 3;
+                    grow = a > b;
+                };
+                // ---- BATCH: the rows behind the event, while the set does not change.  A tentative push
+                // that is rolled back leaves the set as it was (records.rs:439-450: `summed` stays), and so
+                // does a row that is no event -- so the rows p, p + 1, ... up to the first push that is KEPT
+                // all face the same set, and their scores and leave-one-out passes are independent jobs.
+                // When events come back to back (genome collections under `max`: nearly every row is one,
+                // one in fifty is kept) the next E rows are worked out in one go: E (n + 3) jobs over the
+                // grid, ONE rendezvous, eight decisions at a time by the eight waves of every workgroup,
+                // then the rows are walked in stream order up to the first kept push or the first row too
+                // close to call (which stays unconsumed: the next window meets it as its first event).
+                const bool dense = p == st.cursor;  // the window's very first row was the event
+                uint32_t E = mx_batch;
+                if (uint64_t(E) > st.npos - p) E = uint32_t(st.npos - p);
+                if (n1 + 1 > P_BATCH_MEMBERS || !CACHED) E = 1;
+                bool known0 = true;  // row p is known to be an event (it came out of the resolve phase)
+                bool left = false;   // the batches are over: on with the main loop
+                if (E >= 2) {
+                for (;;) {  // batch after batch while the rows keep being events
+                    constexpr uint32_t JW = P_BATCH_MEMBERS + 2;  // result rows per batch entry
+                    double *bres = reinterpret_cast<double *>(part + p_acc_bytes(maxn) / 8);
+                    const uint32_t jpe = n + 3;  // leave-one-out of n + 1 members, the whole bigger set, the score
+                    __syncthreads();  // every thread has read the member arrays of the resolve phase
+                    if (tid < E) {
+                        const double t = double(d.totals[p + tid]);
+                        s_bt[tid] = t;
+                        s_bH[tid] = d.rowH[p + tid];
+                    }
+                    __syncthreads();
+                    // Jobs by member: a workgroup takes ONE member r (or the whole set, or the score) and every
+                    // ng-th row of the batch -- the member's counts are read once, the next row's are requested
+                    // while this row's are worked on.
+                    P_STAMP(8);  // (everything since the accept was decided, or since the previous batch's walk)
+                    const uint32_t ng = G >= jpe ? G / jpe : 1u;
+                    const uint32_t r_step = G >= jpe ? jpe : G;
+                    const uint32_t e_first = G >= jpe ? blockIdx.x / jpe : 0u;
+                    for (uint32_t r = G >= jpe ? blockIdx.x % jpe : blockIdx.x; r < jpe && e_first < ng; r += r_step) {
+                        T cv[P_J];
+                        double fmv[P_J];  // the member's frequencies
+                        if (r < n) {
+                            const T *mrow = mat + s_pos[r] * B;
+                            const double mtot = s_tot[r], mrt = s_rt[r];
+#pragma unroll
+                            for (int j = 0; j < P_J; j++) {
+                                const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                                fmv[j] = i < B ? count_freq_x(mrow[i], mtot, mrt) : 0.0;
+                            }
+                        }
+                        auto request = [&](uint32_t e) {
+                            const T *crow = mat + (p + e) * B;
+#pragma unroll
+                            for (int j = 0; j < P_J; j++) {
+                                const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                                if (i < B) cv[j] = crow[i];
+                            }
+                        };
+                        if (e_first < E) request(e_first);
+                        for (uint32_t e = e_first; e < E; e += ng) {
+                            const double tot_e = s_bt[e], rt_e = 1.0 / tot_e;
+                            double fv[P_J];
+#pragma unroll
+                            for (int j = 0; j < P_J; j++) fv[j] = count_freq_x(cv[j], tot_e, rt_e);
+                            if (e + ng < E) request(e + ng);
+                            if (tot_e == 0.0 || (known0 && e == 0 && r == n + 2)) continue;  // (no k-mers: never an event; nobody reads the result)
+                            double h = 0.0, sv = 0.0, mn = 0.0;
+                            if (r == n + 2) {  // increases_jsd of row p + e (records.rs:70-92), as `evaluate` above
+                                Ent en;
+#pragma unroll
+                                for (int j = 0; j < P_J; j++) {
+                                    const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                                    if (i < B) en.add((sl[i] + fv[j]) * rn, s_ltab);
+                                }
+                                h = en.h;
+                                sv = en.sum;
+                                mn = en.mn;
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < P_J; j++) {
+                                    const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                                    if (i < B) {
+                                        const double f = fv[j];
+                                        const double stv = Sl[i] + f;  // S of the bigger set
+                                        double u;
+                                        if (r == n1) {
+                                            u = stv * rn1;
+                                        } else {
+                                            const double fm = r == n ? f : fmv[j];
+                                            u = (stv - fm) * rdiv1;  // updated_mean_freqs, records.rs:276-286
+                                            if (u <= DVS_EPS) u = 0.0;
+                                        }
+                                        if (u > 0.0) h -= u * log2_tab(u, s_ltab);
+                                        sv += u;
+                                    }
+                                }
+                            }
+                            h = dvs_wave_sum_dpp(h);
+                            sv = dvs_wave_sum_dpp(sv);
+                            mn = dvs_wave_min(mn);
+                            // (no barrier per job: every wave leaves its share in a slot of its own and goes on)
+                            if (lane == 0) {
+                                s_bpart[(e * 3 + 0) * 8 + wave] = h;
+                                s_bpart[(e * 3 + 1) * 8 + wave] = sv;
+                                s_bpart[(e * 3 + 2) * 8 + wave] = mn;
+                            }
+                        }
+                        // this member's results for the workgroup's rows, by wave 0 (whose thread 0 then arrives at the
+                        // rendezvous: a wave's memory operations are acknowledged in order); waves summed in a fixed order
+                        __syncthreads();
+                        if (wave == 0) {
+                            for (uint32_t x = lane; x < 3 * E; x += 64) {
+                                const uint32_t e = x / 3, k = x % 3;
+                                if (e >= e_first && (e - e_first) % ng == 0) {
+                                    const double *pw = s_bpart + x * 8;
+                                    double t = pw[0];
+                                    for (uint32_t w = 1; w < P_THREADS / 64; w++) t = k == 2 ? fmin(t, pw[w]) : t + pw[w];
+                                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(bres) + (uint64_t(e) * 3 + k) * JW + r,
+                                                       (unsigned long long)__double_as_longlong(t), RLX_AGENT);
+                                }
+                            }
+                        }
+                        __syncthreads();  // (s_bpart is rewritten by the next member's jobs)
+                    }
+                    P_STAMP(3);  // the batch's jobs
+                    if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
+                    P_STAMP(4);  // its rendezvous
+                    // ---- the decisions: wave w takes rows w, w + 8, ... of the batch; lane l the members l, l + 64, ...
+                    auto rd = [&](uint32_t e, uint32_t r, uint32_t k) {  // result k of member r for row e
+                        return __longlong_as_double((long long)__hip_atomic_load(
+                            reinterpret_cast<unsigned long long *>(bres) + (uint64_t(e) * 3 + k) * JW + r, RLX_AGENT));
+                    };
+                    constexpr uint32_t QB = (P_BATCH_MEMBERS + 63) / 64;
+                    for (uint32_t e = wave; e < E; e += P_THREADS / 64) {
+                        double *out = s_bev + e * 12;
+                        const double tot_e = s_bt[e], H_e = s_bH[e];
+                        // every word this row's decision may need is requested before the first one is looked at
+                        const double hs = rd(e, n + 2, 0), ss = rd(e, n + 2, 1), ms = rd(e, n + 2, 2);
+                        const double hm = rd(e, n1, 0), svm = rd(e, n1, 1);
+                        double hr[QB], sr[QB];
+#pragma unroll
+                        for (uint32_t q = 0; q < QB; q++) {
+                            const uint32_t r = lane + 64 * q;
+                            hr[q] = r < n1 ? rd(e, r, 0) : 0.0;
+                            sr[q] = r < n1 ? rd(e, r, 1) : 1.0;
+                        }
+                        double kind = 0.0;  // 0 no event, 1 event, 2 too close to call (score)
+                        if (tot_e != 0.0) {
+                            kind = 1.0;
+                            if (e > 0 || !known0) {
+                                const double js = (ms < 0.0) ? NAN : hs - (st.sumH - s_mH[st.li] + H_e) / dn;
+                                if (sum_risky(ss, B) || fabs(js - st.thr) <= st.band) kind = 2.0;
+                                else if (!(js > st.thr)) kind = 0.0;
+                                if (lane == 0) out[9] = js;
+                            }
+                        }
+                        if (kind == 1.0) {
+                            const double sumH_e = st.sumH + H_e;
+                            const double tj_e = hm - sumH_e * rn1;
+                            double v[QB], best = 1e6, acc = 0.0;
+                            bool rk = false;
+#pragma unroll
+                            for (uint32_t q = 0; q < QB; q++) {
+                                const uint32_t r = lane + 64 * q;
+                                v[q] = 1e6;
+                                if (r < n1) {
+                                    const double mh = r < n ? s_mH[r] : H_e;
+                                    v[q] = tj_e - (hr[q] - (sumH_e - mh) * rdiv1);  // delta_jsd of member r
+                                    rk |= sum_risky(sr[q], B);
+                                    acc += v[q];
+                                    if (v[q] < best) best = v[q];
+                                }
+                            }
+                            const double mnv = dvs_wave_min(best);
+                            double fi = 4294967295.0;
+#pragma unroll
+                            for (uint32_t q = 0; q < QB; q++)
+                                if (mnv < 1e6 && lane + 64 * q < n1 && v[q] == mnv) fi = fmin(fi, double(lane + 64 * q));
+                            const double first = dvs_wave_min(fi);
+                            const uint32_t lw = (first < 4294967295.0) ? uint32_t(first) : 0u;
+                            const double mu = dvs_wave_sum(acc) / double(n1);
+                            double sec = 1e6, tv = 0.0;
+#pragma unroll
+                            for (uint32_t q = 0; q < QB; q++) {
+                                const uint32_t r = lane + 64 * q;
+                                if (r < n1) {
+                                    if (r != lw && v[q] < sec) sec = v[q];
+                                    const double t = v[q] - mu;
+                                    tv += t * t;
+                                }
+                            }
+                            sec = dvs_wave_min(sec);
+                            const double var = dvs_wave_sum(tv);
+                            const unsigned long long anyr = __ballot(rk);
+                            const double sd_e = sqrt(var / (double(n1) - 1.0));
+                            sumH_t = sumH_e;
+                            decide(hm, svm, mnv, sec, mu, sd_e, anyr != 0ull);  // (here, by eight waves at a time, not in the walk)
+                            if (lane == 0) {
+                                out[1] = hm;
+                                out[2] = svm;
+                                out[3] = mnv;
+                                out[4] = sec;
+                                out[5] = mu;
+                                out[6] = sd_e;
+                                out[7] = anyr ? 1.0 : 0.0;
+                                out[8] = double(lw);
+                                out[10] = unclear ? 1.0 : 0.0;
+                                out[11] = grow ? 1.0 : 0.0;
+                            }
+                        }
+                        if (lane == 0) out[0] = kind;
+                    }
+                    __syncthreads();
+                    P_STAMP(6);  // the decisions
+                    // ---- the walk, in stream order (every workgroup alike)
+                    uint32_t e_commit = E, e_stop = E, n_ev = 0;
+                    for (uint32_t e = 0; e < E; e++) {
+                        const double *ev = s_bev + e * 12;
+                        const bool counted = known0 && e == 0;  // (the resolve phase has counted row p)
+                        if (ev[0] == 0.0) {
+                            if (!counted && s_bt[e] != 0.0) st.n_events++;  // (an exact score below the threshold: rejected)
+                            continue;
+                        }
+                        if (ev[0] == 2.0) { e_stop = e; break; }
+                        if (ev[10] != 0.0) { e_stop = e; break; }
+                        if (!counted) st.n_events++;
+                        n_ev++;
+                        if (ev[11] != 0.0) { e_commit = e; break; }
+                    }
+                    if (e_stop == 0 && known0) {  // the event itself is too close to call: it stays unconsumed
+                        if (s_bev[0] == 1.0) {
+                            sumH_t = st.sumH + s_bH[0];
+                            decide(s_bev[1], s_bev[2], s_bev[3], s_bev[4], s_bev[5], s_bev[6], s_bev[7] != 0.0);  // (which check it was)
+                        }
+                        if (lead && tid == 0) ctl->why[why_i]++;
+                        bail = true;
+                        st.n_windows--;
+                        st.n_events--;
+                        __syncthreads();
+                        break;
+                    }
+                    if (e_commit == E) {  // nothing kept: the stream moves on behind the rows walked
+                        st.cursor = p + e_stop;
+                        const bool dense_b = e_stop == E && n_ev * 2 >= E;
+                        if (dense_b) mx_batch = E * 2 <= P_BATCH ? E * 2 : P_BATCH;
+                        else if (n_ev * 2 < e_stop) mx_batch = E / 2;
+                        if (lead && tid == 0) {
+                            ctl->cursor = st.cursor;
+                            ctl->event_pos = SEL_NONE;
+                        }
+                        __syncthreads();  // (s_bev, scratch)
+                        if (st.cursor >= st.npos) { exit_status = SEL_DONE; left = true; break; }
+                        if (dense_b) {  // the next batch right away: its first row is scored like the others
+                            p = st.cursor;
+                            known0 = false;
+                            E = mx_batch;
+                            if (uint64_t(E) > st.npos - p) E = uint32_t(st.npos - p);
+                            if (E >= 2) continue;
+                        }
+                        st.window = p_next_window(st, nwg, wg_thresh, wg_scale, wgmode);
+                        epoch++;
+                        left = true;
+                        break;
+                    }
+                    // ---- row p + e_commit is kept: it becomes the candidate of the commit below
+                    {
+                        const uint32_t e = e_commit;
+                        const double *ev = s_bev + e * 12;
+                        sumH_t = st.sumH + s_bH[e];
+                        decide(ev[1], ev[2], ev[3], ev[4], ev[5], ev[6], ev[7] != 0.0);  // (tj, band, mean, sd of the kept set)
+                        low1 = uint32_t(ev[8]);
+                        if (e > 0) jsd = ev[9];
+                        p += e;
+                        tot = s_bt[e];
+                        rtot = 1.0 / tot;
+                        cand_H = s_bH[e];
+                        rp = mat + p * B;
+#pragma unroll
+                        for (int j = 0; j < P_J; j++) {
+                            const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                            if (i < B) fr[j] = cand_freq_x(rp, i, tot, rtot);
+                        }
+                        __syncthreads();  // (s_bev has been read by everybody)
+                        for (uint32_t r = tid; r < n1; r += P_THREADS) {
+                            const double mh = r < n ? s_mH[r] : cand_H;
+                            s_dl[r] = tj - (rd(e, r, 0) - (sumH_t - mh) * rdiv1);
+                            s_ds[r] = rd(e, r, 1);
+                        }
+                        if (tid == 0) {
+                            s_slot[n] = n;
+                            s_mH[n] = cand_H;
+                            s_pos[n] = p;
+                            s_tot[n] = tot;
+                            s_rt[n] = rtot;
+                        }
+                        __syncthreads();
+                    }
+                    break;  // (on to the commit)
+                }
+                if (exit_status == SEL_ERROR || bail || (left && exit_status == SEL_DONE)) break;
+                if (left) continue;
+                } else {
                 const uint32_t slot_t = st.n_loo % 3;
                 st.n_loo++;
-                const double sumH_t = st.sumH + cand_H;
                 uint32_t K1 = 1;
                 {
                     const uint32_t kmax = (n1 + 1 < G) ? (G - 1) / (n1 + 1) : 1u;
@@ -1500,7 +1835,6 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 }
                 unsigned long long *accw = part + uint64_t(slot_t) * 8 * (maxn + 1) * 2;
                 const unsigned long long *accr = accw + uint64_t(blockIdx.x & 7u) * (maxn + 1) * 2;
-                const double rn1 = 1.0 / double(n1), rdiv1 = 1.0 / double(n);
                 bool first1 = true;
                 for (uint32_t job = blockIdx.x; job < jobs1; job += G) {
                     if (lead && one1) break;
@@ -1559,36 +1893,28 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     }
                 }
                 __syncthreads();
-                const double hm = scratch[110];
-                const double tj = hm - sumH_t * rn1;
-                const bool evr = sum_risky(scratch[111], B) || !(hm == hm);
-                for (uint32_t r = tid; r < n1; r += P_THREADS) s_dl[r] = tj - s_dl[r];  // delta_jsd
+                {
+                    const double hm0 = scratch[110];
+                    const double tj0 = hm0 - sumH_t * rn1;
+                    for (uint32_t r = tid; r < n1; r += P_THREADS) s_dl[r] = tj0 - s_dl[r];  // delta_jsd
+                }
                 __syncthreads();
                 if (wave == 0) p_argmin<(maxn + 63) / 64>(s_dl, s_ds, n1, B, lane, scratch);
                 __syncthreads();
-                const double dmin1 = scratch[100], dsec1 = scratch[102], mean1 = scratch[103], sd1 = scratch[104];
-                const uint32_t low1 = uint32_t(scratch[101]);
-                const bool anyr = scratch[105] != 0.0;
-                const double band1 = sel_band(tj + sumH_t * rn1, B);
-                const double cov1 = sd1 / mean1;
-                const double a = st.stat == DVS_STAT_STDEV ? sd1 : cov1;
-                const double b = st.stat == DVS_STAT_STDEV ? st.std_d : st.cov_d;
-                // every delta_jsd carries an error <= band, so std moves by <= ~band and cov = std / mean
-                // by ~ band (1 + |cov|) / |mean| (finalize_kernel); NaN compares false
-                const double mm = fmin(fabs(mean1), fabs(st.mean_d));
-                const double sband = st.stat == DVS_STAT_STDEV
-                                         ? 4.0 * band1
-                                         : 4.0 * band1 * (1.0 + fmax(fabs(a), fabs(b))) / fmax(mm, 1e-300);
-                if (anyr || evr || (dsec1 - dmin1 <= band1 && dsec1 < 1e6) || !(fabs(a - b) > sband)) {
-                    if (lead && tid == 0) ctl->why[(anyr || evr) ? 1 : (dsec1 - dmin1 <= band1 && dsec1 < 1e6) ? 2 : 3]++;
+                low1 = uint32_t(scratch[101]);
+                decide(scratch[110], scratch[111], scratch[100], scratch[102], scratch[103], scratch[104], scratch[105] != 0.0);
+                if (unclear) {
+                    if (lead && tid == 0) ctl->why[why_i]++;
                     bail = true;  // too close to call (or NaN): the event stays unconsumed
                     st.n_windows--;
                     st.n_events--;
                     __syncthreads();
                     break;
                 }
+                mx_batch = dense ? 2u : 1u;  // (a second event right behind the first: the next ones go in batches)
+                }
                 st.cursor = p + 1;
-                if (a > b) {  // ---- commit: the bigger set is the set
+                if (grow) {  // ---- commit: the bigger set is the set
                     st.n_accepts++;
                     st.n = n1;
                     st.sumH = sumH_t;
@@ -1603,7 +1929,6 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     const bool low_is_new = low1 == n;
                     const T *lrow = mat + s_pos[low1] * B;
                     const double ltot = s_tot[low1], lrt = s_rt[low1];
-                    const double dn1 = double(n1);
 #pragma unroll
                     for (int j = 0; j < P_J; j++) {
                         const uint64_t i = uint64_t(j) * P_THREADS + tid;
@@ -1617,7 +1942,6 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                             if (lead) {
                                 d.S[i] = stv;
                                 d.M[uint64_t(n) * B + i] = f;
-                                (void)dn1;
                             }
                         }
                     }
@@ -2276,7 +2600,8 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     auto lds_for = [&](uint32_t maxn_) {
         return ((B + 1) & ~1ull) * 8 + (cached && s->mat_kind != 1 ? ((B + 3) & ~3ull) * 4 : 0) +
                (maxm ? ((B + 1) & ~1ull) * 8 : 0) + 128 * 8 + size_t(maxn_) * 52 + 8 + P_SOFT * 8 + 64 +
-               128 * 16 + 128;  // (+ log2_tab's table, + the stamps of a -DDVS_PERSIST_STAMPS build)
+               128 * 16 + 128 +  // (+ log2_tab's table, + the stamps of a -DDVS_PERSIST_STAMPS build)
+               (maxm ? p_batch_lds() : 0);
     };
     size_t lds = lds_for(p_maxn(cached));
     if (s->persist_small) {
@@ -2315,7 +2640,8 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
         s->persist_coop = coop != 0;
     }
     rc = dvs_dev_alloc(ctx, &s->psync, sizeof(PSync), "persistent sync block");
-    if (!rc) rc = dvs_dev_alloc(ctx, &s->ppart, p_acc_bytes(s->persist_maxn), "leave-one-out accumulators");
+    if (!rc) rc = dvs_dev_alloc(ctx, &s->ppart, p_acc_bytes(s->persist_maxn) + (maxm ? p_batch_bytes() : 0),
+                                "leave-one-out accumulators");  // (MODE_MAX: + the results of a batch's jobs)
     if (rc) return rc;
     s->persist = true;
     return DVS_OK;
