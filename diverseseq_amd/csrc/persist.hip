@@ -1775,6 +1775,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     {
                         const uint32_t e = e_commit;
                         const double *ev = s_bev + e * 12;
+                        if (2 * (e + 1) < mx_batch) mx_batch = 2 * (e + 1);  // (kept pushes this close together: shorter batches)
                         sumH_t = st.sumH + s_bH[e];
                         decide(ev[1], ev[2], ev[3], ev[4], ev[5], ev[6], ev[7] != 0.0);  // (tj, band, mean, sd of the kept set)
                         low1 = uint32_t(ev[8]);
@@ -1911,7 +1912,9 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     __syncthreads();
                     break;
                 }
-                mx_batch = dense ? 2u : 1u;  // (a second event right behind the first: the next ones go in batches)
+                // (a rolled-back push right behind the previous event: the next rows go in batches; a kept one
+                // changes the set, and whatever was worked out for the rows behind it would be thrown away)
+                mx_batch = dense && !grow ? 2u : 1u;
                 }
                 st.cursor = p + 1;
                 if (grow) {  // ---- commit: the bigger set is the set

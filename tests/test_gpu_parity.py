@@ -502,6 +502,44 @@ def test_persistent_engine_max_mode(ctx, k, min_size, max_size, stat):
     m.close()
 
 
+def _own_composition_seqs(rng, nseq, lo, hi, dead=()):
+    """every sequence with a base composition of its own (so nearly every row of a `max` stream is an
+    event); the rows listed in `dead` hold no valid k-mer"""
+    seqs = []
+    for i in range(nseq):
+        n = int(rng.integers(lo, hi + 1))
+        pr = rng.dirichlet([3.0, 3.0, 3.0, 3.0])
+        s = rng.choice(4, size=n, p=pr).astype(np.uint8)
+        if i in dead:
+            s[:] = 4 if i % 2 else s[:]
+            if i % 2 == 0:
+                s = s[:3]  # shorter than k
+        seqs.append(s)
+    return seqs
+
+
+@pytest.mark.parametrize("k,min_size,max_size,stat", [(6, 30, None, "stdev"), (6, 30, None, "cov"), (5, 8, None, "stdev"),
+                                                      (6, 12, 20, "stdev"), (4, 40, 47, "cov"), (6, 100, None, "stdev")])
+def test_max_mode_batches_of_consecutive_events(ctx, k, min_size, max_size, stat):
+    """`dvs max` over a stream in which nearly every row is an event (records.rs:390-454): the persistent
+    engine takes the rows behind an event along in batches while the set does not change -- rolled-back
+    pushes, rows without k-mers inside a batch, a kept push in the middle of one, the switch to
+    replace_lowest at max_size, the end of the stream inside a batch -- against the oracle, row for row"""
+    rng = np.random.default_rng(900 + 7 * k + min_size)
+    nseq = 700
+    dead = {min_size + 3, min_size + 4, 200, 201, 202, 450, nseq - 1}
+    seqs = _own_composition_seqs(rng, nseq, 3000, 5000, dead)
+    mx = nseq if max_size is None else max_size
+    m = ctx.build_matrix(seqs, k, 4)
+    sel = m.max_divergent(min_size, mx, stat)
+    s = _assert_selection(sel, oracle.max_divergent(seqs, min_size, mx, k, 4, stat))
+    assert s.engine == 1, "the persistent engine should have run"
+    if max_size is None and stat == "stdev":  # (under cov nearly every push of this stream is kept: nothing to batch)
+        assert s.n_events > 300 and s.n_windows * 4 < s.n_events, (s.n_windows, s.n_events)  # (batches were formed)
+    sel.close()
+    m.close()
+
+
 def test_randomised_small_selections(ctx):
     """sixty small random problems -- short sequences (many near-ties: the arbiter and the engines'
     hand-overs get their share), duplicates, invalid symbols, every mode -- against the oracle"""
