@@ -19,12 +19,27 @@
 
 #include "select.h"
 
+unsigned dvs_host_threads();  // pack.hip: host cores this process may use (cgroup quota respected), at most 16
+
 namespace {
+
+// A frequency row: written once when it is fetched, read-only afterwards -- copies (the reference's clone,
+// records.rs:182-189, copies every record of the set) share the one buffer.
+class RowVec {
+    std::shared_ptr<std::vector<double>> v;
+
+   public:
+    void resize(size_t n) { v = std::make_shared<std::vector<double>>(n); }
+    double *data() { return v->data(); }
+    const double *data() const { return v->data(); }
+    double &operator[](size_t i) { return (*v)[i]; }
+    const double &operator[](size_t i) const { return (*v)[i]; }
+};
 
 struct ExactRow {
     uint64_t pos = 0;
     uint32_t label = 0;
-    std::vector<double> f;
+    RowVec f;
     double H = 0.0;
     double delta = 0.0;
 };
@@ -96,8 +111,7 @@ class ExactSet {
             }
             r.delta = total_jsd - (eom - mean_entropy);
         };
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const size_t nthr = (n * B >= (size_t(1) << 18)) ? std::min<size_t>({n, size_t(hw), size_t(16)}) : 1;
+        const size_t nthr = (n * B >= (size_t(1) << 18)) ? std::min<size_t>(n, size_t(dvs_host_threads())) : 1;
         if (nthr <= 1) {
             for (size_t i = 0; i < n; i++) member(i, work);
         } else {
@@ -265,6 +279,63 @@ int fetch_row(dvs_ctx *ctx, const dvs_select *s, uint64_t p, ExactSet &scratch, 
     return DVS_OK;
 }
 
+// many rows at once (the initial set: a genome-scale `max` starts from 100 seeds -- row by row that is 300
+// blocking copies and 100 x 4^k libm logarithms on one thread): one copy per run of consecutive matrix rows,
+// then the divisions and the entropies on host threads.  Same values as fetch_row, row for row.
+int fetch_rows(dvs_ctx *ctx, const dvs_select *s, const std::vector<uint64_t> &positions, ExactSet &scratch,
+               std::vector<ExactRow> &out) {
+    const dvs_matrix *m = s->mat;
+    const uint64_t B = m->nbins;
+    const size_t n = positions.size();
+    out.assign(n, ExactRow());
+    if (m->kind == 1 || n < 8) {
+        for (size_t i = 0; i < n; i++) {
+            int rc = fetch_row(ctx, s, positions[i], scratch, out[i]);
+            if (rc) return rc;
+        }
+        return DVS_OK;
+    }
+    std::vector<uint32_t> rows(n), tots(n);
+    for (size_t i = 0; i < n; i++) rows[i] = s->h_order.empty() ? uint32_t(positions[i]) : s->h_order[positions[i]];
+    const size_t esz = m->kind == 2 ? 2 : 4;
+    std::vector<unsigned char> raw(n * B * esz);
+    for (size_t a = 0; a < n;) {
+        size_t b = a + 1;
+        while (b < n && rows[b] == rows[b - 1] + 1) b++;
+        const void *src = m->kind == 2 ? static_cast<const void *>(m->d_counts16 + uint64_t(rows[a]) * B)
+                                       : static_cast<const void *>(m->d_counts + uint64_t(rows[a]) * B);
+        DVS_HIP(ctx, hipMemcpy(raw.data() + a * B * esz, src, (b - a) * B * esz, hipMemcpyDeviceToHost));
+        DVS_HIP(ctx, hipMemcpy(tots.data() + a, m->d_totals + rows[a], (b - a) * 4, hipMemcpyDeviceToHost));
+        a = b;
+    }
+    std::vector<std::string> errs(n);
+    auto one = [&](size_t i) {
+        ExactRow &r = out[i];
+        r.pos = positions[i];
+        r.label = s->h_labels.empty() ? rows[i] : s->h_labels[positions[i]];
+        r.f.resize(B);
+        const double total = double(tots[i]);  // record.rs:135-139
+        if (esz == 2) {
+            const uint16_t *c = reinterpret_cast<const uint16_t *>(raw.data()) + i * B;
+            for (uint64_t j = 0; j < B; j++) r.f[j] = double(c[j]) / total;
+        } else {
+            const uint32_t *c = reinterpret_cast<const uint32_t *>(raw.data()) + i * B;
+            for (uint64_t j = 0; j < B; j++) r.f[j] = double(c[j]) / total;
+        }
+        (void)ExactSet::entropy_into(r.f.data(), B, r.H, errs[i]);  // KmerSeq::new, record.rs:157-159
+    };
+    const size_t nthr = std::min<size_t>(n, size_t(dvs_host_threads()));
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < nthr; t++)
+        pool.emplace_back([&, t]() {
+            for (size_t i = t; i < n; i += nthr) one(i);
+        });
+    for (std::thread &th : pool) th.join();
+    for (size_t i = 0; i < n; i++)
+        if (!errs[i].empty()) return dvs_set_error(ctx, DVS_ERR_VALUE, "%s", errs[i].c_str());
+    return DVS_OK;
+}
+
 // the same from a frequency row already on the device (stepwise selections: the row log, the pending
 // candidate in d.cand, a tentative member's row) -- the row itself may live on another rank
 int fetch_dev_row(dvs_ctx *ctx, const dvs_select *s, uint64_t p, const double *d_row, ExactSet &scratch, ExactRow &out) {
@@ -300,9 +371,9 @@ int dvs_select_arbitrate(dvs_ctx *ctx, dvs_select *s) {
     int rc;
     const bool stepwise = (s->params.flags & DVS_SELECT_STEPWISE) != 0;
     if (!a.built) {  // SummedRecords::new over the usable seeds (records.rs:288-308)
-        std::vector<ExactRow> rows(s->seed_positions.size());
-        for (size_t i = 0; i < rows.size(); i++)
-            if ((rc = fetch_row(ctx, s, s->seed_positions[i], set, rows[i]))) return rc;
+        std::vector<ExactRow> rows;
+        std::vector<uint64_t> seed_pos(s->seed_positions.begin(), s->seed_positions.end());
+        if ((rc = fetch_rows(ctx, s, seed_pos, set, rows))) return rc;
         if (!set.init(std::move(rows), B)) return dvs_set_error(ctx, DVS_ERR_VALUE, "%s", set.err.c_str());
         a.built = true;
     }

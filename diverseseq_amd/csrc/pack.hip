@@ -47,8 +47,10 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint8_t *__restrict__
     *reinterpret_cast<uint4 *>(out + g) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+}  // namespace
+
 // host cores this process may really use (the affinity mask capped by the cgroup's CPU quota), at most 16
-unsigned pack_threads() {
+unsigned dvs_host_threads() {
     static const unsigned n = [] {
         unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
@@ -62,8 +64,6 @@ unsigned pack_threads() {
     }();
     return n;
 }
-
-}  // namespace
 
 bool dvs_packed_upload_wanted(const dvs_ctx *ctx, uint32_t num_states, uint64_t nbytes) {
     return num_states == 4 && nbytes >= (uint64_t(32) << 20) && !ctx->knobs.no_packed_upload;
@@ -106,7 +106,7 @@ int dvs_upload_packed(dvs_ctx *ctx, const uint8_t *seqs, uint64_t nbytes, uint8_
             done[c].store(1, std::memory_order_release);
         }
     };
-    const unsigned nthr = unsigned(std::min<size_t>(pack_threads(), nchunks));
+    const unsigned nthr = unsigned(std::min<size_t>(dvs_host_threads(), nchunks));
     std::vector<std::thread> pool;
     for (unsigned t = 0; t + 1 < nthr; t++) pool.emplace_back(work);  // (this thread sends; with one core it packs too)
     hipError_t e = hipSuccess;
