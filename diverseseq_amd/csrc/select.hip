@@ -1030,7 +1030,11 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
             return dvs_set_error(ctx, DVS_ERR_RUNTIME, "selection engine stopped with an internal error");
         if (c.status != SEL_RUN)
             return dvs_set_error(ctx, DVS_ERR_RUNTIME, "selection engine in state %u", c.status);
-        if (s->persist) {
+        // a `max` set that has outgrown the engine's LDS replica and may still grow: the engine would hand
+        // every launch straight back (it did: 152 of 309 launches of a 664-member cov selection) -- the
+        // multi-launch kernels keep the stream until the set is full
+        const bool replica_full = s->params.mode == DVS_MODE_MAX && c.size + 2 > s->persist_maxn && c.size < c.max_size;
+        if (s->persist && !replica_full) {
             // a persistent launch that comes back still RUNNING with the cursor where it was did
             // not take the state it found (e.g. an event left pending by the arbiter's hand-off):
             // the multi-launch kernels, which take any state, carry on -- never a relaunch loop
@@ -1056,7 +1060,8 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
         // (behind a persistent launch that left ONE event for these kernels -- a decision inside its band --
         // a single iteration takes that event; the engine is launched again right after)
         // (an engine that keeps coming back where it started -- a set its replica cannot hold -- gets whole batches)
-        const int iters = (s->persist && persist_launches && !persist_was_last && persist_idle < 2) ? 1 : s->batch;
+        if (replica_full) persist_was_last = false;
+        const int iters = (s->persist && !replica_full && persist_launches && !persist_was_last && persist_idle < 2) ? 1 : s->batch;
         for (int i = 0; i < iters; i++) launch_iteration<T>(ctx, s, mat, 0);
         DVS_HIP(ctx, hipGetLastError());
     }
