@@ -175,6 +175,9 @@ if __name__ == "__main__":
                     reps=2, composition=True, min_size=100)
         select_case("C3 scaled (1050 genomes, i.i.d. uniform: degenerate)", 1050, 2_500_000, 3_500_000, 6, "max",
                     reps=2, min_size=100)
+    if "C3F" in which:  # (only when asked for: 31.5 GB of sequence)
+        select_case("C3 as stated (10 500 genomes, own base composition each)", 10_500, 2_500_000, 3_500_000, 6, "max",
+                    reps=2, composition=True, min_size=100)
     if want("ING"):
         ingest_case("FASTA ingest, 100 x 3 Mb genomes", 100, 3_000_000)
         ingest_case("FASTA ingest, 100k x 5 kb records", 100_000, 5_040)
