@@ -1573,37 +1573,89 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                             for (int j = 0; j < P_J; j++) fv[j] = count_freq_x(cv[j], tot_e, rt_e);
                             if (e + ng < E) request(e + ng);
                             if (tot_e == 0.0 || (known0 && e == 0 && r == n + 2)) continue;  // (no k-mers: never an event; nobody reads the result)
+                            // The job's kind is the workgroup's, not the bin's: one loop per kind, no test inside
+                            // (as eight tests and branches per bin the job was 560 vector + scalar instructions, twice
+                            // its arithmetic).  A term that is zero is multiplied out instead of skipped: log2_tab of a
+                            // tiny positive number is finite, so u = 0 adds -0 * finite -- bit for bit the sum of the
+                            // single-row path.
                             double h = 0.0, sv = 0.0, mn = 0.0;
-                            if (r == n + 2) {  // increases_jsd of row p + e (records.rs:70-92), as `evaluate` above
-                                Ent en;
+                            // sum of -u log2 u over the thread's bins, u >= 0: log2_tab (select_dev.h) in three passes --
+                            // all mantissas and table reads first, then the polynomials -- so that the eight LDS
+                            // reads travel together instead of one wait per bin (two waves per SIMD hide nothing)
+                            auto entropy_of = [&](const double (&u)[P_J]) {
+                                double mnt[P_J];
+                                int ex[P_J];
+                                double2 tb[P_J];
 #pragma unroll
                                 for (int j = 0; j < P_J; j++) {
-                                    const uint64_t i = uint64_t(j) * P_THREADS + tid;
-                                    if (i < B) en.add((sl[i] + fv[j]) * rn, s_ltab);
+                                    const double x = fmax(u[j], 1e-300);
+                                    mnt[j] = __builtin_amdgcn_frexp_mant(x);
+                                    ex[j] = __builtin_amdgcn_frexp_exp(x);
+                                    tb[j] = s_ltab[(uint32_t(__double2hiint(mnt[j])) >> 13) & 127u];
                                 }
-                                h = en.h;
-                                sv = en.sum;
-                                mn = en.mn;
-                            } else {
+                                double acc = 0.0;
 #pragma unroll
                                 for (int j = 0; j < P_J; j++) {
-                                    const uint64_t i = uint64_t(j) * P_THREADS + tid;
-                                    if (i < B) {
-                                        const double f = fv[j];
-                                        const double stv = Sl[i] + f;  // S of the bigger set
-                                        double u;
-                                        if (r == n1) {
-                                            u = stv * rn1;
-                                        } else {
-                                            const double fm = r == n ? f : fmv[j];
-                                            u = (stv - fm) * rdiv1;  // updated_mean_freqs, records.rs:276-286
-                                            if (u <= DVS_EPS) u = 0.0;
+                                    const double r_ = fma(mnt[j], tb[j].y, -1.0);
+                                    double q = 1.0 / 7.0;
+                                    q = fma(q, r_, -1.0 / 6.0);
+                                    q = fma(q, r_, 1.0 / 5.0);
+                                    q = fma(q, r_, -1.0 / 4.0);
+                                    q = fma(q, r_, 1.0 / 3.0);
+                                    q = fma(q, r_, -1.0 / 2.0);
+                                    q = fma(q, r_, 1.0);
+                                    const double lg = fma(q * r_, 1.4426950408889634, double(ex[j]) + tb[j].x);
+                                    acc -= u[j] * lg;  // (in bin order, as the single-row path adds them)
+                                }
+                                return acc;
+                            };
+                            auto job = [&](auto full_c) {
+                                constexpr bool FULL = decltype(full_c)::value;  // 4^k = 4096: every thread owns P_J bins
+                                double u[P_J];
+                                if (r == n + 2) {  // increases_jsd of row p + e (records.rs:70-92), as `evaluate` above
+#pragma unroll
+                                    for (int j = 0; j < P_J; j++) {
+                                        const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                                        u[j] = 0.0;
+                                        if (FULL || i < B) {
+                                            const double x = (sl[i] + fv[j]) * rn;
+                                            u[j] = fmax(x, 0.0);
+                                            sv += x;
+                                            mn = fmin(mn, x);
                                         }
-                                        if (u > 0.0) h -= u * log2_tab(u, s_ltab);
-                                        sv += u;
+                                    }
+                                } else if (r == n1) {  // the bigger set as a whole
+#pragma unroll
+                                    for (int j = 0; j < P_J; j++) {
+                                        const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                                        u[j] = 0.0;
+                                        if (FULL || i < B) {
+                                            const double x = (Sl[i] + fv[j]) * rn1;
+                                            u[j] = fmax(x, 0.0);
+                                            sv += x;
+                                        }
+                                    }
+                                } else {  // without member r (r == n: without the candidate itself)
+                                    if (r == n) {
+#pragma unroll
+                                        for (int j = 0; j < P_J; j++) fmv[j] = fv[j];
+                                    }
+#pragma unroll
+                                    for (int j = 0; j < P_J; j++) {
+                                        const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                                        u[j] = 0.0;
+                                        if (FULL || i < B) {
+                                            double x = ((Sl[i] + fv[j]) - fmv[j]) * rdiv1;  // updated_mean_freqs, records.rs:276-286
+                                            if (x <= DVS_EPS) x = 0.0;
+                                            u[j] = x;
+                                            sv += x;
+                                        }
                                     }
                                 }
-                            }
+                                h = entropy_of(u);
+                            };
+                            if (B == uint64_t(P_J) * P_THREADS) job(std::true_type{});
+                            else job(std::false_type{});
                             h = dvs_wave_sum_dpp(h);
                             sv = dvs_wave_sum_dpp(sv);
                             mn = dvs_wave_min(mn);
