@@ -132,6 +132,7 @@ void dvs_knobs_from_env(dvs_knobs *k) {
     k->cu_mask_set = on("HSA_CU_MASK") || on("ROC_GLOBAL_CU_MASK");
     k->no_persist = on("DVS_NO_PERSIST");
     k->no_persist_max = on("DVS_NO_PERSIST_MAX");
+    k->no_max_batch = on("DVS_NO_MAX_BATCH");
     k->no_head_phase = on("DVS_NO_HEAD_PHASE");
     k->no_side_stream = on("DVS_NO_SIDE_STREAM");
     k->keep_labels = on("DVS_KEEP_LABELS");

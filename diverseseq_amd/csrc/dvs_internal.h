@@ -36,7 +36,7 @@ struct dvs_knobs {
     int head_cus = 0;                 // DVS_HEAD_CUS
     bool cu_mask_set = false;         // HSA_CU_MASK / ROC_GLOBAL_CU_MASK present: the device reports CUs it will not give
     // selection engines (select.hip, persist.hip)
-    bool no_persist = false, no_persist_max = false, no_head_phase = false, no_side_stream = false;
+    bool no_persist = false, no_persist_max = false, no_max_batch = false, no_head_phase = false, no_side_stream = false;
     bool keep_labels = false, persist_no_seeded = false, persist_seeded_any = false, persist_no_small = false;
     bool persist_coop = false, persist_debug = false;
     bool persist_no_coarse = false, persist_no_events = false, persist_no_burst_drop = false, persist_no_speculation = false;

@@ -26,6 +26,8 @@ struct SelCtl {
     uint32_t ev_n;      // members taking part in the pending leave-one-out pass
     uint32_t ev_risky;  // a sum-to-one check is too close to call on the device
     uint32_t s_is_resum;  // S still equals the members' rows added up in member order (only pushes so far)
+    uint32_t mb_rows;     // MODE_MAX batches: rows the batch pairs have moved the cursor over
+    uint32_t mb_stuck;    // MODE_MAX batches: the row at the cursor is the ordinary iteration's (a push to keep, a call too close)
     uint32_t n_windows, n_events, n_accepts;
     uint32_t n_logged;  // entries of the event log (accepted set changes, for the arbiter)
     double total_jsd, sum_entropy;      // records.rs: total_jsd, summed_entropies
@@ -111,6 +113,9 @@ struct dvs_select {
     std::vector<unsigned char> h_psync;  // host image of the sync block (source of its upload)
     std::vector<unsigned char> h_psync_head;  // ... and the head phase's
     void *ppart = nullptr;
+    double *d_mbres = nullptr;  // MODE_MAX batches (select.hip: max_batch_*): the jobs' results, 3 x MB_ROWS x mb_jw
+    uint32_t mb_jw = 0;
+    uint32_t mb_launched = 0;   // batch pairs launched (summary / tests)
     void *psync_head = nullptr, *ppart_head = nullptr;  // the head phase's own blocks
     bool persist_seeded = false;    // the next persistent launch starts from the seed positions (no set-up kernels ran)
     bool seeded_start = false;      // ... this selection began that way (sel_run_loop: a launch may hand the set-up back)

@@ -340,6 +340,7 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, double *scrat
             const uint64_t end = umin64(ctl->cursor + uint64_t(ctl->window), ctl->npos);
             ctl->n_windows++;
             ctl->cursor = end;
+            ctl->mb_stuck = 0;
             if (end >= ctl->npos) ctl->status = SEL_DONE;
             ctl_next_window(ctl);
         }
@@ -389,6 +390,7 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, double *scrat
             ctl->cursor = p + 1;
             ctl->event_pos = SEL_NONE;
             ctl->last_jsd = jsd;
+            if (action == 0) ctl->mb_stuck = 0;  // (rejected: the row a batch stopped at is behind the cursor now)
             if (action == 0 && ctl->cursor >= ctl->npos) ctl->status = SEL_DONE;
         }
         s_action = action;
@@ -720,12 +722,190 @@ __device__ void finalize_body(SelDev &d, double *scratch, int &s_go) {
         ctl->thr = ctl->total_jsd + DVS_EPS;
         ctl->ev_kind = 0;
         ctl->ev_risky = 0;
+        ctl->mb_stuck = 0;
         ctl->event_pos = SEL_NONE;
         if (ctl->cursor >= ctl->npos) ctl->status = SEL_DONE;
         ctl_next_window(ctl);
     }
 }
 
+
+// ---- MODE_MAX while the set may grow: a BATCH of rows against the unchanged set.
+// A tentative push that is rolled back leaves the set as it was (records.rs:439-450), and so does a row that
+// is no event: the rows from the cursor up to the next push that is KEPT all face the same set.  Where
+// events come back to back (genome collections: nearly every row is one, one in fifty is kept) the iteration
+// above -- five launches and ~130 us per event -- walks them one by one.  These two kernels take MB_ROWS rows
+// at once: max_batch_jobs works out, for every row, its own increases_jsd score and the leave-one-out pass
+// of the bigger set (one workgroup per row and member), max_batch_decide takes the decisions (the
+// arithmetic and the bands of resolve / finalize) and moves the cursor over the rows that are NOT events or
+// whose push is clearly rolled back -- nothing else: the first row that would be kept, or that is too close
+// to call, stays where it is, and the ordinary iteration behind the pair deals with it (commit, arbiter).
+// The persistent engine has the same thing in-kernel (persist.hip); this one has no limits on 4^k or the set.
+constexpr uint32_t MB_ROWS = 32;
+constexpr int MB_THREADS = 256;
+constexpr uint32_t MB_MAX_MEMBERS = 4096;  // sets up to this size (the result block is 3 x MB_ROWS x (this + 3) doubles)
+
+__device__ __forceinline__ bool max_batch_applies(const SelCtl *ctl, const SelDev &d, uint32_t JW) {
+    return ctl->status == SEL_RUN && ctl->ev_kind == 0 && ctl->mode == DVS_MODE_MAX && ctl->size < ctl->max_size &&
+           ctl->s_is_resum != 0 && ctl->forced == FORCE_NONE && !d.gather_all && ctl->size + 3 <= JW && ctl->size >= 2 &&
+           ctl->mb_stuck == 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(MB_THREADS) void max_batch_jobs_kernel(SelDev d, const T *__restrict__ mat,
+                                                                    double *__restrict__ res, uint32_t JW) {
+    __shared__ double scratch[48];
+    __shared__ double2 ltab[128];  // log2_tab's table (select_dev.h): ~18 instead of ~33 instructions per logarithm
+    const SelCtl *ctl = d.ctl;
+    if (!max_batch_applies(ctl, d, JW)) return;
+    const uint32_t n = ctl->size, r = blockIdx.x, e = blockIdx.y;
+    if (r >= n + 3) return;
+    if (threadIdx.x < 128) log2_tab_fill(ltab, threadIdx.x);
+    __syncthreads();
+    const uint64_t p = ctl->cursor + e;
+    if (p >= ctl->npos) return;
+    const uint32_t row = d.order ? d.order[p] : uint32_t(p);
+    const uint32_t lab = d.labels ? d.labels[p] : row;
+    if (lab < d.nlabels && d.inset[lab]) return;  // a member already: no event (records.rs:71-74,87-89)
+    const uint32_t toti = d.totals[row];
+    if (toti == 0) return;  // no valid k-mer: the stream skips the row (records.rs:419-423)
+    const double tot = double(toti);
+    const T *rp = mat + uint64_t(row) * d.B;
+    Ent en;
+    if (r == n + 2) {  // increases_jsd: block_delta_jsd's arithmetic
+        const double *low = d.M + uint64_t(d.ord[ctl->lowest]) * d.B;
+        const double dsize = double(n);
+        for (uint64_t i = threadIdx.x; i < d.B; i += MB_THREADS) {
+            const double v = d.S[i] - low[i];
+            en.add((v + cand_freq(rp, i, tot)) / dsize, ltab);
+        }
+    } else if (r == n + 1) {  // the bigger set as a whole (resolve_body: Stmp = S + candidate, H(Stmp / (n + 1)))
+        const double dn1 = double(n + 1);
+        for (uint64_t i = threadIdx.x; i < d.B; i += MB_THREADS) en.add((d.S[i] + cand_freq(rp, i, tot)) / dn1, ltab);
+    } else {  // without member r, r == n: without the candidate (loo_body)
+        const double div = double(n);
+        const double *mrow = r < n ? d.M + uint64_t(d.ord[r]) * d.B : nullptr;
+        for (uint64_t i = threadIdx.x; i < d.B; i += MB_THREADS) {
+            const double f = cand_freq(rp, i, tot);
+            double v = ((d.S[i] + f) - (mrow ? mrow[i] : f)) / div;  // updated_mean_freqs, records.rs:276-286
+            if (v <= DVS_EPS) v = 0.0;
+            en.add(v, ltab);
+        }
+    }
+    double h = en.h, mn = en.mn, sm = en.sum;
+    block_red3(h, mn, sm, scratch);
+    if (threadIdx.x == 0) {
+        res[(uint64_t(e) * 3 + 0) * JW + r] = h;
+        res[(uint64_t(e) * 3 + 1) * JW + r] = sm;
+        res[(uint64_t(e) * 3 + 2) * JW + r] = mn;
+    }
+}
+
+__global__ __launch_bounds__(WIDE_THREADS) void max_batch_decide_kernel(SelDev d, const double *__restrict__ res, uint32_t JW) {
+    __shared__ double s_kind[MB_ROWS], s_counted[MB_ROWS];
+    SelCtl *ctl = d.ctl;
+    if (!max_batch_applies(ctl, d, JW)) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = WIDE_THREADS / 64;
+    const uint32_t n = ctl->size, n1 = n + 1;
+    const uint64_t p0 = ctl->cursor;
+    const uint32_t nrows = uint32_t(umin64(MB_ROWS, ctl->npos - p0));
+    const double dn = double(n), dn1 = double(n1);
+    for (uint32_t e = wave; e < nrows; e += nwave) {
+        // kind: 0 the stream moves on (no event, or a push that is clearly rolled back), 2 it stops here (a push
+        // that would be kept, or anything too close to call)
+        double kind = 0.0, counted = 0.0;
+        const uint64_t p = p0 + e;
+        const uint32_t row = d.order ? d.order[p] : uint32_t(p);
+        const uint32_t lab = d.labels ? d.labels[p] : row;
+        const bool dead = (lab < d.nlabels && d.inset[lab]) || d.totals[row] == 0;
+        if (!dead) {
+            const double H_e = d.rowH[row];
+            const double *re = res + uint64_t(e) * 3 * JW;
+            const double hs = re[n + 2], ss = re[JW + n + 2], ms = re[2 * JW + n + 2];
+            const double jsd = (ms < 0.0) ? NAN : hs - (ctl->he_base + H_e) / dn;  // block_delta_jsd
+            counted = 1.0;
+            if (sum_risky(ss, d.B) || fabs(jsd - ctl->thr) <= ctl->band) {
+                kind = 2.0;
+                counted = 0.0;
+            } else if (jsd > ctl->thr) {  // an event: the tentative push (resolve_body, loo_body, finalize_body)
+                const double sumH_t = ctl->sum_entropy + H_e;
+                const double hm = re[n1], svm = re[JW + n1];
+                const double tj = hm - sumH_t / dn1;
+                const double div = dn1 - 1.0;
+                auto delta = [&](uint32_t r) {
+                    const double mh = r < n ? d.mH[d.ord[r]] : H_e;
+                    return tj - (re[r] - (sumH_t - mh) / div);
+                };
+                double best = 1e6, acc = 0.0;
+                bool risky = sum_risky(svm, d.B) || !(hm == hm);
+                for (uint32_t r = lane; r < n1; r += 64) {
+                    const double v = delta(r);
+                    risky |= sum_risky(re[JW + r], d.B);
+                    acc += v;
+                    if (v < best) best = v;
+                }
+                const double dmin = dvs_wave_min(best);
+                double fi = 4294967295.0;
+                for (uint32_t r = lane; r < n1; r += 64)
+                    if (dmin < 1e6 && delta(r) == dmin) fi = fmin(fi, double(r));
+                const double dfirst = dvs_wave_min(fi);
+                const uint32_t lowest = (dfirst < 4294967295.0) ? uint32_t(dfirst) : 0u;
+                const double mean = dvs_wave_sum(acc) / dn1;
+                double second = 1e6, tv = 0.0;
+                for (uint32_t r = lane; r < n1; r += 64) {
+                    const double v = delta(r);
+                    if (r != lowest && v < second) second = v;
+                    const double t = v - mean;
+                    tv += t * t;
+                }
+                const double dsecond = dvs_wave_min(second);
+                const double sd = sqrt(dvs_wave_sum(tv) / (dn1 - 1.0));
+                const double cov = sd / mean;
+                const bool any_risky = __ballot(risky) != 0ull;
+                const double band = sel_band(tj + sumH_t / dn1, d.B);
+                const double a = ctl->stat == DVS_STAT_STDEV ? sd : cov;
+                const double b = ctl->stat == DVS_STAT_STDEV ? ctl->std_delta : ctl->cov_delta;
+                const double mm = fmin(fabs(mean), fabs(ctl->mean_delta));
+                const double sband = ctl->stat == DVS_STAT_STDEV
+                                         ? 4.0 * band
+                                         : 4.0 * band * (1.0 + fmax(fabs(a), fabs(b))) / fmax(mm, 1e-300);
+                const bool tie = any_risky || (dsecond - dmin <= band && dsecond < 1e6) || !(fabs(a - b) > sband);
+                if (tie || a > b) {  // too close to call, or a push that is kept: the ordinary iteration's
+                    kind = 2.0;
+                    counted = 0.0;
+                }
+            }
+        }
+        if (lane == 0) {
+            s_kind[e] = kind;
+            s_counted[e] = counted;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t stop = nrows, events = 0;
+        for (uint32_t e = 0; e < nrows; e++) {
+            if (s_kind[e] == 2.0) {
+                stop = e;
+                break;
+            }
+            events += s_counted[e] != 0.0;
+        }
+        // (a batch that stopped in front of a row leaves that row to the ordinary iteration; the batch pairs
+        // queued behind this one return at once until finalize has dealt with it)
+        if (stop < nrows) ctl->mb_stuck = 1;
+        if (stop > 0) {
+            ctl->cursor = p0 + stop;
+            ctl->mb_rows += stop;
+            ctl->n_events += events;
+            ctl->n_windows++;
+            ctl->rows_scored += stop;
+            ctl->event_pos = SEL_NONE;
+            if (ctl->cursor >= ctl->npos) ctl->status = SEL_DONE;
+            ctl_next_window(ctl);
+        }
+    }
+}
 
 // Resolve kernel (one block).  (Resolve + leave-one-out + finalize as ONE single-block launch for
 // small sets measured slower -- 10.6 vs 8.9 ms per stepwise selection: one CU issues every
@@ -855,6 +1035,7 @@ static void sel_free(dvs_select *s) {
         dvs_dev_free(s->ctx, p);
     dvs_pinned_put(s->ctx, s->h_ctl);
     for (hipEvent_t e : s->ev_pool) dvs_event_put(s->ctx, e);
+    dvs_dev_free(s->ctx, s->d_mbres);
     dvs_dev_free(s->ctx, s->psync);
     dvs_dev_free(s->ctx, s->ppart);
     dvs_dev_free(s->ctx, s->psync_head);
@@ -900,6 +1081,23 @@ static void launch_iteration(dvs_ctx *ctx, dvs_select *s, const T *mat, int stag
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(WIDE_THREADS), 0, stream, d);
 }
 
+// the batch pair in front of an ordinary iteration (MODE_MAX while the set may grow and events are dense);
+// size_bound: no set this launch can meet is larger
+template <typename T>
+static int launch_max_batch(dvs_ctx *ctx, dvs_select *s, const T *mat, uint32_t size_bound) {
+    if (!s->d_mbres) {
+        s->mb_jw = std::min<uint32_t>(s->cap, MB_MAX_MEMBERS) + 3;
+        int rc = dvs_dev_alloc(ctx, (void **)&s->d_mbres, size_t(3) * MB_ROWS * s->mb_jw * sizeof(double), "max batch results");
+        if (rc) return rc;
+    }
+    if (size_bound + 3 > s->mb_jw) return DVS_OK;  // (a set beyond the result block: the ordinary iterations alone)
+    hipLaunchKernelGGL((max_batch_jobs_kernel<T>), dim3(size_bound + 3, MB_ROWS), dim3(MB_THREADS), 0, ctx->stream, s->dev, mat,
+                       s->d_mbres, s->mb_jw);
+    hipLaunchKernelGGL(max_batch_decide_kernel, dim3(1), dim3(WIDE_THREADS), 0, ctx->stream, s->dev, s->d_mbres, s->mb_jw);
+    s->mb_launched++;
+    return DVS_OK;
+}
+
 static int sel_poll(dvs_ctx *ctx, dvs_select *s) {
     DVS_HIP(ctx, hipMemcpyAsync(s->h_ctl, s->dev.ctl, sizeof(SelCtl), hipMemcpyDeviceToHost,
                                 ctx->stream));
@@ -916,6 +1114,10 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
     unsigned persist_launches = 0;
     bool persist_was_last = false;  // nothing but the poll happened since the last persistent launch
     unsigned persist_idle = 0;      // persistent launches in a row that came back where they started
+    bool mb_seen = false, mb_dense = true;  // MODE_MAX batches: events per row between the last two looks (dense until seen otherwise)
+    unsigned long long mb_cursor = 0, mb_events = 0;
+    bool mb_useful = true;
+    uint32_t mb_rows_seen = 0, mb_round_pairs = 0, mb_idle_rounds = 0;
     if (s->persist && first_unpolled) {
         // straight behind the set-up kernels, no host round trip in between: the kernel itself
         // returns at once unless the control block says RUN
@@ -1062,7 +1264,34 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
         // (an engine that keeps coming back where it started -- a set its replica cannot hold -- gets whole batches)
         if (replica_full) persist_was_last = false;
         const int iters = (s->persist && !replica_full && persist_launches && !persist_was_last && persist_idle < 2) ? 1 : s->batch;
-        for (int i = 0; i < iters; i++) launch_iteration<T>(ctx, s, mat, 0);
+        // MODE_MAX while the set may grow: where at least every second row since the last look was an event,
+        // a batch pair goes in front of every iteration (it skips the rows that change nothing)
+        if (mb_seen) {
+            const unsigned long long rows = c.cursor - mb_cursor, evs = c.n_events - mb_events;
+            if (rows) mb_dense = evs * 2 >= rows;
+        }
+        mb_seen = true;
+        mb_cursor = c.cursor;
+        mb_events = c.n_events;
+        // ... and only while the pairs earn their keep: a stream whose pushes are nearly all KEPT (cov over
+        // sequences of very different composition) stops every batch at its first row -- then they are left
+        // out, and tried again every eighth look
+        // (a probe: pairs in front of the first two iterations of a look only)
+        if (mb_round_pairs) mb_useful = (c.mb_rows - mb_rows_seen) >= 2u * mb_round_pairs;
+        mb_rows_seen = c.mb_rows;
+        mb_round_pairs = 0;
+        const bool mb_can = mb_dense && iters > 1 && c.mode == DVS_MODE_MAX && c.size < c.max_size && c.s_is_resum != 0 &&
+                            !(s->params.flags & DVS_SELECT_STEPWISE) && !ctx->knobs.no_max_batch;
+        const bool mb_probe = mb_can && !mb_useful && ++mb_idle_rounds >= 4;
+        if (mb_probe || mb_useful) mb_idle_rounds = 0;
+        const int mb_iters = !mb_can ? 0 : mb_useful ? iters : mb_probe ? 2 : 0;  // (a selection starts with them on)
+        for (int i = 0; i < iters; i++) {
+            for (int b = 0; i < mb_iters && b < 3; b++) {  // (the second and third return at once where the first one stopped at a row)
+                if ((rc = launch_max_batch<T>(ctx, s, mat, c.size + uint32_t(i)))) return rc;
+                mb_round_pairs += b == 0;
+            }
+            launch_iteration<T>(ctx, s, mat, 0);
+        }
         DVS_HIP(ctx, hipGetLastError());
     }
 }

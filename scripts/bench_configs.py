@@ -175,6 +175,9 @@ if __name__ == "__main__":
                     reps=2, composition=True, min_size=100)
         select_case("C3 scaled (1050 genomes, i.i.d. uniform: degenerate)", 1050, 2_500_000, 3_500_000, 6, "max",
                     reps=2, min_size=100)
+    if "C3K7" in which:  # (`max` at 4^7 bins: not on the persistent engine)
+        select_case("C3 scaled at k=7 (1050 genomes, own base composition each)", 1050, 2_500_000, 3_500_000, 7, "max",
+                    reps=2, composition=True, min_size=100)
     if "C3F" in which:  # (only when asked for: 31.5 GB of sequence)
         select_case("C3 as stated (10 500 genomes, own base composition each)", 10_500, 2_500_000, 3_500_000, 6, "max",
                     reps=2, composition=True, min_size=100)

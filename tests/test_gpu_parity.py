@@ -519,7 +519,8 @@ def _own_composition_seqs(rng, nseq, lo, hi, dead=()):
 
 
 @pytest.mark.parametrize("k,min_size,max_size,stat", [(6, 30, None, "stdev"), (6, 30, None, "cov"), (5, 8, None, "stdev"),
-                                                      (6, 12, 20, "stdev"), (4, 40, 47, "cov"), (6, 100, None, "stdev")])
+                                                      (6, 12, 20, "stdev"), (4, 40, 47, "cov"), (6, 100, None, "stdev"),
+                                                      (7, 30, None, "stdev"), (7, 9, 40, "cov"), (7, 20, None, "cov")])
 def test_max_mode_batches_of_consecutive_events(ctx, k, min_size, max_size, stat):
     """`dvs max` over a stream in which nearly every row is an event (records.rs:390-454): the persistent
     engine takes the rows behind an event along in batches while the set does not change -- rolled-back
@@ -533,9 +534,33 @@ def test_max_mode_batches_of_consecutive_events(ctx, k, min_size, max_size, stat
     m = ctx.build_matrix(seqs, k, 4)
     sel = m.max_divergent(min_size, mx, stat)
     s = _assert_selection(sel, oracle.max_divergent(seqs, min_size, mx, k, 4, stat))
-    assert s.engine == 1, "the persistent engine should have run"
+    # 4^7 bins: not the persistent engine's -- the multi-launch kernels' own batches (select.hip: max_batch_*)
+    assert s.engine == (1 if k <= 6 else 0)
     if max_size is None and stat == "stdev":  # (under cov nearly every push of this stream is kept: nothing to batch)
         assert s.n_events > 300 and s.n_windows * 4 < s.n_events, (s.n_windows, s.n_events)  # (batches were formed)
+    sel.close()
+    m.close()
+
+
+def test_max_mode_batches_with_an_order_and_labels(ctx):
+    """the multi-launch batches under a caller's order and labels (duplicated labels: a row whose label is
+    already in the set is no event, records.rs:71-74): the oracle's answer"""
+    rng = np.random.default_rng(4242)
+    seqs = _own_composition_seqs(rng, 400, 2000, 3000, {50, 51, 300})
+    order = rng.permutation(400).astype(np.uint32)
+    labels = np.arange(400, dtype=np.uint32)
+    labels[order[120]] = labels[order[3]]  # two rows share a label with a seed / an early row
+    labels[order[121]] = labels[order[40]]
+    m = ctx.build_matrix(seqs, 6, 4)
+    lab = labels[order]
+    sel = m.max_divergent(20, 400, "stdev", order=order, labels=lab)
+    exp = oracle.max_divergent([seqs[i] for i in order], 20, 400, 6, 4, "stdev", labels=lab.tolist())
+    gm, s = sel.members(False), sel.summary()
+    assert s.size == exp.size and s.size > 20
+    assert [int(lab[p]) for p in gm.positions] == exp.members()[0].tolist()
+    np.testing.assert_allclose(gm.delta_jsd, exp.members()[1], rtol=RTOL, atol=1e-13)
+    assert abs(s.total_jsd - exp.total_jsd) <= RTOL * exp.total_jsd
+    assert s.engine == 0 and s.n_windows * 3 < s.n_events, (s.n_windows, s.n_events)  # (batches were formed)
     sel.close()
     m.close()
 
