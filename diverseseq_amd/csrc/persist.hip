@@ -52,13 +52,14 @@ constexpr int P_J = 8;                      // bins per thread kept in registers
 constexpr int P_CH = 16;                    // row chunks requested per burst (4096 bins)
 constexpr uint32_t P_MAXN = 512;            // members the LDS replica holds when 4^k <= 4096 ...
 constexpr uint32_t P_MAXN_BIG = 256;        // ... and beyond (k = 7: 128 KB of LDS go to the set state)
-constexpr uint32_t p_maxn(bool cached) { return cached ? P_MAXN : P_MAXN_BIG; }
+constexpr uint32_t P_MAXN_MAX = 1024;       // ... `max` with 4^k <= 4096 (sets grow; nmost's scan loop pays for the constant in scratch)
+constexpr uint32_t p_maxn(bool cached, bool maxm = false) { return cached ? (maxm ? P_MAXN_MAX : P_MAXN) : P_MAXN_BIG; }
 // SMALL sets (nmost over 16-bit count rows of 4096 bins): the members' count rows live in every
 // workgroup's LDS (see the kernel)
 constexpr uint32_t P_SMALLN = 16;      // members the replica arrays of a SMALL launch hold ...
 constexpr uint32_t P_SMALL_ROWS = 13;  // ... and rows (8 KB each) that fit beside the state in 160 KB of LDS
 // leave-one-out jobs per event: (n + 1) * K <= max(G - 1, n + 1) <= maxn + 1 (G <= maxn + 2 is checked)
-constexpr uint32_t p_maxjobs(bool cached) { return p_maxn(cached) + 1; }
+constexpr uint32_t p_maxjobs(bool cached, bool maxm = false) { return p_maxn(cached, maxm) + 1; }
 // leave-one-out accumulators: 3 slots (accept % 3) x 8 group replicas x (maxn + 1) members x 2 words
 constexpr size_t p_acc_bytes(uint32_t maxn) { return size_t(3) * 8 * (maxn + 1) * 2 * sizeof(unsigned long long); }
 // A leave-one-out accumulator word = (2^-50 fixed-point sum << 6) + number of contributions: a
@@ -744,7 +745,7 @@ template <typename T, bool CACHED, bool MAXM = false, bool SMALL = false>
 __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, const T *__restrict__ mat,
                                                                     PSync *sync, unsigned long long *part, uint32_t G) {
     static_assert(!SMALL || (CACHED && !MAXM && sizeof(T) == 2), "SMALL: nmost, 16-bit rows, state in the register cache");
-    constexpr uint32_t maxn = SMALL ? P_SMALLN : p_maxn(CACHED);
+    constexpr uint32_t maxn = SMALL ? P_SMALLN : p_maxn(CACHED, MAXM);
     // SPEC: nmost over a count matrix whose rows fit the register cache -- the accept's first steps (the
     // candidate's row, its frequencies, this workgroup's leave-one-out job) are taken while the window's
     // rendezvous is still completing (see the event loop)
@@ -2658,14 +2659,14 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
                128 * 16 + 128 +  // (+ log2_tab's table, + the stamps of a -DDVS_PERSIST_STAMPS build)
                (maxm ? p_batch_lds() : 0);
     };
-    size_t lds = lds_for(p_maxn(cached));
+    size_t lds = lds_for(p_maxn(cached, maxm));
     if (s->persist_small) {
         const size_t lds_small = lds_for(P_SMALLN) + size_t(s->persist_small_rows) * B * 2 + 16;
         if (lds_small <= ctx->lds_per_block) lds = lds_small;
         else s->persist_small = false;
     }
-    s->persist_maxn = s->persist_small ? P_SMALLN : p_maxn(cached);
-    s->persist_maxjobs = s->persist_small ? P_SMALLN + 1 : p_maxjobs(cached);
+    s->persist_maxn = s->persist_small ? P_SMALLN : p_maxn(cached, maxm);
+    s->persist_maxjobs = s->persist_small ? P_SMALLN + 1 : p_maxjobs(cached, maxm);
     // (MODE_MAX: max_size may be the whole stream; the kernel hands over when its LDS replica is full)
     if (!maxm && s->cap > s->persist_maxn) return DVS_OK;
     if (lds > ctx->lds_per_block) return DVS_OK;
