@@ -2238,21 +2238,80 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 }
             } else {
                 const bool need_m = r < n && !is_new;
-                for (uint32_t c0 = part_i; c0 < nchunk; c0 += 4 * K) {  // four chunks' requests at a time
-                    T cv[4], mv[4];
+                // Eight chunks at a time: sixteen loads in flight per thread, then the bins WITHOUT a test inside
+                // (the job's kind is the workgroup's; as tests and branches per bin, and with four chunks a time,
+                // a job of sixteen chunks at 4^7 bins took 8.6 us) and their logarithms in three passes (all table
+                // reads together).  A term that is zero is multiplied out (log2_tab of a tiny number is finite).
+                constexpr int NQ = sizeof(T) <= 4 ? 8 : 4;
+                for (uint32_t c0 = part_i; c0 < nchunk; c0 += NQ * K) {
+                    T cv[NQ], mv[NQ];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
+                    for (int q = 0; q < NQ; q++) {
                         const uint64_t i = uint64_t(c0 + q * K) * P_THREADS + tid;
                         if (c0 + q * K < nchunk && i < B) {
                             cv[q] = rp[i];
                             if (need_m) mv[q] = mrow[i];
                         }
                     }
+                    double u[NQ];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
+                    for (int q = 0; q < NQ; q++) {
                         const uint64_t i = uint64_t(c0 + q * K) * P_THREADS + tid;
-                        if (c0 + q * K < nchunk && i < B)
-                            bin(i, count_freq_x(cv[q], tot, rtot), need_m ? count_freq_x(mv[q], mtot, mrt) : 0.0);
+                        u[q] = 0.0;
+                        if (c0 + q * K < nchunk && i < B) {
+                            double v = sl[i];
+                            if (v <= DVS_EPS) v = 0.0;
+                            const double f = count_freq_x(cv[q], tot, rtot);
+                            u[q] = v + f;  // S' of the bin
+                        }
+                    }
+                    if (r == n) {  // the whole set
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) u[q] = fmax(u[q] * rn, 0.0);
+                    } else if (is_new) {  // without the new member itself
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) {
+                            const uint64_t i = uint64_t(c0 + q * K) * P_THREADS + tid;
+                            if (c0 + q * K < nchunk && i < B) {
+                                double x = (u[q] - count_freq_x(cv[q], tot, rtot)) * rdiv;
+                                if (x <= DVS_EPS) x = 0.0;
+                                u[q] = x;
+                            }
+                        }
+                    } else {  // without member r
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) {
+                            const uint64_t i = uint64_t(c0 + q * K) * P_THREADS + tid;
+                            if (c0 + q * K < nchunk && i < B) {
+                                double x = (u[q] - count_freq_x(mv[q], mtot, mrt)) * rdiv;
+                                if (x <= DVS_EPS) x = 0.0;
+                                u[q] = x;
+                            }
+                        }
+                    }
+                    double mnt[NQ];
+                    int ex[NQ];
+                    double2 tb[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) {
+                        const double x = fmax(u[q], 1e-300);
+                        mnt[q] = __builtin_amdgcn_frexp_mant(x);
+                        ex[q] = __builtin_amdgcn_frexp_exp(x);
+                        tb[q] = s_ltab[(uint32_t(__double2hiint(mnt[q])) >> 13) & 127u];
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) {
+                        const double r_ = fma(mnt[q], tb[q].y, -1.0);
+                        double pl = 1.0 / 7.0;
+                        pl = fma(pl, r_, -1.0 / 6.0);
+                        pl = fma(pl, r_, 1.0 / 5.0);
+                        pl = fma(pl, r_, -1.0 / 4.0);
+                        pl = fma(pl, r_, 1.0 / 3.0);
+                        pl = fma(pl, r_, -1.0 / 2.0);
+                        pl = fma(pl, r_, 1.0);
+                        const double lg = fma(pl * r_, 1.4426950408889634, double(ex[q]) + tb[q].x);
+                        h -= u[q] * lg;
+                        sv += u[q];
                     }
                 }
             }
@@ -2452,10 +2511,12 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             const bool low_is_new = lowest == n - 1;
             const T *lrow = mat + s_pos[lowest] * B;
             const double ltot = s_tot[lowest], lrt = s_rt[lowest];
-            for (uint64_t b0 = 0; b0 < B; b0 += uint64_t(P_J) * P_THREADS) {
-                // every count of the block is requested before the first is used: 2 P_J loads in
+            // (4^7 bins of 16- or 32-bit counts: sixteen chunks a block -- two memory round trips instead of four)
+            constexpr int RB = (!CACHED && sizeof(T) <= 4) ? 2 * P_J : P_J;
+            for (uint64_t b0 = 0; b0 < B; b0 += uint64_t(RB) * P_THREADS) {
+                // every count of the block is requested before the first is used: 2 RB loads in
                 // flight per thread instead of one memory round trip per bin (k = 7: 32 bins a thread)
-                T cv[P_J], lv[P_J];
+                T cv[RB], lv[RB];
                 if constexpr (SMALL) {  // the new lowest member's counts: this thread's 16 bytes of its LDS row
                     const uint4 q = *reinterpret_cast<const uint4 *>(s_rows + uint64_t(s_slot[lowest]) * 4096 + uint32_t(tid) * 8);
                     lv[0] = T(q.x & 0xFFFFu); lv[1] = T(q.x >> 16);
@@ -2464,7 +2525,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     lv[6] = T(q.w & 0xFFFFu); lv[7] = T(q.w >> 16);
                 } else {
 #pragma unroll
-                for (int j = 0; j < P_J; j++) {
+                for (int j = 0; j < RB; j++) {
                     const uint64_t i = b0 + uint64_t(j) * P_THREADS + tid;
                     if (i < B) {
                         if (!CACHED) cv[j] = rp[i];
@@ -2477,12 +2538,12 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 P_STAMP(8);
 #endif
 #pragma unroll
-                for (int j = 0; j < P_J; j++) {
+                for (int j = 0; j < RB; j++) {
                     const uint64_t i = b0 + uint64_t(j) * P_THREADS + tid;
                     if (i < B) {
                         double v = sl[i];
                         if (v <= DVS_EPS) v = 0.0;
-                        const double f = CACHED ? fr[j] : count_freq_x(cv[j], tot, rtot);
+                        const double f = CACHED ? fr[j % P_J] : count_freq_x(cv[j], tot, rtot);
                         const double sn = v + f;
                         const double nv = sn - (low_is_new ? f : count_freq_x(lv[j], ltot, lrt));
                         sl[i] = nv;
