@@ -349,12 +349,19 @@ int fetch_dev_row(dvs_ctx *ctx, const dvs_select *s, uint64_t p, const double *d
     return DVS_OK;
 }
 
+// The decision goes to the control block with blocking copies AND a device synchronisation behind them: a
+// small copy from pageable memory returns once the bytes are staged, not once they are in device memory,
+// and the context's stream is a non-blocking one -- without the wait the kernels queued next saw, one time in
+// a few hundred, the old ARBITER status, returned at once, and the host arbitrated the same decision a
+// second time (same answer, twice the work; found by repeating one selection 600 times,
+// scripts/micro/c4_repeat.py).
 int write_forced(dvs_ctx *ctx, dvs_select *s, uint32_t forced, uint32_t forced_lowest) {
     SelCtl *d = s->dev.ctl;
     const uint32_t run = SEL_RUN;
     DVS_HIP(ctx, hipMemcpy(&d->forced, &forced, 4, hipMemcpyHostToDevice));
     DVS_HIP(ctx, hipMemcpy(&d->forced_lowest, &forced_lowest, 4, hipMemcpyHostToDevice));
     DVS_HIP(ctx, hipMemcpy(&d->status, &run, 4, hipMemcpyHostToDevice));
+    DVS_HIP(ctx, hipDeviceSynchronize());
     return DVS_OK;
 }
 

@@ -70,6 +70,21 @@ __device__ __forceinline__ unsigned long long p_acc_word(double v) {
     return ((unsigned long long)__double2ll_rn(v * 0x1p50) << 6) + 1ull;
 }
 __device__ __forceinline__ double p_acc_value(unsigned long long w) { return double((long long)w >> 6) * 0x1p-50; }
+// A job's two words added to an accumulator pair.  settle: the adds RETURN and the results are consumed, i.e.
+// the additions have been performed when the thread goes on -- needed wherever the readers only pass a grid
+// barrier (sets of 64 members and more, the seeded start, max mode): a non-returning add is merely on its
+// way when the adding thread's barrier arrival (a returning atomic) comes back.  Smaller sets poll the
+// words until their contribution counts are complete and need no such wait.
+__device__ __forceinline__ void p_acc_add(unsigned long long *dst, double th, double ts, bool settle) {
+    if (settle) {
+        const unsigned long long a = atomicAdd(dst, p_acc_word(th));
+        const unsigned long long b = atomicAdd(dst + 1, p_acc_word(ts));
+        asm volatile("" ::"v"(a), "v"(b) : "memory");
+    } else {
+        atomicAdd(dst, p_acc_word(th));
+        atomicAdd(dst + 1, p_acc_word(ts));
+    }
+}
 __device__ __forceinline__ uint32_t p_acc_count(unsigned long long w) { return uint32_t(w & 63ull); }
 constexpr uint32_t P_SPIN_LIMIT = 1u << 22;  // ~0.5 s of polling
 #ifndef DVS_P_FLAT_GRID
@@ -141,7 +156,16 @@ struct PState {  // replicated scalars (identical in every workgroup)
 // mirror block stores to global memory is read by nobody before the kernel ends.  (An agent-scope
 // release + acquire pair around the barrier -- L2 write-back and invalidate on every XCD -- cost
 // another 4 us per barrier.)
+// What a wave has SENT before it gets here without consuming a result -- the leave-one-out partials are
+// non-returning atomic adds, a batch's results plain atomic stores -- is waited for first (s_waitcnt
+// vmcnt(0): the memory system has acknowledged every outstanding operation of the wave).  Issue order alone
+// is not enough: thread 0's arrival below is a RETURNING atomic, and returns overtake acknowledgements of
+// earlier non-returning operations now and then -- one selection in a hundred at 4^7 bins and n = 100 lost a
+// job's partial that way (the reader behind the barrier saw the accumulator without it; the sum check
+// caught it and sent the argmin to the arbiter, but total_jsd came from the same accumulators:
+// scripts/micro/c4_repeat.py, 3000 repetitions of one selection, found 22 such and 6 wrong answers).
 __device__ bool grid_barrier(PSync *sync, uint32_t G, uint32_t &gen, int *s_ok) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t target = gen + 1;
@@ -963,8 +987,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     ts += scratch[80 + w];
                 }
                 unsigned long long *dst = acc_all + (uint64_t(tid) * (maxn + 1) + r) * 2;
-                atomicAdd(dst, p_acc_word(th));
-                atomicAdd(dst + 1, p_acc_word(ts));
+                p_acc_add(dst, th, ts, true);
             }
         }
         if (!grid_barrier(sync, G, gen, s_flag)) {
@@ -1124,16 +1147,18 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         unsigned long long *evrec = evs + (blockIdx.x & 7u) * 32;    // this workgroup's copy of the record ...
         unsigned long long *evp = evrec + 1;                          // ... and its event word
         // the slot of the NEXT epoch is cleared now (event words, listed flags, the list's count -- not the
-        // generations); an exchange (its result is consumed) has been performed before this thread's
-        // arrival at the barrier below can be
-        // (plain stores, nobody waits for them: this wave's arrival at the window's rendezvous below is a
-        // returning atomic issued behind them, and a wave's memory operations are acknowledged in order --
-        // they have been performed before anybody can leave that rendezvous and post to the slot)
+        // generations), by exchanges whose results are consumed: PERFORMED before this thread's arrival at the
+        // window's rendezvous below, i.e. before anybody can leave that rendezvous and post to the slot.
+        // (They were plain stores for a while this round, on the assumption that a wave's memory operations
+        // are acknowledged in order; the returning arrival overtakes non-returning operations now and then --
+        // see grid_barrier.  The mirror block scans nothing, so the round trip costs the window nothing.)
         if (lead && tid < 17) {
             unsigned long long *nx = &sync->ev[(epoch + 1) % 3][0];
-            if (tid < 8) __hip_atomic_store(nx + tid * 32 + 1, SEL_NONE, RLX_AGENT);
-            else if (tid < 16) __hip_atomic_store(reinterpret_cast<uint32_t *>(nx + (tid - 8) * 32) + 1, 0u, RLX_AGENT);
-            else __hip_atomic_store(&sync->soft[(epoch + 1) % 3][0], 0ull, RLX_AGENT);
+            unsigned long long seen;
+            if (tid < 8) seen = __hip_atomic_exchange(nx + tid * 32 + 1, SEL_NONE, RLX_AGENT);
+            else if (tid < 16) seen = __hip_atomic_exchange(reinterpret_cast<uint32_t *>(nx + (tid - 8) * 32) + 1, 0u, RLX_AGENT);
+            else seen = __hip_atomic_exchange(&sync->soft[(epoch + 1) % 3][0], 0ull, RLX_AGENT);
+            asm volatile("" ::"v"(seen) : "memory");
         }
 #ifdef DVS_PERSIST_STAMPS
         const unsigned long long t_window = __builtin_amdgcn_s_memrealtime();
@@ -1671,16 +1696,18 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                         // rendezvous: a wave's memory operations are acknowledged in order); waves summed in a fixed order
                         __syncthreads();
                         if (wave == 0) {
+                            unsigned long long seen = 0;  // (exchanges, results consumed: performed before the rendezvous)
                             for (uint32_t x = lane; x < 3 * E; x += 64) {
                                 const uint32_t e = x / 3, k = x % 3;
                                 if (e >= e_first && (e - e_first) % ng == 0) {
                                     const double *pw = s_bpart + x * 8;
                                     double t = pw[0];
                                     for (uint32_t w = 1; w < P_THREADS / 64; w++) t = k == 2 ? fmin(t, pw[w]) : t + pw[w];
-                                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(bres) + (uint64_t(e) * 3 + k) * JW + r,
-                                                       (unsigned long long)__double_as_longlong(t), RLX_AGENT);
+                                    seen |= __hip_atomic_exchange(reinterpret_cast<unsigned long long *>(bres) + (uint64_t(e) * 3 + k) * JW + r,
+                                                                  (unsigned long long)__double_as_longlong(t), RLX_AGENT);
                                 }
                             }
+                            asm volatile("" ::"v"(seen) : "memory");
                         }
                         __syncthreads();  // (s_bpart is rewritten by the next member's jobs)
                     }
@@ -1884,8 +1911,12 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 if (lead) {  // the accumulators of the next round (eight replicas), as in the replace path
                     unsigned long long *nx = part + uint64_t((slot_t + 1) % 3) * 8 * (maxn + 1) * 2;
                     const uint32_t ne = (n1 + 2 <= maxn + 1 ? n1 + 2 : maxn + 1) * 2u;
-                    for (uint32_t i = tid; i < 8u * ne; i += P_THREADS)
-                        __hip_atomic_store(nx + (uint64_t(i / ne) * (maxn + 1)) * 2 + i % ne, 0ull, RLX_AGENT);
+                    if (wave == 0) {  // (wave 0 alone, by exchanges whose results are consumed: see the replace path)
+                        unsigned long long seen = 0;
+                        for (uint32_t i = lane; i < 8u * ne; i += 64)
+                            seen |= __hip_atomic_exchange(nx + (uint64_t(i / ne) * (maxn + 1)) * 2 + i % ne, 0ull, RLX_AGENT);
+                        asm volatile("" ::"v"(seen) : "memory");
+                    }
                 }
                 unsigned long long *accw = part + uint64_t(slot_t) * 8 * (maxn + 1) * 2;
                 const unsigned long long *accr = accw + uint64_t(blockIdx.x & 7u) * (maxn + 1) * 2;
@@ -1930,8 +1961,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                             ts += scratch[80 + w];
                         }
                         unsigned long long *dst = accw + (uint64_t(tid) * (maxn + 1) + r) * 2;
-                        atomicAdd(dst, p_acc_word(th));
-                        atomicAdd(dst + 1, p_acc_word(ts));
+                        p_acc_add(dst, th, ts, true);
                     }
                 }
                 if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
@@ -2056,8 +2086,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 if (tid < 8) {  // lane g adds the job's words to group g's replica
                     unsigned long long *dst = part + uint64_t(acc_slot) * 8 * (maxn + 1) * 2 +
                                               (uint64_t(tid) * (maxn + 1) + blockIdx.x / K) * 2;
-                    atomicAdd(dst, p_acc_word(spec_th));
-                    atomicAdd(dst + 1, p_acc_word(spec_ts));
+                    p_acc_add(dst, spec_th, spec_ts, st.n >= 64);
                 }
                 job_published = true;
             }
@@ -2171,11 +2200,19 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             // the accumulators of the next accept are cleared now: every workgroup read them (two
             // accepts ago) before it arrived at this window's first barrier
             // (all eight group replicas; the stores are acknowledged before this block's next
-            // barrier arrival, and nobody adds to that slot before that barrier has completed)
+            // barrier arrival, and nobody adds to that slot before that barrier has completed.
+            // By WAVE 0 ALONE, which then WAITS for the acknowledgements: it is thread 0 that arrives at that
+            // barrier; a store of another wave, queued behind this block's 256 KB of mirror stores, could land
+            // after another workgroup's add of the next accept and wipe it -- and so could wave 0's own without
+            // the wait: see grid_barrier.)
             unsigned long long *nx = part + uint64_t((acc_slot + 1) % 3) * 8 * (maxn + 1) * 2;
-            for (uint32_t i = tid; i < 8u * (n + 1) * 2u; i += P_THREADS) {
-                const uint32_t g = i / ((n + 1) * 2u), w = i % ((n + 1) * 2u);
-                __hip_atomic_store(nx + (uint64_t(g) * (maxn + 1)) * 2 + w, 0ull, RLX_AGENT);
+            if (wave == 0) {
+                unsigned long long seen = 0;  // (exchanges whose results are consumed: PERFORMED, not merely issued)
+                for (uint32_t i = lane; i < 8u * (n + 1) * 2u; i += 64) {
+                    const uint32_t g = i / ((n + 1) * 2u), w = i % ((n + 1) * 2u);
+                    seen |= __hip_atomic_exchange(nx + (uint64_t(g) * (maxn + 1)) * 2 + w, 0ull, RLX_AGENT);
+                }
+                asm volatile("" ::"v"(seen) : "memory");
             }
         }
         // ================= leave-one-out (get_lowest_record_index, records.rs:220-252, with
@@ -2221,8 +2258,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 small_job(r, part_i, r, n, th, ts);
                 if (tid < 8) {  // lane g adds the job's words to group g's replica
                     unsigned long long *dst = acc_all + (uint64_t(tid) * (maxn + 1) + r) * 2;
-                    atomicAdd(dst, p_acc_word(th));
-                    atomicAdd(dst + 1, p_acc_word(ts));
+                    p_acc_add(dst, th, ts, n >= 64);
                 }
                 first_job = false;
                 continue;
@@ -2331,8 +2367,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     ts += scratch[80 + w];
                 }
                 unsigned long long *dst = acc_all + (uint64_t(tid) * (maxn + 1) + r) * 2;
-                atomicAdd(dst, p_acc_word(th));
-                atomicAdd(dst + 1, p_acc_word(ts));
+                p_acc_add(dst, th, ts, n >= 64);
             }
         }
         st.cursor = p + 1;
