@@ -60,8 +60,14 @@ constexpr uint32_t P_SMALLN = 16;      // members the replica arrays of a SMALL 
 constexpr uint32_t P_SMALL_ROWS = 13;  // ... and rows (8 KB each) that fit beside the state in 160 KB of LDS
 // leave-one-out jobs per event: (n + 1) * K <= max(G - 1, n + 1) <= maxn + 1 (G <= maxn + 2 is checked)
 constexpr uint32_t p_maxjobs(bool cached, bool maxm = false) { return p_maxn(cached, maxm) + 1; }
-// leave-one-out accumulators: 3 slots (accept % 3) x 8 group replicas x (maxn + 1) members x 2 words
-constexpr size_t p_acc_bytes(uint32_t maxn) { return size_t(3) * 8 * (maxn + 1) * 2 * sizeof(unsigned long long); }
+// leave-one-out accumulators: P_ACC_SLOTS slots (accept % P_ACC_SLOTS) x 8 group replicas x (maxn + 1) members x
+// 2 words.  Sixteen slots, not three: a slot is cleared (plain stores by the mirror block) EIGHT accepts before
+// it is used again -- tens of microseconds, where a clear one accept ahead had to be verified before the
+// next rendezvous (1600 memory-side round trips at n = 100 behind the mirror block's own 256 KB of stores:
+// +1.3 us per accept) or, unverified, lost a race now and then.  The readers check contribution counts
+// (p_acc_complete), so a clear that did come too late would end in a time-out, not in a wrong total.
+constexpr uint32_t P_ACC_SLOTS = 16;
+constexpr size_t p_acc_bytes(uint32_t maxn) { return size_t(P_ACC_SLOTS) * 8 * (maxn + 1) * 2 * sizeof(unsigned long long); }
 // A leave-one-out accumulator word = (2^-50 fixed-point sum << 6) + number of contributions: a
 // reader that finds the count at K knows the sum is complete -- no barrier between the jobs and
 // the workgroups that need their totals.  Sums of such words add sums and counts independently
@@ -70,22 +76,32 @@ __device__ __forceinline__ unsigned long long p_acc_word(double v) {
     return ((unsigned long long)__double2ll_rn(v * 0x1p50) << 6) + 1ull;
 }
 __device__ __forceinline__ double p_acc_value(unsigned long long w) { return double((long long)w >> 6) * 0x1p-50; }
-// A job's two words added to an accumulator pair.  settle: the adds RETURN and the results are consumed, i.e.
-// the additions have been performed when the thread goes on -- needed wherever the readers only pass a grid
-// barrier (sets of 64 members and more, the seeded start, max mode): a non-returning add is merely on its
-// way when the adding thread's barrier arrival (a returning atomic) comes back.  Smaller sets poll the
-// words until their contribution counts are complete and need no such wait.
-__device__ __forceinline__ void p_acc_add(unsigned long long *dst, double th, double ts, bool settle) {
-    if (settle) {
-        const unsigned long long a = atomicAdd(dst, p_acc_word(th));
-        const unsigned long long b = atomicAdd(dst + 1, p_acc_word(ts));
-        asm volatile("" ::"v"(a), "v"(b) : "memory");
-    } else {
-        atomicAdd(dst, p_acc_word(th));
-        atomicAdd(dst + 1, p_acc_word(ts));
-    }
+// A job's two words added to an accumulator pair: non-returning adds, merely SENT when the adding thread's
+// workgroup arrives at the next barrier (a returning atomic overtakes them now and then) -- which is why
+// every reader checks the contribution count in the words' low bits (p_acc_complete), barrier or not.
+__device__ __forceinline__ void p_acc_add(unsigned long long *dst, double th, double ts) {
+    atomicAdd(dst, p_acc_word(th));
+    atomicAdd(dst + 1, p_acc_word(ts));
 }
 __device__ __forceinline__ uint32_t p_acc_count(unsigned long long w) { return uint32_t(w & 63ull); }
+// an accumulator word once all K contributions are in (bounded spin: ok = false on a time-out -- also what a
+// slot that was not cleared in time ends in: an error and the multi-launch kernels, never a wrong total)
+__device__ __forceinline__ unsigned long long p_acc_complete(const unsigned long long *w, uint32_t K, bool &ok) {
+    unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t spins = 0;
+#ifndef DVS_P_VERIFY_COUNTS
+#define DVS_P_VERIFY_COUNTS 1
+#endif
+    while (DVS_P_VERIFY_COUNTS && uint32_t(v & 63ull) != K) {
+        if (++spins > (1u << 20)) {
+            ok = false;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return v;
+}
 constexpr uint32_t P_SPIN_LIMIT = 1u << 22;  // ~0.5 s of polling
 #ifndef DVS_P_FLAT_GRID
 #define DVS_P_FLAT_GRID 64
@@ -137,7 +153,7 @@ struct PState {  // replicated scalars (identical in every workgroup)
     uint32_t n, li;
     double sumH, total_jsd, thr, band, wscale;
     uint32_t n_windows, n_events, n_accepts;
-    uint32_t n_loo;  // leave-one-out rounds of this launch (accumulator slot = n_loo % 3)
+    uint32_t n_loo;  // leave-one-out rounds of this launch (accumulator slot = n_loo % P_ACC_SLOTS)
     // MODE_MAX: the set grows while it is below max_size (tentative pushes, records.rs:427-451)
     uint32_t max_size, stat;
     double mean_d, std_d, cov_d;  // statistics of the current set's delta_jsd
@@ -156,16 +172,16 @@ struct PState {  // replicated scalars (identical in every workgroup)
 // mirror block stores to global memory is read by nobody before the kernel ends.  (An agent-scope
 // release + acquire pair around the barrier -- L2 write-back and invalidate on every XCD -- cost
 // another 4 us per barrier.)
-// What a wave has SENT before it gets here without consuming a result -- the leave-one-out partials are
-// non-returning atomic adds, a batch's results plain atomic stores -- is waited for first (s_waitcnt
-// vmcnt(0): the memory system has acknowledged every outstanding operation of the wave).  Issue order alone
-// is not enough: thread 0's arrival below is a RETURNING atomic, and returns overtake acknowledgements of
-// earlier non-returning operations now and then -- one selection in a hundred at 4^7 bins and n = 100 lost a
-// job's partial that way (the reader behind the barrier saw the accumulator without it; the sum check
-// caught it and sent the argmin to the arbiter, but total_jsd came from the same accumulators:
-// scripts/micro/c4_repeat.py, 3000 repetitions of one selection, found 22 such and 6 wrong answers).
+// "Consumed" is meant literally: a non-returning atomic add or a plain atomic store that the writer merely
+// ISSUED before thread 0's arrival below (a returning atomic) is NOT necessarily performed when that
+// arrival comes back -- returns overtake the acknowledgements of earlier non-returning operations now and
+// then.  One selection in a hundred at 4^7 bins and n = 100 lost a leave-one-out partial that way (the reader
+// behind the barrier saw the accumulator without it; the sum check caught it and sent the argmin to the
+// arbiter, but total_jsd came from the same accumulators: scripts/micro/c4_repeat.py, 3000 repetitions of
+// one selection, found 22 such runs and 6 wrong answers).  Hence p_acc_add(settle) and the exchanges with
+// consumed results wherever the readers only pass this barrier.  (Waiting for vmcnt(0) here instead would
+// also hold the mirror block until its 256 KB of stores per accept are acknowledged: +7 us per accept.)
 __device__ bool grid_barrier(PSync *sync, uint32_t G, uint32_t &gen, int *s_ok) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t target = gen + 1;
@@ -235,11 +251,22 @@ __device__ __forceinline__ unsigned long long p_ev_word(uint64_t p, bool sure) {
     return ((unsigned long long)p << 1) | (sure ? 0ull : 1ull);
 }
 __device__ __forceinline__ uint64_t p_ev_pos(unsigned long long w) { return w == SEL_NONE ? SEL_NONE : uint64_t(w >> 1); }
+// (the results are CONSUMED: the minimum has been taken at the memory side when the posting thread goes on,
+// hence before its workgroup's arrival at the window's rendezvous -- a non-returning atomic is merely on its
+// way then, see grid_barrier)
+#ifndef DVS_P_POST_CONSUME
+#define DVS_P_POST_CONSUME 1
+#endif
 __device__ __forceinline__ void p_post_event_wave(unsigned long long *evs, uint64_t p, bool sure, uint32_t lane) {
-    if (lane < 8) atomicMin(evs + lane * 32 + 1, p_ev_word(p, sure));
+    if (lane < 8) {
+        const unsigned long long old = atomicMin(evs + lane * 32 + 1, p_ev_word(p, sure));
+        if (DVS_P_POST_CONSUME) asm volatile("" ::"v"(old) : "memory");
+    }
 }
 __device__ __forceinline__ void p_post_event_thread(unsigned long long *evs, uint64_t p, bool sure) {
-    for (uint32_t g = 0; g < 8; g++) atomicMin(evs + g * 32 + 1, p_ev_word(p, sure));
+    unsigned long long seen = 0;
+    for (uint32_t g = 0; g < 8; g++) seen |= atomicMin(evs + g * 32 + 1, p_ev_word(p, sure));
+    if (DVS_P_POST_CONSUME) asm volatile("" ::"v"(seen) : "memory");
 }
 // a candidate was listed: the flag of every group's record (the results are consumed: performed before
 // this thread's workgroup can arrive at the rendezvous)
@@ -875,6 +902,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     uint32_t pend_kind = 0;  // ev_kind left pending for the multi-launch kernels (finalize tie)
     bool bail = false;       // leave with the state as it stands and status RUN (MAXM: an undecidable push)
     [[maybe_unused]] uint32_t mx_batch = 1;  // MAXM: rows the next tentative push takes along (identical in every workgroup)
+    uint32_t acc_cleared_for = 0xFFFFFFFFu;  // mirror block: the accept whose accumulators have been cleared
     const uint64_t wpb = P_THREADS / 64;
     const uint32_t nwg = G > 1 ? G - 1 : 1;           // scanning workgroups
     const uint64_t nwaves = uint64_t(nwg) * wpb;      // scanning waves
@@ -987,16 +1015,17 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     ts += scratch[80 + w];
                 }
                 unsigned long long *dst = acc_all + (uint64_t(tid) * (maxn + 1) + r) * 2;
-                p_acc_add(dst, th, ts, true);
+                p_acc_add(dst, th, ts);
             }
         }
         if (!grid_barrier(sync, G, gen, s_flag)) {
             if (lead && tid == 0) ctl->status = SEL_ERROR;
             return;
         }
+        bool acc_ok = true;
         for (uint32_t r = tid; r <= n; r += P_THREADS) {
-            const double h = p_acc_value(__hip_atomic_load(acc + uint64_t(r) * 2, RLX_AGENT));
-            const double sv = p_acc_value(__hip_atomic_load(acc + uint64_t(r) * 2 + 1, RLX_AGENT));
+            const double h = p_acc_value(p_acc_complete(acc + uint64_t(r) * 2, K, acc_ok));
+            const double sv = p_acc_value(p_acc_complete(acc + uint64_t(r) * 2 + 1, K, acc_ok));
             if (r == n) {
                 scratch[110] = h;
                 scratch[111] = sv;
@@ -1005,7 +1034,10 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 s_ds[r] = sv;
             }
         }
-        __syncthreads();
+        if (__syncthreads_or(acc_ok ? 0 : 1)) {  // (a contribution that never arrived: every workgroup sees the same)
+            if (lead && tid == 0) ctl->status = SEL_ERROR;
+            return;
+        }
         const double hm = scratch[110];
         const double tj = hm - sh / dn0;
         const bool evr = sum_risky(scratch[111], B) || !(hm == hm);
@@ -1029,7 +1061,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         st.mean_d = mean0;
         st.std_d = sd0;
         st.cov_d = sd0 / mean0;
-        st.n_loo = 1;  // (slot 0 is in use; the first accept takes slot 1 and clears slot 2)
+        st.n_loo = 1;  // (slot 0 is in use; the first accept takes slot 1)
         {   // sl <- S - lowest (no clamp: what the set-up kernels' base vector holds)
             const T *lrow = mat + s_pos[low0] * B;
             const double ltot = s_tot[low0], lrt = s_rt[low0];
@@ -1152,13 +1184,25 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // (They were plain stores for a while this round, on the assumption that a wave's memory operations
         // are acknowledged in order; the returning arrival overtakes non-returning operations now and then --
         // see grid_barrier.  The mirror block scans nothing, so the round trip costs the window nothing.)
+#ifndef DVS_P_SLOT_EXCH
+#define DVS_P_SLOT_EXCH 1
+#endif
         if (lead && tid < 17) {
             unsigned long long *nx = &sync->ev[(epoch + 1) % 3][0];
             unsigned long long seen;
             if (tid < 8) seen = __hip_atomic_exchange(nx + tid * 32 + 1, SEL_NONE, RLX_AGENT);
             else if (tid < 16) seen = __hip_atomic_exchange(reinterpret_cast<uint32_t *>(nx + (tid - 8) * 32) + 1, 0u, RLX_AGENT);
             else seen = __hip_atomic_exchange(&sync->soft[(epoch + 1) % 3][0], 0ull, RLX_AGENT);
-            asm volatile("" ::"v"(seen) : "memory");
+            if (DVS_P_SLOT_EXCH) asm volatile("" ::"v"(seen) : "memory");
+        }
+        // ... and the leave-one-out accumulators eight accepts AHEAD (plain stores, once per accept: see
+        // P_ACC_SLOTS; that slot's last readers passed a rendezvous eight accepts ago)
+        if (lead && acc_cleared_for != st.n_loo) {
+            acc_cleared_for = st.n_loo;
+            unsigned long long *nx = part + uint64_t((st.n_loo + P_ACC_SLOTS / 2) % P_ACC_SLOTS) * 8 * (maxn + 1) * 2;
+            const uint32_t ne = (st.n + P_ACC_SLOTS <= maxn + 1 ? st.n + P_ACC_SLOTS : maxn + 1) * 2u;  // (max mode: the set may grow by then)
+            for (uint32_t i = tid; i < 8u * ne; i += P_THREADS)
+                __hip_atomic_store(nx + (uint64_t(i / ne) * (maxn + 1)) * 2 + i % ne, 0ull, RLX_AGENT);
         }
 #ifdef DVS_PERSIST_STAMPS
         const unsigned long long t_window = __builtin_amdgcn_s_memrealtime();
@@ -1890,7 +1934,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 if (exit_status == SEL_ERROR || bail || (left && exit_status == SEL_DONE)) break;
                 if (left) continue;
                 } else {
-                const uint32_t slot_t = st.n_loo % 3;
+                const uint32_t slot_t = st.n_loo % P_ACC_SLOTS;
                 st.n_loo++;
                 uint32_t K1 = 1;
                 {
@@ -1908,16 +1952,6 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     s_rt[n] = rtot;
                 }
                 __syncthreads();
-                if (lead) {  // the accumulators of the next round (eight replicas), as in the replace path
-                    unsigned long long *nx = part + uint64_t((slot_t + 1) % 3) * 8 * (maxn + 1) * 2;
-                    const uint32_t ne = (n1 + 2 <= maxn + 1 ? n1 + 2 : maxn + 1) * 2u;
-                    if (wave == 0) {  // (wave 0 alone, by exchanges whose results are consumed: see the replace path)
-                        unsigned long long seen = 0;
-                        for (uint32_t i = lane; i < 8u * ne; i += 64)
-                            seen |= __hip_atomic_exchange(nx + (uint64_t(i / ne) * (maxn + 1)) * 2 + i % ne, 0ull, RLX_AGENT);
-                        asm volatile("" ::"v"(seen) : "memory");
-                    }
-                }
                 unsigned long long *accw = part + uint64_t(slot_t) * 8 * (maxn + 1) * 2;
                 const unsigned long long *accr = accw + uint64_t(blockIdx.x & 7u) * (maxn + 1) * 2;
                 bool first1 = true;
@@ -1961,13 +1995,14 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                             ts += scratch[80 + w];
                         }
                         unsigned long long *dst = accw + (uint64_t(tid) * (maxn + 1) + r) * 2;
-                        p_acc_add(dst, th, ts, true);
+                        p_acc_add(dst, th, ts);
                     }
                 }
                 if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
+                bool acc_ok = true;
                 for (uint32_t r = tid; r <= n1; r += P_THREADS) {
-                    const double h = p_acc_value(__hip_atomic_load(accr + uint64_t(r) * 2, RLX_AGENT));
-                    const double sv = p_acc_value(__hip_atomic_load(accr + uint64_t(r) * 2 + 1, RLX_AGENT));
+                    const double h = p_acc_value(p_acc_complete(accr + uint64_t(r) * 2, K1, acc_ok));
+                    const double sv = p_acc_value(p_acc_complete(accr + uint64_t(r) * 2 + 1, K1, acc_ok));
                     if (r == n1) {
                         scratch[110] = h;
                         scratch[111] = sv;
@@ -1976,7 +2011,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                         s_ds[r] = sv;
                     }
                 }
-                __syncthreads();
+                if (__syncthreads_or(acc_ok ? 0 : 1)) { exit_status = SEL_ERROR; break; }
                 {
                     const double hm0 = scratch[110];
                     const double tj0 = hm0 - sumH_t * rn1;
@@ -2075,7 +2110,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             }
         }
         // ================= replace_lowest (records.rs:94-147) + leave-one-out
-        const uint32_t acc_slot = st.n_loo % 3;
+        const uint32_t acc_slot = st.n_loo % P_ACC_SLOTS;
         st.n_loo++;
         st.n_accepts++;
         // SPEC: a leave-one-out job worked out for this very candidate while the rendezvous was completing
@@ -2086,7 +2121,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 if (tid < 8) {  // lane g adds the job's words to group g's replica
                     unsigned long long *dst = part + uint64_t(acc_slot) * 8 * (maxn + 1) * 2 +
                                               (uint64_t(tid) * (maxn + 1) + blockIdx.x / K) * 2;
-                    p_acc_add(dst, spec_th, spec_ts, st.n >= 64);
+                    p_acc_add(dst, spec_th, spec_ts);
                 }
                 job_published = true;
             }
@@ -2197,23 +2232,6 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     }
                 }
             }
-            // the accumulators of the next accept are cleared now: every workgroup read them (two
-            // accepts ago) before it arrived at this window's first barrier
-            // (all eight group replicas; the stores are acknowledged before this block's next
-            // barrier arrival, and nobody adds to that slot before that barrier has completed.
-            // By WAVE 0 ALONE, which then WAITS for the acknowledgements: it is thread 0 that arrives at that
-            // barrier; a store of another wave, queued behind this block's 256 KB of mirror stores, could land
-            // after another workgroup's add of the next accept and wipe it -- and so could wave 0's own without
-            // the wait: see grid_barrier.)
-            unsigned long long *nx = part + uint64_t((acc_slot + 1) % 3) * 8 * (maxn + 1) * 2;
-            if (wave == 0) {
-                unsigned long long seen = 0;  // (exchanges whose results are consumed: PERFORMED, not merely issued)
-                for (uint32_t i = lane; i < 8u * (n + 1) * 2u; i += 64) {
-                    const uint32_t g = i / ((n + 1) * 2u), w = i % ((n + 1) * 2u);
-                    seen |= __hip_atomic_exchange(nx + (uint64_t(g) * (maxn + 1)) * 2 + w, 0ull, RLX_AGENT);
-                }
-                asm volatile("" ::"v"(seen) : "memory");
-            }
         }
         // ================= leave-one-out (get_lowest_record_index, records.rs:220-252, with
         // updated_mean_freqs :276-286) as (n + 1) * K jobs over the workgroups.  A job's two sums
@@ -2258,7 +2276,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 small_job(r, part_i, r, n, th, ts);
                 if (tid < 8) {  // lane g adds the job's words to group g's replica
                     unsigned long long *dst = acc_all + (uint64_t(tid) * (maxn + 1) + r) * 2;
-                    p_acc_add(dst, th, ts, n >= 64);
+                    p_acc_add(dst, th, ts);
                 }
                 first_job = false;
                 continue;
@@ -2367,7 +2385,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     ts += scratch[80 + w];
                 }
                 unsigned long long *dst = acc_all + (uint64_t(tid) * (maxn + 1) + r) * 2;
-                p_acc_add(dst, th, ts, n >= 64);
+                p_acc_add(dst, th, ts);
             }
         }
         st.cursor = p + 1;
@@ -2489,9 +2507,10 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             // acknowledged before their workgroups arrived)
             if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
             P_STAMP(4);
+            bool acc_ok = true;
             for (uint32_t r = tid; r <= n; r += P_THREADS) {
-                const double h = p_acc_value(__hip_atomic_load(acc + uint64_t(r) * 2, RLX_AGENT));
-                const double sv = p_acc_value(__hip_atomic_load(acc + uint64_t(r) * 2 + 1, RLX_AGENT));
+                const double h = p_acc_value(p_acc_complete(acc + uint64_t(r) * 2, K, acc_ok));
+                const double sv = p_acc_value(p_acc_complete(acc + uint64_t(r) * 2 + 1, K, acc_ok));
                 if (r == n) {
                     scratch[110] = h;
                     scratch[111] = sv;
@@ -2500,7 +2519,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     s_ds[r] = sv;
                 }
             }
-            __syncthreads();
+            if (__syncthreads_or(acc_ok ? 0 : 1)) { exit_status = SEL_ERROR; break; }
             P_STAMP(6);
             const double hm = scratch[110];
             st.total_jsd = hm - st.sumH / dn;
