@@ -510,7 +510,7 @@ __device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const 
                 if (tid == 0) nread++;
                 if (!(jf0 > thr_c_lo)) continue;
                 if (jf0 > thr_c_hi) {
-                    if (tid == 0) p_post_event_thread(evs, p, true);
+                    if (tid < 8) p_post_event_wave(evs, p, true, tid);  // (eight lanes, one instruction: every thread knows the score)
                     continue;
                 }
                 if (tid == 0) {
@@ -570,11 +570,12 @@ __device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const 
             neg += slot[8 + w];
         }
         const double jf = hf - (he_base + hrow) / dn;
+        // (a sure event goes out from eight lanes in one instruction: every thread knows the score)
+        if (tid < 8 && neg == 0.0 && jf > thr_fast && jf > thr_sure) p_post_event_wave(evs, p, true, tid);
         if (tid == 0) {
             nread++;
             if (neg == 0.0 && jf > thr_fast) {
                 if (jf > thr_sure) {
-                    p_post_event_thread(evs, p, true);
                 } else {
                     nprecise++;
                     const unsigned long long idx = atomicAdd(softp, 1ull);
@@ -675,7 +676,7 @@ __device__ __forceinline__ void p_scan_rows_wg_stream(const T *__restrict__ mat,
         if (tid == 0) nread++;
         if (!(jf0 > thr_c_lo)) return true;  // (NaN: a negative bin, rejected as the reference does)
         if (jf0 > thr_c_hi) {
-            if (tid == 0) p_post_event_thread(evs, p, true);
+            if (tid < 8) p_post_event_wave(evs, p, true, tid);  // (eight lanes, one instruction: every thread knows the score)
             return true;
         }
         if (tid == 0) {
