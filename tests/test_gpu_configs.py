@@ -477,6 +477,23 @@ def test_a_repeated_selection_gives_the_same_answer_every_time(ctx, k, nseq, n, 
     assert len(seen) == 1, sorted((v, k_[:5]) for k_, v in seen.items())
 
 
+@pytest.mark.parametrize("k", [6, 7])
+def test_a_repeated_max_selection_gives_the_same_answer_every_time(ctx, k):
+    """the same for `max` over a stream of back-to-back events: the persistent engine's batches (k = 6) and
+    the multi-launch kernels' (k = 7) hand their jobs' results over behind one rendezvous / between two launches"""
+    seqs, offs = synth_device(900, 20_000, 30_000, 20260450 + k, composition=True)
+    seen = {}
+    for i in range(120):
+        m = ctx.build_matrix_device(seqs.data_ptr(), offs, k, 4)
+        sel = m.max_divergent(40, 900, "stdev")
+        s, mem = sel.summary(), sel.members(False)
+        key = (s.size, s.n_accepts, s.n_arbitrated, s.n_events, repr(s.total_jsd), mem.positions.tobytes())
+        seen[key] = seen.get(key, 0) + 1
+        sel.close()
+        m.close()
+    assert len(seen) == 1, sorted((v, k_[:5]) for k_, v in seen.items())
+
+
 # ---------------------------------------------------------------- head phase (CU split)
 def _device_build(ctx, seqs, k):
     import torch
