@@ -7,7 +7,7 @@ import sys
 c = sqlite3.connect(sys.argv[1])
 ks = c.execute("select name, start, end from kernels order by start").fetchall()
 hist = [k for k in ks if "kmer_hist_kernel" in k[0]]
-t0, t1 = hist[-2][1], hist[-1][1]
+t0, t1 = hist[-4][1], hist[-2][1]  # (two histogram launches per step: head rows, rest)
 cols = [d[1] for d in c.execute("pragma table_info(regions)")]
 rows = c.execute("select name, start, end from regions where start >= ? and start < ? order by start",
                  (t0 - 200000, t1)).fetchall()
