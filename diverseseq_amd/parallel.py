@@ -33,10 +33,13 @@ def chunk_bounds(total_items: int, num_chunks: int) -> list[tuple[int, int]]:
     return [(int(s), int(e)) for s, e in zip(starts, ends)]
 
 
-def gather_winners(rows: np.ndarray, ids: np.ndarray, world: int, device, cap: int):
+def gather_winners(rows: np.ndarray, ids: np.ndarray, world: int, device, cap: int, timing: dict | None = None):
     """all_gather of every rank's member rows (padded to `cap` rows) and their global ids.
     Returns (rows [sum sizes, B], ids [sum sizes]) in rank order, i.e. the list order
-    `apply_app` hands to the merge."""
+    `apply_app` hands to the merge.  timing: {"collective_ms": [...]} gets the two collectives' duration
+    (host clock: this is the host-staged form)."""
+    import time
+
     import torch
     import torch.distributed as dist
 
@@ -50,8 +53,11 @@ def gather_winners(rows: np.ndarray, ids: np.ndarray, world: int, device, cap: i
     t_meta = torch.from_numpy(meta).to(device)
     all_rows = torch.empty((world * cap, B), dtype=torch.float64, device=device)
     all_meta = torch.empty((world * (cap + 1),), dtype=torch.int64, device=device)
+    t0 = time.perf_counter()
     dist.all_gather_into_tensor(all_rows, t_rows)
     dist.all_gather_into_tensor(all_meta, t_meta)
+    if timing is not None:
+        timing.setdefault("collective_ms", []).append((time.perf_counter() - t0) * 1e3)
     all_rows = all_rows.cpu().numpy().reshape(world, cap, B)
     all_meta = all_meta.cpu().numpy().reshape(world, cap + 1)
     out_rows, out_ids = [], []
@@ -63,7 +69,7 @@ def gather_winners(rows: np.ndarray, ids: np.ndarray, world: int, device, cap: i
 
 
 def gather_winners_device(ctx, sel, world: int, device, cap: int, *, shared_stream: bool = False,
-                          buffers: dict | None = None):
+                          buffers: dict | None = None, timing: dict | None = None):
     """The same exchange with no host round trip: the members are gathered on the device
     straight into the all_gather's send buffer.  Returns device tensors (rows [world*cap, B],
     meta [world*cap, 2] = (chunk-local position, valid)); ranks with fewer than `cap` members
@@ -71,7 +77,9 @@ def gather_winners_device(ctx, sel, world: int, device, cap: int, *, shared_stre
 
     shared_stream: the ctx launches on torch's current stream (Context(stream=...)), so the gather
     kernel, the collectives and whatever consumes their output are ordered by the stream alone and
-    nothing here waits on the host.  buffers: a dict the four tensors are kept in between calls."""
+    nothing here waits on the host.  buffers: a dict the four tensors are kept in between calls.
+    timing: {"collective_events": [...]} collects (start, end) device events around the two collectives
+    (no host wait here; `collective_times` turns them into milliseconds afterwards)."""
     import torch
     import torch.distributed as dist
 
@@ -91,11 +99,28 @@ def gather_winners_device(ctx, sel, world: int, device, cap: int, *, shared_stre
     sel.gather_members(t_rows.data_ptr(), t_meta.data_ptr(), cap)
     if not shared_stream:
         ctx.sync()
+    ev = None
+    if timing is not None and len(timing.setdefault("collective_events", [])) < 256:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     dist.all_gather_into_tensor(all_rows, t_rows)
     dist.all_gather_into_tensor(all_meta, t_meta)
+    if ev is not None:
+        ev[1].record()
+        timing["collective_events"].append(ev)
     if not shared_stream:
         torch.cuda.current_stream().synchronize()
     return all_rows, all_meta
+
+
+def collective_times(timing: dict | None):
+    """device events collected by gather_winners_device -> timing["collective_ms"] (waits for them)"""
+    if timing and timing.get("collective_events"):
+        import torch
+
+        torch.cuda.synchronize()
+        timing.setdefault("collective_ms", []).extend(a.elapsed_time(b) for a, b in timing.pop("collective_events"))
+    return timing
 
 
 def _global_ids(all_meta, chunk_starts, cap: int, src_rows=None) -> np.ndarray:
@@ -121,14 +146,15 @@ class _LazyGlobalIds:
 
 
 def merge_nmost(ctx, sel, n: int, rank: int, world: int, chunk_start: int, device,
-                chunk_starts=None, *, shared_stream: bool = False, buffers: dict | None = None):
+                chunk_starts=None, *, shared_stream: bool = False, buffers: dict | None = None,
+                timing: dict | None = None):
     """exchange the winners and run final_nmost on the device; returns the merged Selection
     (its member positions index the gathered row list; `merged.global_ids` maps them to
     global stream positions).  With `chunk_starts` (every rank's chunk start) on a GPU the
     rows never leave HBM."""
     if chunk_starts is not None and getattr(device, "type", str(device)) == "cuda":
         all_rows, all_meta = gather_winners_device(ctx, sel, world, device, cap=n, shared_stream=shared_stream,
-                                                   buffers=buffers)
+                                                   buffers=buffers, timing=timing)
         m = ctx.matrix_from_device_freqs(all_rows.data_ptr(), world * n, sel.matrix.nbins,
                                          all_meta.data_ptr())
         merged = m.nmost(n)
@@ -137,7 +163,7 @@ def merge_nmost(ctx, sel, n: int, rank: int, world: int, chunk_start: int, devic
         return merged
     mem = sel.members(with_freqs=True)
     ids = mem.positions.astype(np.int64) + chunk_start
-    rows, gids = gather_winners(mem.kfreqs, ids, world, device, cap=n)
+    rows, gids = gather_winners(mem.kfreqs, ids, world, device, cap=n, timing=timing)
     m = ctx.matrix_from_freqs(rows)
     merged = m.nmost(n)  # ids are unique across chunks: identity labels
     merged.global_ids = gids

@@ -148,56 +148,7 @@ def test_sharded_mash_distances_world2():
 
 
 # ----------------------------------------------------------------------------- exact mode
-class _OracleStepper:
-    """the per-rank compute of the exact mode stated with the oracle: scan this rank's rows of the
-    window against the replicated set, pack the first local event, apply the gathered winner"""
-
-    def __init__(self, seqs, owned, mode, n_seed, k, window, max_size=0, stat="stdev"):
-        import oracle
-
-        self.o, self.seqs, self.k, self.window = oracle, seqs, k, window
-        self.mode, self.max_size, self.stat = mode, min(max_size, len(seqs)), stat
-        self.owned = set(int(p) for p in owned)
-        self.set = oracle.SummedRecords.from_seqs(seqs[:n_seed], k, 4, labels=np.arange(n_seed, dtype=np.uint32))
-        self.cursor, self.npos, self.B = n_seed, len(seqs), 4 ** k
-
-    def pack(self):
-        import torch
-
-        slot = np.zeros(self.B + 2)
-        slot[0] = -1.0
-        for p in range(self.cursor, min(self.cursor + self.window, self.npos)):
-            if p not in self.owned or self.seqs[p].size < self.k:
-                continue
-            f, h = self.o.to_kfreqs(self.seqs[p], 4, self.k)
-            if self.set.increases_jsd(f, h, p):
-                slot[0], slot[1], slot[2:] = p, h, f
-                break
-        return torch.from_numpy(slot)
-
-    def _stat(self, s):
-        return s.std_delta_jsd if self.stat == "stdev" else s.cov_delta_jsd
-
-    def apply(self, all_slots, world):
-        a = all_slots.numpy().reshape(world, -1)
-        live = [r for r in range(world) if a[r, 0] >= 0]
-        if not live:
-            self.cursor = min(self.cursor + self.window, self.npos)
-            return
-        r = min(live, key=lambda i: a[i, 0])
-        p, h, f = int(a[r, 0]), float(a[r, 1]), a[r, 2:].copy()
-        if self.mode == "nmost" or self.set.size >= self.max_size:
-            self.set.replace_lowest(f, h, p)
-        else:  # records.rs:427-451: clone + push, kept iff the statistic rose
-            lab, _, ent, fr = self.set.members(with_freqs=True)
-            grown = self.o.SummedRecords.new(np.vstack([fr, f[None]]), np.append(ent, h),
-                                             np.append(lab, p).astype(np.uint32))
-            if self._stat(grown) > self._stat(self.set):
-                self.set = grown
-        self.cursor = p + 1
-
-    def done(self):
-        return self.cursor >= self.npos
+from bench_cpu_engine import OracleStepper as _OracleStepper  # (shared with bench.py's CPU test hook)
 
 
 def _exact_cpu_worker(rank, world, port, q):
