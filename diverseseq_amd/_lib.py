@@ -39,6 +39,9 @@ EXPORTS = (
     "dvs_default_alphabet_lut", "dvs_seqbatch_from_fasta", "dvs_seqbatch_destroy", "dvs_seqbatch_info",
     "dvs_seqbatch_offsets", "dvs_seqbatch_header_positions", "dvs_seqbatch_dev_codes", "dvs_seqbatch_get_codes",
     "dvs_matrix_build_from_seqbatch",
+    "dvs_pack_sequences", "dvs_packed_destroy", "dvs_packed_info", "dvs_packed_dev_codes", "dvs_packed_dev_mask",
+    "dvs_packed_get", "dvs_matrix_build_packed", "dvs_sketches_build_packed", "dvs_seqbatch_pack",
+    "dvs_seqbatch_packed", "dvs_sketches_build_from_seqbatch",
 )
 
 
@@ -183,7 +186,21 @@ def load() -> C.CDLL:
         L.dvs_seqbatch_dev_codes.restype = vp
         L.dvs_seqbatch_get_codes.argtypes = [vp, vp, u8p]
         L.dvs_matrix_build_from_seqbatch.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
-        if L.dvs_abi_version() != 2:
+        L.dvs_pack_sequences.argtypes = [vp, vp, C.c_int, C.c_uint64, C.POINTER(vp)]
+        L.dvs_packed_destroy.argtypes = [vp]
+        L.dvs_packed_destroy.restype = None
+        L.dvs_packed_info.argtypes = [vp, u64p, u64p]
+        for n in ("dvs_packed_dev_codes", "dvs_packed_dev_mask", "dvs_seqbatch_packed"):
+            getattr(L, n).argtypes = [vp]
+            getattr(L, n).restype = vp
+        L.dvs_packed_get.argtypes = [vp, vp, u32p, C.POINTER(C.c_uint16)]
+        L.dvs_matrix_build_packed.argtypes = [vp, vp, u64p, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+        L.dvs_sketches_build_packed.argtypes = [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                                C.POINTER(vp)]
+        L.dvs_seqbatch_pack.argtypes = [vp, vp]
+        L.dvs_sketches_build_from_seqbatch.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                                       C.POINTER(vp)]
+        if L.dvs_abi_version() != 3:
             raise RuntimeError("libdvs_hip.so ABI version mismatch")
         _lib = L
         return _lib

@@ -7,13 +7,10 @@
 
 uint64_t dvs_pow_u64(uint32_t base, uint32_t exp, bool *overflow);
 void dvs_matrix_free_fields(dvs_matrix *m);
-int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs, uint64_t nbytes,
-                           const uint64_t *offsets, bool no_wait);
+int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const dvs_seq_view &sv, const uint64_t *offsets, bool no_wait);
 int dvs_matrix_fill_freq_entropy(dvs_ctx *ctx, dvs_matrix *m);
 int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint32_t k, uint64_t nbytes, size_t *n_long_out);
 bool dvs_hist_rows_fit_u16(const dvs_ctx *ctx, uint64_t B, size_t n_long);
-bool dvs_packed_upload_wanted(const dvs_ctx *ctx, uint32_t num_states, uint64_t nbytes);  // pack.hip
-int dvs_upload_packed(dvs_ctx *ctx, const uint8_t *seqs, uint64_t nbytes, uint8_t *d_out);
 int dvs_matrix_fill_freq_totals(dvs_ctx *ctx, dvs_matrix *m, const double *d_meta);
 int dvs_matrix_fill_compacted(dvs_ctx *ctx, dvs_matrix *m, const double *d_in, const double *d_meta);
 
@@ -340,11 +337,8 @@ static int matrix_alloc(dvs_ctx *ctx, dvs_matrix *m) {
     return rc;
 }
 
-int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, const uint64_t *offsets,
-                     uint32_t nseq, uint32_t k, uint32_t num_states, dvs_matrix **out) {
-    if (!ctx || !offsets || !out || (!seqs && nseq && offsets[nseq] > 0))
-        return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
-    *out = nullptr;
+// k and num_states of a build: the reference's panics first, then what the device path cannot hold
+static int build_shape(dvs_ctx *ctx, uint32_t k, uint32_t num_states, uint64_t *B_out) {
     if (k == 0) return dvs_set_error(ctx, DVS_ERR_VALUE, "k cannot be 0");  // record.rs:126
     if (num_states < 1 || num_states > 255)
         return dvs_set_error(ctx, DVS_ERR_VALUE, "num_states %u outside 1..255", num_states);
@@ -354,14 +348,22 @@ int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, cons
     if (ovf || B > (1ull << 32))
         return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "%u^%u bins do not fit a dense count row",
                              num_states, k);
-    DVS_HIP(ctx, hipSetDevice(ctx->device));
-    const uint64_t nbytes = nseq ? offsets[nseq] : 0;
-    const uint64_t padded = ((nbytes + 15) & ~15ull) + 16;
-    uint64_t readable = seqs_on_device ? nbytes : padded;
+    *B_out = B;
+    return DVS_OK;
+}
+
+// The build over sequences that are in HBM already, in either form (sv): offsets validated (and the tile
+// lists of genome-length sequences derived), matrix allocated, kernels launched.
+static int matrix_build_view(dvs_ctx *ctx, const dvs_seq_view &sv, const uint64_t *offsets, uint32_t nseq, uint32_t k,
+                             uint32_t num_states, bool no_wait, dvs_matrix **out) {
+    *out = nullptr;
+    uint64_t B = 0;
+    const int arc = build_shape(ctx, k, num_states, &B);
+    if (arc) return arc;
     // the offsets first: whether any sequence needs more than one tile decides the width of the rows
     size_t n_long = 0;
     if (nseq) {
-        const int prc = dvs_hist_prepare(ctx, offsets, nseq, k, readable, &n_long);
+        const int prc = dvs_hist_prepare(ctx, offsets, nseq, k, sv.nbytes, &n_long);
         if (prc) return prc;
     }
     dvs_matrix *m = new dvs_matrix();
@@ -372,55 +374,9 @@ int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, cons
     m->num_states = num_states;
     m->device = ctx->device;
     int rc = matrix_alloc(ctx, m);
-    if (rc) {
-        dvs_matrix_free_fields(m);
-        delete m;
-        return rc;
-    }
-    uint8_t *d_tmp = nullptr;
-    const uint8_t *d_seqs = seqs;
-    if (!seqs_on_device) {
-        rc = dvs_dev_alloc(ctx, (void **)&d_tmp, padded, "sequence upload buffer");
-        if (rc) {
-            dvs_matrix_free_fields(m);
-            delete m;
-            return rc;
-        }
-        hipError_t ue = hipMemsetAsync(d_tmp + (nbytes & ~15ull), 0xFF, padded - (nbytes & ~15ull), ctx->stream);
-        if (ue == hipSuccess && nbytes && dvs_packed_upload_wanted(ctx, num_states, nbytes)) {
-            // four-state sequences: 3 bits per base across PCIe, expanded again on the device (pack.hip)
-            rc = dvs_upload_packed(ctx, seqs, nbytes, d_tmp);
-            if (rc) {
-                dvs_dev_free(ctx, d_tmp);
-                dvs_matrix_free_fields(m);
-                delete m;
-                return rc;
-            }
-        } else if (ue == hipSuccess && nbytes) {
-            ue = hipMemcpyAsync(d_tmp, seqs, nbytes, hipMemcpyHostToDevice, ctx->stream);
-        }
-        if (ue != hipSuccess) {  // a failed upload must not become a silently wrong matrix
-            (void)hipStreamSynchronize(ctx->stream);
-            dvs_dev_free(ctx, d_tmp);
-            dvs_matrix_free_fields(m);
-            delete m;
-            return dvs_hip_fail(ctx, ue, "sequence upload");
-        }
-        d_seqs = d_tmp;
-    } else if (reinterpret_cast<uintptr_t>(seqs) & 15) {
-        dvs_matrix_free_fields(m);
-        delete m;
-        return dvs_set_error(ctx, DVS_ERR_VALUE, "device sequence buffer must be 16-byte aligned");
-    }
     // (a device-resident input needs no host wait: the kernels' completion is an event the consumers
     // of the matrix wait on when they need host-side data, dvs_matrix_settle)
-    rc = nseq ? dvs_matrix_fill_counts(ctx, m, d_seqs, readable, offsets,
-                                       seqs_on_device != 0 && !ctx->knobs.build_wait)
-              : DVS_OK;
-    if (d_tmp) {
-        (void)hipStreamSynchronize(ctx->stream);
-        dvs_dev_free(ctx, d_tmp);
-    }
+    if (!rc && nseq) rc = dvs_matrix_fill_counts(ctx, m, sv, offsets, no_wait);
     if (rc) {
         dvs_matrix_free_fields(m);
         delete m;
@@ -428,6 +384,76 @@ int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, cons
     }
     *out = m;
     return DVS_OK;
+}
+
+int dvs_matrix_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, const uint64_t *offsets,
+                     uint32_t nseq, uint32_t k, uint32_t num_states, dvs_matrix **out) {
+    if (!ctx || !offsets || !out || (!seqs && nseq && offsets[nseq] > 0))
+        return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    *out = nullptr;
+    {
+        uint64_t B_ = 0;
+        const int arc = build_shape(ctx, k, num_states, &B_);
+        if (arc) return arc;
+    }
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t nbytes = nseq ? offsets[nseq] : 0;
+    dvs_seq_view sv;
+    if (seqs_on_device) {
+        if (reinterpret_cast<uintptr_t>(seqs) & 15)
+            return dvs_set_error(ctx, DVS_ERR_VALUE, "device sequence buffer must be 16-byte aligned");
+        sv.seqs = seqs;
+        sv.nbytes = nbytes;
+        return matrix_build_view(ctx, sv, offsets, nseq, k, num_states, !ctx->knobs.build_wait, out);
+    }
+    // Host memory.  Four-state sequences cross PCIe packed -- 3 bits per base, packed by host threads
+    // beside the copies -- and the histogram reads the packed words as they are (pack.hip); anything
+    // else is copied as it is.
+    if (nbytes && dvs_packed_upload_wanted(ctx, num_states, nbytes)) {
+        dvs_packed *p = nullptr;
+        int rc = dvs_packed_alloc(ctx, nbytes, &p);
+        if (!rc) rc = dvs_packed_fill_from_host(ctx, p, seqs);
+        if (!rc) {
+            sv.codes = p->d_codes;
+            sv.mask = p->d_mask;
+            sv.nbytes = nbytes;
+            rc = matrix_build_view(ctx, sv, offsets, nseq, k, num_states, false, out);
+        }
+        if (p) {
+            (void)hipStreamSynchronize(ctx->stream);  // (the planes go back to the cache: nothing may still read them)
+            dvs_packed_destroy(p);
+        }
+        return rc;
+    }
+    const uint64_t padded = ((nbytes + 15) & ~15ull) + 16;
+    uint8_t *d_tmp = nullptr;
+    int rc = dvs_dev_alloc(ctx, (void **)&d_tmp, padded, "sequence upload buffer");
+    if (rc) return rc;
+    hipError_t ue = hipMemsetAsync(d_tmp + (nbytes & ~15ull), 0xFF, padded - (nbytes & ~15ull), ctx->stream);
+    if (ue == hipSuccess && nbytes) ue = hipMemcpyAsync(d_tmp, seqs, nbytes, hipMemcpyHostToDevice, ctx->stream);
+    if (ue != hipSuccess) {  // a failed upload must not become a silently wrong matrix
+        (void)hipStreamSynchronize(ctx->stream);
+        dvs_dev_free(ctx, d_tmp);
+        return dvs_hip_fail(ctx, ue, "sequence upload");
+    }
+    sv.seqs = d_tmp;
+    sv.nbytes = padded;
+    rc = matrix_build_view(ctx, sv, offsets, nseq, k, num_states, false, out);
+    (void)hipStreamSynchronize(ctx->stream);
+    dvs_dev_free(ctx, d_tmp);
+    return rc;
+}
+
+int dvs_matrix_build_packed(dvs_ctx *ctx, const dvs_packed *p, const uint64_t *offsets, uint32_t nseq, uint32_t k,
+                            dvs_matrix **out) {
+    if (!ctx || !p || !offsets || !out) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    *out = nullptr;
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    dvs_seq_view sv;
+    sv.codes = p->d_codes;
+    sv.mask = p->d_mask;
+    sv.nbytes = p->nbases;
+    return matrix_build_view(ctx, sv, offsets, nseq, k, 4, !ctx->knobs.build_wait, out);
 }
 
 int dvs_matrix_from_freqs(dvs_ctx *ctx, const double *freqs, uint32_t nrows, uint64_t nbins,

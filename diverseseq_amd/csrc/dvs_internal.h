@@ -182,6 +182,30 @@ struct dvs_matrix {
     dvs_ctx *ctx = nullptr;  // owner of the allocations
 };
 
+// Four-state sequences in HBM at 3 bits per base (pack.hip, pack_host.cpp): positions index the
+// concatenated buffer exactly as in the one-byte form, so a batch's offsets are the same in both.
+//   d_codes[w]: bases 16 w .. 16 w + 15, two bits each, base 16 w in bits 31..30
+//   d_mask[w]:  bit 15 - i set when base 16 w + i is invalid (>= 4, or behind the end of the buffer)
+// nwords = ceil(nbases / 16) words of each plane are valid; the planes are allocated a little longer
+// (a multiple of 16 bytes) so that vector loads near the end stay inside them.
+struct dvs_packed {
+    dvs_ctx *ctx = nullptr;
+    uint32_t *d_codes = nullptr;
+    uint16_t *d_mask = nullptr;
+    uint64_t nbases = 0, nwords = 0;
+};
+// what the kernels take: either the byte form (seqs) or the packed planes
+struct dvs_seq_view {
+    const uint8_t *seqs = nullptr;  // one byte per base ...
+    const uint32_t *codes = nullptr;  // ... or the packed planes (codes != NULL)
+    const uint16_t *mask = nullptr;
+    uint64_t nbytes = 0;  // readable bases
+};
+int dvs_packed_alloc(dvs_ctx *ctx, uint64_t nbases, dvs_packed **out);                       // pack.hip
+int dvs_packed_fill_from_device(dvs_ctx *ctx, dvs_packed *p, const uint8_t *d_seqs);         // bytes in HBM -> planes
+int dvs_packed_fill_from_host(dvs_ctx *ctx, dvs_packed *p, const uint8_t *seqs);             // host threads pack, chunks cross PCIe packed
+bool dvs_packed_upload_wanted(const dvs_ctx *ctx, uint32_t num_states, uint64_t nbytes);
+
 // f(typed row pointer) for the matrix's element type
 template <typename F>
 auto dvs_mat_dispatch(const dvs_matrix *m, F &&f) {
@@ -192,6 +216,27 @@ auto dvs_mat_dispatch(const dvs_matrix *m, F &&f) {
 
 // ---- device helpers -------------------------------------------------------
 #ifdef __HIPCC__
+// 4 bases (little-endian bytes, earliest base in the low byte) -> 8 bits, the earliest base in the TOP two bits
+__device__ __forceinline__ uint32_t dvs_pack4(uint32_t w) {
+    const uint32_t x = w & 0x03030303u;
+    return ((x << 6) | (x >> 4) | (x >> 14) | (x >> 24)) & 0xFFu;
+}
+// 4 bases -> 4 bits, bit set where the byte is >= 4, earliest base in bit 3
+__device__ __forceinline__ uint32_t dvs_inv4(uint32_t w) {
+    uint32_t t = w & 0xFCFCFCFCu;
+    t |= t >> 4;
+    t |= t >> 2;
+    t |= t >> 1;
+    t &= 0x01010101u;
+    return ((t << 3) | (t >> 6) | (t >> 15) | (t >> 24)) & 0xFu;
+}
+// 16 bases -> a code word / a mask word of the packed form (dvs_packed)
+__device__ __forceinline__ uint32_t dvs_pack16(uint4 v) {
+    return (dvs_pack4(v.x) << 24) | (dvs_pack4(v.y) << 16) | (dvs_pack4(v.z) << 8) | dvs_pack4(v.w);
+}
+__device__ __forceinline__ uint32_t dvs_inv16(uint4 v) {
+    return (dvs_inv4(v.x) << 12) | (dvs_inv4(v.y) << 8) | (dvs_inv4(v.z) << 4) | dvs_inv4(v.w);
+}
 __device__ __forceinline__ double dvs_wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -276,10 +276,12 @@ struct dvs_seqbatch {
     uint32_t nseq = 0;
     std::vector<uint64_t> offsets;     // nseq + 1
     std::vector<uint64_t> header_pos;  // file offset of the '>' of every record of the file
+    dvs_packed *packed = nullptr;      // after dvs_seqbatch_pack: the bases at 3 bits each (d_codes released)
 };
 
 extern "C" void dvs_seqbatch_destroy(dvs_seqbatch *b) {
     if (!b) return;
+    if (b->packed) dvs_packed_destroy(b->packed);
     if (b->d_codes) dvs_dev_free(b->ctx, b->d_codes);
     dvs_ctx_release(b->ctx);
     delete b;
@@ -485,12 +487,54 @@ extern "C" int dvs_seqbatch_header_positions(const dvs_seqbatch *b, uint64_t *po
 extern "C" const void *dvs_seqbatch_dev_codes(const dvs_seqbatch *b) { return b ? b->d_codes : nullptr; }
 extern "C" int dvs_seqbatch_get_codes(dvs_ctx *ctx, const dvs_seqbatch *b, uint8_t *codes_out) {
     if (!ctx || !b || (!codes_out && b->total)) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (b->packed) {  // the planes, expanded on the host: code & 3, or 255 where the mask says invalid
+        std::vector<uint32_t> codes(b->packed->nwords);
+        std::vector<uint16_t> mask(b->packed->nwords);
+        const int rc = dvs_packed_get(ctx, b->packed, codes.data(), mask.data());
+        if (rc) return rc;
+        for (uint64_t i = 0; i < b->total; i++) {
+            const uint32_t sh = uint32_t(i & 15);
+            codes_out[i] = ((mask[i >> 4] >> (15 - sh)) & 1u) ? 255 : uint8_t((codes[i >> 4] >> (30 - 2 * sh)) & 3u);
+        }
+        return DVS_OK;
+    }
     DVS_HIP(ctx, hipMemcpyAsync(codes_out, b->d_codes, b->total, hipMemcpyDeviceToHost, ctx->stream));
     DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return DVS_OK;
 }
+extern "C" int dvs_seqbatch_pack(dvs_ctx *ctx, dvs_seqbatch *b) {
+    if (!ctx || !b) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (b->packed) return DVS_OK;
+    dvs_packed *p = nullptr;
+    int rc = dvs_packed_alloc(ctx, b->total, &p);
+    if (!rc) rc = dvs_packed_fill_from_device(ctx, p, b->d_codes);
+    if (rc) {
+        if (p) dvs_packed_destroy(p);
+        return rc;
+    }
+    b->packed = p;
+    dvs_dev_free(b->ctx, b->d_codes);  // (back to the cache: stream order protects it until the kernel has run)
+    b->d_codes = nullptr;
+    return DVS_OK;
+}
+extern "C" const dvs_packed *dvs_seqbatch_packed(const dvs_seqbatch *b) { return b ? b->packed : nullptr; }
 extern "C" int dvs_matrix_build_from_seqbatch(dvs_ctx *ctx, const dvs_seqbatch *b, uint32_t k, uint32_t num_states,
                                               dvs_matrix **out) {
     if (!ctx || !b || !out) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (b->packed) {
+        if (num_states != 4)
+            return dvs_set_error(ctx, DVS_ERR_VALUE, "a packed batch holds four-state sequences, not %u states", num_states);
+        return dvs_matrix_build_packed(ctx, b->packed, b->offsets.data(), b->nseq, k, out);
+    }
     return dvs_matrix_build(ctx, b->d_codes, 1, b->offsets.data(), b->nseq, k, num_states, out);
+}
+extern "C" int dvs_sketches_build_from_seqbatch(dvs_ctx *ctx, const dvs_seqbatch *b, uint32_t k, uint32_t sketch_size,
+                                                uint32_t num_states, int mash_canonical, dvs_sketches **out) {
+    if (!ctx || !b || !out) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (b->packed) {
+        if (num_states != 4)
+            return dvs_set_error(ctx, DVS_ERR_VALUE, "a packed batch holds four-state sequences, not %u states", num_states);
+        return dvs_sketches_build_packed(ctx, b->packed, b->offsets.data(), b->nseq, k, sketch_size, mash_canonical, out);
+    }
+    return dvs_sketches_build(ctx, b->d_codes, 1, b->offsets.data(), b->nseq, k, sketch_size, num_states, mash_canonical, out);
 }

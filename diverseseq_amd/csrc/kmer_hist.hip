@@ -59,28 +59,6 @@ __device__ __forceinline__ uint4 load16(const uint8_t *base, uint64_t off, uint6
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// 4 bases (little-endian bytes, earliest base in the low byte) -> 8 bits, the
-// earliest base in the TOP two bits.
-__device__ __forceinline__ uint32_t pack4(uint32_t w) {
-    const uint32_t x = w & 0x03030303u;
-    return ((x << 6) | (x >> 4) | (x >> 14) | (x >> 24)) & 0xFFu;
-}
-// 4 bases -> 4 bits, bit set where the byte is >= 4, earliest base in bit 3.
-__device__ __forceinline__ uint32_t inv4(uint32_t w) {
-    uint32_t t = w & 0xFCFCFCFCu;
-    t |= t >> 4;
-    t |= t >> 2;
-    t |= t >> 1;
-    t &= 0x01010101u;
-    return ((t << 3) | (t >> 6) | (t >> 15) | (t >> 24)) & 0xFu;
-}
-__device__ __forceinline__ uint32_t pack16(uint4 v) {
-    return (pack4(v.x) << 24) | (pack4(v.y) << 16) | (pack4(v.z) << 8) | pack4(v.w);
-}
-__device__ __forceinline__ uint32_t inv16(uint4 v) {
-    return (inv4(v.x) << 12) | (inv4(v.y) << 8) | (inv4(v.z) << 4) | inv4(v.w);
-}
-
 // PK16: two 16-bit counters to a word (a tile holds at most TILE_LEN = 32768 windows, so the low
 // half never carries into the high one): half the LDS, twice the workgroups a CU can hold
 template <bool LDS_HIST, bool PK16 = false>
@@ -102,9 +80,14 @@ __device__ __forceinline__ double clog2c(uint32_t c, const double *tbl) {
 // flush emulates the 256-thread partition of the bins -- thread t stands for threads t and t + 128
 // -- so that the row entropy has the same bits as from the unpacked kernel.
 // OUT16 (PK16 only): the row leaves as 16-bit counts, the packed LDS words as they are (matrix kind 2)
-template <bool NS4, bool LDS_HIST, bool PK16 = false, bool OUT16 = false>
+// PACKED (NS4 only): the sequences are the two planes of the packed form (dvs_packed: `seqs` points at the
+// code words, `pmask` at the mask words) -- a lane's 16 bases are one 4-byte and one 2-byte load, and
+// the 2-bit pack and the invalid mask the byte form has to work out (pack16 / inv16: ~60 of the loop's
+// vector instructions per 16 bases) are simply what was loaded.
+template <bool NS4, bool LDS_HIST, bool PK16 = false, bool OUT16 = false, bool PACKED = false>
 __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
-    const uint8_t *__restrict__ seqs, uint64_t nbytes, const uint64_t *__restrict__ offsets,
+    const uint8_t *__restrict__ seqs, const uint16_t *__restrict__ pmask, uint64_t nbytes,
+    const uint64_t *__restrict__ offsets,
     const KTile *__restrict__ tiles, uint32_t *__restrict__ counts, uint32_t *__restrict__ totals,
     double *__restrict__ entropy, const double *__restrict__ clog_tbl, uint32_t k, uint32_t ns,
     uint64_t B, uint32_t hot_rows, uint32_t row0, uint64_t uni_base, uint64_t uni_stride) {
@@ -128,6 +111,7 @@ __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
         if (s1 - s0 < k) t.begin = t.end = s1;               // windows(k) empty: all-zero row
     }
     static_assert(!OUT16 || PK16, "16-bit rows come from the packed histogram");
+    static_assert(!PACKED || NS4, "only four-state sequences have a packed form");
     uint32_t *row = OUT16 ? counts + uint64_t(t.row) * (B / 2) : counts + uint64_t(t.row) * B;
     uint32_t *hist = LDS_HIST ? reinterpret_cast<uint32_t *>(smem) : row;
     double *tbl = reinterpret_cast<double *>(smem + (LDS_HIST ? ((B * (PK16 ? 2 : 4) + 15) & ~15ull) : 0));
@@ -167,20 +151,30 @@ __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
         if (c_lo < c_hi) {  // the chunk in front of the wave's first one (uniform address)
             const uint64_t A0 = abase + (c_lo << 4);
             if (A0 >= 16) {
-                const uint4 pv = load16(seqs, A0 - 16, nbytes);
-                carryP = pack16(pv);
-                carryI = inv16(pv);
+                if constexpr (PACKED) {
+                    carryP = reinterpret_cast<const uint32_t *>(seqs)[(A0 >> 4) - 1];
+                    carryI = pmask[(A0 >> 4) - 1];
+                } else {
+                    const uint4 pv = load16(seqs, A0 - 16, nbytes);
+                    carryP = dvs_pack16(pv);
+                    carryI = dvs_inv16(pv);
+                }
             }
         }
         for (uint64_t c0 = c_lo; c0 < c_hi; c0 += 64) {
             const uint64_t c = c0 + lane;
             const bool live = c < c_hi;
             const uint64_t A = abase + ((live ? c : c_hi - 1) << 4);
-            const uint4 cur = load16(seqs, A, nbytes);
-            const uint32_t Pc = pack16(cur);
-            uint32_t Ic = 0;
-            const uint32_t hib = (cur.x | cur.y | cur.z | cur.w) & 0xFCFCFCFCu;
-            if (__ballot(hib != 0)) Ic = inv16(cur);  // (wave-uniform branch)
+            uint32_t Pc, Ic = 0;
+            if constexpr (PACKED) {  // (A < t.end <= nbytes: word A / 16 exists; positions behind nbytes are flagged in it)
+                Pc = reinterpret_cast<const uint32_t *>(seqs)[A >> 4];
+                Ic = pmask[A >> 4];
+            } else {
+                const uint4 cur = load16(seqs, A, nbytes);
+                Pc = dvs_pack16(cur);
+                const uint32_t hib = (cur.x | cur.y | cur.z | cur.w) & 0xFCFCFCFCu;
+                if (__ballot(hib != 0)) Ic = dvs_inv16(cur);  // (wave-uniform branch)
+            }
             // the neighbour's pack / mask: lane l <- lane l - 1, lane 0 <- the carry
             const uint32_t Pp = uint32_t(__builtin_amdgcn_update_dpp(int(carryP), int(Pc), 0x138, 0xF, 0xF, false));
             const uint32_t Ip = uint32_t(__builtin_amdgcn_update_dpp(int(carryI), int(Ic), 0x138, 0xF, 0xF, false));
@@ -637,9 +631,15 @@ bool dvs_hist_rows_fit_u16(const dvs_ctx *ctx, uint64_t B, size_t n_long) {
 // readable) into an allocated matrix, after dvs_hist_prepare for the same offsets.  One launch gives
 // every sequence that fits a single tile its own workgroup (tile derived from the offsets on the
 // device); genome-length sequences get an explicit tile list and a second launch.
-int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
-                           uint64_t nbytes, const uint64_t *offsets, bool no_wait) {
+int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const dvs_seq_view &sv, const uint64_t *offsets,
+                           bool no_wait) {
+    // (packed: the kernel's `seqs` argument carries the code words, `pmask` the mask words)
+    const bool packed = sv.codes != nullptr;
+    const uint8_t *d_seqs = packed ? reinterpret_cast<const uint8_t *>(sv.codes) : sv.seqs;
+    const uint16_t *d_pmask = sv.mask;
+    const uint64_t nbytes = sv.nbytes;
     const uint32_t nseq = m->nrows, k = m->k, ns = m->num_states;
+    if (packed && ns != 4) return dvs_set_error(ctx, DVS_ERR_VALUE, "packed sequences have four states, not %u", ns);
     const uint64_t B = m->nbins;
     const bool lds_hist = B * 4 <= 64 * 1024;
     const bool ns4 = ns == 4;
@@ -673,20 +673,22 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
     if (ctx->knobs.hist_threads) nthreads = ctx->knobs.hist_threads;
     if (ctx->knobs.hist_tile_threads) tile_threads = ctx->knobs.hist_tile_threads;
     const size_t lds = (lds_hist ? ((B * 4 + 15) & ~15ull) : 0) + (CLOG_TBL + 32) * sizeof(double);
-#define DVS_LAUNCH_HIST(NS4, LH, GRID, TILES, NTHR, HOT)                                                  \
+#define DVS_LAUNCH_HIST(NS4, LH, PKD, GRID, TILES, NTHR, HOT)                                             \
     do {                                                                                         \
-        rc = set_dyn_lds(ctx, kmer_hist_kernel<NS4, LH, false>, lds);                            \
+        rc = set_dyn_lds(ctx, kmer_hist_kernel<NS4, LH, false, false, PKD>, lds);                \
         if (!rc)                                                                                 \
-            hipLaunchKernelGGL((kmer_hist_kernel<NS4, LH, false>), dim3(GRID), dim3(NTHR), lds,  \
-                               ctx->stream, d_seqs, nbytes, d_off, TILES, m->d_counts,           \
+            hipLaunchKernelGGL((kmer_hist_kernel<NS4, LH, false, false, PKD>), dim3(GRID), dim3(NTHR), lds,  \
+                               ctx->stream, d_seqs, d_pmask, nbytes, d_off, TILES, m->d_counts,  \
                                m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, HOT, 0u, uni_base, uni_stride);   \
     } while (0)
 #define DVS_LAUNCH_HIST_ANY(GRID, TILES, NTHR, HOT)                            \
     do {                                                                  \
-        if (ns4 && lds_hist) DVS_LAUNCH_HIST(true, true, GRID, TILES, NTHR, HOT);   \
-        else if (ns4) DVS_LAUNCH_HIST(true, false, GRID, TILES, NTHR, HOT);         \
-        else if (lds_hist) DVS_LAUNCH_HIST(false, true, GRID, TILES, NTHR, HOT);    \
-        else DVS_LAUNCH_HIST(false, false, GRID, TILES, NTHR, HOT);                 \
+        if (packed && lds_hist) DVS_LAUNCH_HIST(true, true, true, GRID, TILES, NTHR, HOT);   \
+        else if (packed) DVS_LAUNCH_HIST(true, false, true, GRID, TILES, NTHR, HOT);         \
+        else if (ns4 && lds_hist) DVS_LAUNCH_HIST(true, true, false, GRID, TILES, NTHR, HOT);   \
+        else if (ns4) DVS_LAUNCH_HIST(true, false, false, GRID, TILES, NTHR, HOT);         \
+        else if (lds_hist) DVS_LAUNCH_HIST(false, true, false, GRID, TILES, NTHR, HOT);    \
+        else DVS_LAUNCH_HIST(false, false, false, GRID, TILES, NTHR, HOT);                 \
     } while (0)
     // The rows a selection reads first (its event-dense head is bound by fetch latency) are built
     // last and with ordinary stores, so that they are what the 256 MB memory-side cache still holds
@@ -712,17 +714,23 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
         const size_t lds16 = ((B * 2 + 15) & ~15ull) + (CLOG_TBL + 32) * sizeof(double);
         uint32_t *out16 = reinterpret_cast<uint32_t *>(m->d_counts16);
         auto launch16 = [&](uint32_t row0, uint32_t count, uint32_t hot_end, hipStream_t on) {
-            if (ns4) {
+            if (packed) {
+                rc = set_dyn_lds(ctx, kmer_hist_kernel<true, true, true, true, true>, lds16);
+                if (!rc)
+                    hipLaunchKernelGGL((kmer_hist_kernel<true, true, true, true, true>), dim3(count), dim3(128), lds16, on,
+                                       d_seqs, d_pmask, nbytes, d_off, static_cast<const KTile *>(nullptr), out16,
+                                       m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_end, row0, uni_base, uni_stride);
+            } else if (ns4) {
                 rc = set_dyn_lds(ctx, kmer_hist_kernel<true, true, true, true>, lds16);
                 if (!rc)
                     hipLaunchKernelGGL((kmer_hist_kernel<true, true, true, true>), dim3(count), dim3(128), lds16, on,
-                                       d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), out16,
+                                       d_seqs, d_pmask, nbytes, d_off, static_cast<const KTile *>(nullptr), out16,
                                        m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_end, row0, uni_base, uni_stride);
             } else {
                 rc = set_dyn_lds(ctx, kmer_hist_kernel<false, true, true, true>, lds16);
                 if (!rc)
                     hipLaunchKernelGGL((kmer_hist_kernel<false, true, true, true>), dim3(count), dim3(128), lds16, on,
-                                       d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), out16,
+                                       d_seqs, d_pmask, nbytes, d_off, static_cast<const KTile *>(nullptr), out16,
                                        m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_end, row0, uni_base, uni_stride);
             }
         };
@@ -780,17 +788,23 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const uint8_t *d_seqs,
         }
     } else if (pk16) {
         const size_t lds16 = ((B * 2 + 15) & ~15ull) + (CLOG_TBL + 32) * sizeof(double);
-        if (ns4) {
+        if (packed) {
+            rc = set_dyn_lds(ctx, kmer_hist_kernel<true, true, true, false, true>, lds16);
+            if (!rc)
+                hipLaunchKernelGGL((kmer_hist_kernel<true, true, true, false, true>), dim3(nseq), dim3(128), lds16, ctx->stream,
+                                   d_seqs, d_pmask, nbytes, d_off, static_cast<const KTile *>(nullptr), m->d_counts,
+                                   m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_rows, 0u, uni_base, uni_stride);
+        } else if (ns4) {
             rc = set_dyn_lds(ctx, kmer_hist_kernel<true, true, true>, lds16);
             if (!rc)
                 hipLaunchKernelGGL((kmer_hist_kernel<true, true, true>), dim3(nseq), dim3(128), lds16, ctx->stream,
-                                   d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), m->d_counts,
+                                   d_seqs, d_pmask, nbytes, d_off, static_cast<const KTile *>(nullptr), m->d_counts,
                                    m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_rows, 0u, uni_base, uni_stride);
         } else {
             rc = set_dyn_lds(ctx, kmer_hist_kernel<false, true, true>, lds16);
             if (!rc)
                 hipLaunchKernelGGL((kmer_hist_kernel<false, true, true>), dim3(nseq), dim3(128), lds16, ctx->stream,
-                                   d_seqs, nbytes, d_off, static_cast<const KTile *>(nullptr), m->d_counts,
+                                   d_seqs, d_pmask, nbytes, d_off, static_cast<const KTile *>(nullptr), m->d_counts,
                                    m->d_totals, m->d_entropy, ctx->d_clog_tbl, k, ns, B, hot_rows, 0u, uni_base, uni_stride);
         }
     } else

@@ -151,18 +151,6 @@ __global__ __launch_bounds__(MASH_THREADS) void hash_filter_kernel(
 // 32-bit multiply left: v * 0xCC9E2D51 -> rotl 15 -> * 0x1B873593 takes four values for v in 0..3
 // (selected, not computed) and h * 5 + c is a shift-add.  (v_mul_lo_u32 runs at a quarter of the
 // rate of the other integer instructions; the byte-wise kernel spends three per base.)
-__device__ __forceinline__ uint32_t mash_pack4(uint32_t w) {  // 4 bases -> 8 bits, earliest in the top pair
-    const uint32_t x = w & 0x03030303u;
-    return ((x << 6) | (x >> 4) | (x >> 14) | (x >> 24)) & 0xFFu;
-}
-__device__ __forceinline__ uint32_t mash_inv4(uint32_t w) {  // 4 bases -> 4 bits, set where the byte is >= 4
-    uint32_t t = w & 0xFCFCFCFCu;
-    t |= t >> 4;
-    t |= t >> 2;
-    t |= t >> 1;
-    t &= 0x01010101u;
-    return ((t << 3) | (t >> 6) | (t >> 15) | (t >> 24)) & 0xFu;
-}
 constexpr uint32_t mash_round_const(uint32_t v) {
     uint32_t k = v * 0xCC9E2D51u;
     k = (k << 15) | (k >> 17);
@@ -192,9 +180,12 @@ __device__ __forceinline__ uint32_t mash_round_k(uint32_t h, uint32_t kk) {  // 
 // TBLW: words of the tile's hash set.  The full 2 x MASH_TILE (64 KB) leaves room for two workgroups
 // per CU; when the hash range lets only a few windows per tile through (genomes: ~0.2 %), 2048 words
 // do and the CU holds eight workgroups, which hides the serial chain of the rounds much better.
-template <bool K16, uint32_t TBLW>  // K16: k <= 16, a window fits 32 bits
+// PACKED: the sequences are the planes of the packed form (dvs_packed: `seqs` points at the code words,
+// `pmask` at the mask words), whose words are this kernel's LDS words: staging a tile is two loads per 16 bases.
+template <bool K16, uint32_t TBLW, bool PACKED = false>  // K16: k <= 16, a window fits 32 bits
 __global__ __launch_bounds__(MASH_THREADS) void hash_filter_dna_kernel(
-    const uint8_t *__restrict__ seqs, uint64_t nbytes_all, const MTile *__restrict__ tiles, uint32_t k,
+    const uint8_t *__restrict__ seqs, const uint16_t *__restrict__ pmask, uint64_t nbytes_all,
+    const MTile *__restrict__ tiles, uint32_t k,
     int canonical, const long long *__restrict__ lo, const uint32_t *__restrict__ hi,
     const uint8_t *__restrict__ active, uint32_t *__restrict__ cand,
     const uint64_t *__restrict__ cand_off, const uint32_t *__restrict__ cand_cap,
@@ -214,6 +205,13 @@ __global__ __launch_bounds__(MASH_THREADS) void hash_filter_dna_kernel(
     const uint32_t nwords = uint32_t((t.begin - base_al + nbytes + 15) >> 4);
     for (uint32_t j = threadIdx.x; j < nwords + 3; j += MASH_THREADS) {
         const uint64_t a = base_al + uint64_t(j) * 16;
+        if constexpr (PACKED) {
+            uint2 w = make_uint2(0u, 0xFFFFu);  // invalid filler
+            if (j < nwords && a < nbytes_all)   // (positions behind the end are flagged inside the last word)
+                w = make_uint2(reinterpret_cast<const uint32_t *>(seqs)[a >> 4], pmask[a >> 4]);
+            pk[j] = w;
+            continue;
+        }
         uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);  // invalid filler
         if (j < nwords) {
             if (a + 16 <= nbytes_all) {
@@ -228,9 +226,7 @@ __global__ __launch_bounds__(MASH_THREADS) void hash_filter_dna_kernel(
                 v = make_uint4(w[0], w[1], w[2], w[3]);
             }
         }
-        const uint32_t p = (mash_pack4(v.x) << 24) | (mash_pack4(v.y) << 16) | (mash_pack4(v.z) << 8) | mash_pack4(v.w);
-        const uint32_t m = (mash_inv4(v.x) << 12) | (mash_inv4(v.y) << 8) | (mash_inv4(v.z) << 4) | mash_inv4(v.w);
-        pk[j] = make_uint2(p, m);
+        pk[j] = make_uint2(dvs_pack16(v), dvs_inv16(v));
     }
     for (uint32_t i = threadIdx.x; i < TBLW; i += MASH_THREADS) tbl[i] = 0xFFFFFFFFu;
     if (threadIdx.x == 0) s_max_seen = 0;
@@ -602,7 +598,7 @@ struct PooledBuf {  // a block of the context's cache, handed back on scope exit
 
 // sketches of a batch, left in HBM: nseq x sketch_size uint32 (ascending, first d_lens[i] valid) in
 // blocks of the context's cache (the caller hands them back with dvs_dev_free)
-static int mash_sketch_core(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, const uint64_t *offsets,
+static int mash_sketch_view(dvs_ctx *ctx, const dvs_seq_view &sv, const uint64_t *offsets,
                             uint32_t nseq, uint32_t k, uint32_t sketch_size, uint32_t num_states,
                             int mash_canonical, uint32_t **d_sk_out, uint32_t **d_lens_out) {
     *d_sk_out = nullptr;
@@ -610,15 +606,15 @@ static int mash_sketch_core(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_devic
     DVS_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t s = sketch_size;
     const uint64_t nbytes = offsets[nseq];
-
-    DevBuf d_seq_own;
-    const uint8_t *d_seqs = seqs;
-    if (!seqs_on_device) {
-        DVS_HIP(ctx, hipMalloc(&d_seq_own.p, nbytes ? nbytes : 16));
-        if (nbytes)
-            DVS_HIP(ctx, hipMemcpyAsync(d_seq_own.p, seqs, nbytes, hipMemcpyHostToDevice, ctx->stream));
-        d_seqs = d_seq_own.as<uint8_t>();
-    }
+    const bool packed = sv.codes != nullptr;
+    if (nbytes > sv.nbytes)
+        return dvs_set_error(ctx, DVS_ERR_VALUE, "offsets[%u] = %llu beyond the %llu bases of the batch", nseq,
+                             (unsigned long long)nbytes, (unsigned long long)sv.nbytes);
+    if (packed && (num_states != 4 || k > 32))
+        return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "packed sequences are sketched with four states and k <= 32 (k = %u, %u states)",
+                             k, num_states);
+    const uint8_t *d_seqs = packed ? reinterpret_cast<const uint8_t *>(sv.codes) : sv.seqs;
+    const uint16_t *d_pmask = sv.mask;
 
     // tiles and the first hash range (lo, hi] per sequence: hashes are ~uniform, so
     // hi = 2^32 * (1.5 s + 256) / n_windows holds ~1.5 s candidates; a sequence of
@@ -698,22 +694,28 @@ static int mash_sketch_core(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_devic
         DVS_HIP(ctx, hipMemcpyAsync(d_active.p, active.data(), nseq, hipMemcpyHostToDevice, ctx->stream));
         DVS_HIP(ctx, hipMemcpyAsync(d_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         DVS_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, nseq * 4, ctx->stream));
-        if (num_states == 4 && k <= 32 && !ctx->knobs.mash_bytewise) {  // 2-bit packed windows
+        if (num_states == 4 && k <= 32 && (packed || !ctx->knobs.mash_bytewise)) {  // 2-bit packed windows
             // the small hash set when no active sequence lets more than ~512 windows of a tile through
             bool small = !ctx->knobs.mash_big_table;
             for (uint32_t q : list) {
                 const long double frac = ((long double)hi[q] - (long double)lo[q]) / 4294967296.0L;
                 if (frac * MASH_TILE > 512.0L) small = false;
             }
-#define DVS_LAUNCH_DNA(K16, TBLW)                                                                              \
-    hipLaunchKernelGGL((hash_filter_dna_kernel<K16, TBLW>), dim3(uint32_t(tiles.size())), dim3(MASH_THREADS), 0, \
-                       ctx->stream, d_seqs, nbytes, d_tiles.as<MTile>(), k, mash_canonical, d_lo.as<long long>(), \
+#define DVS_LAUNCH_DNA(K16, TBLW, PKD)                                                                         \
+    hipLaunchKernelGGL((hash_filter_dna_kernel<K16, TBLW, PKD>), dim3(uint32_t(tiles.size())), dim3(MASH_THREADS), 0, \
+                       ctx->stream, d_seqs, d_pmask, nbytes, d_tiles.as<MTile>(), k, mash_canonical, d_lo.as<long long>(), \
                        d_hi.as<uint32_t>(), d_active.as<uint8_t>(), d_cand.as<uint32_t>(), d_coff.as<uint64_t>(), \
                        d_cap.as<uint32_t>(), d_cnt.as<uint32_t>())
-            if (k <= 16 && small) DVS_LAUNCH_DNA(true, 2048);
-            else if (k <= 16) DVS_LAUNCH_DNA(true, 2 * MASH_TILE);
-            else if (small) DVS_LAUNCH_DNA(false, 2048);
-            else DVS_LAUNCH_DNA(false, 2 * MASH_TILE);
+#define DVS_LAUNCH_DNA_ANY(PKD)                                  \
+    do {                                                         \
+        if (k <= 16 && small) DVS_LAUNCH_DNA(true, 2048, PKD);   \
+        else if (k <= 16) DVS_LAUNCH_DNA(true, 2 * MASH_TILE, PKD); \
+        else if (small) DVS_LAUNCH_DNA(false, 2048, PKD);        \
+        else DVS_LAUNCH_DNA(false, 2 * MASH_TILE, PKD);          \
+    } while (0)
+            if (packed) DVS_LAUNCH_DNA_ANY(true);
+            else DVS_LAUNCH_DNA_ANY(false);
+#undef DVS_LAUNCH_DNA_ANY
 #undef DVS_LAUNCH_DNA
         } else
             hipLaunchKernelGGL(hash_filter_kernel, dim3(uint32_t(tiles.size())), dim3(MASH_THREADS), 0,
@@ -756,6 +758,44 @@ static int mash_sketch_core(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_devic
     *d_lens_out = d_lens.as<uint32_t>();
     d_sk.p = d_lens.p = nullptr;  // handed over
     return DVS_OK;
+}
+
+// the byte form, from either side of PCIe.  Host memory: four-state sequences of k <= 32 cross packed
+// (pack.hip: 3/8 of the bytes) and are sketched from the packed words; anything else is copied as it is.
+static int mash_sketch_core(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, const uint64_t *offsets,
+                            uint32_t nseq, uint32_t k, uint32_t sketch_size, uint32_t num_states,
+                            int mash_canonical, uint32_t **d_sk_out, uint32_t **d_lens_out) {
+    const uint64_t nbytes = offsets[nseq];
+    dvs_seq_view sv;
+    sv.nbytes = nbytes;
+    if (seqs_on_device) {
+        sv.seqs = seqs;
+        return mash_sketch_view(ctx, sv, offsets, nseq, k, sketch_size, num_states, mash_canonical, d_sk_out, d_lens_out);
+    }
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    if (k <= 32 && !ctx->knobs.mash_bytewise && dvs_packed_upload_wanted(ctx, num_states, nbytes)) {
+        dvs_packed *p = nullptr;
+        int rc = dvs_packed_alloc(ctx, nbytes, &p);
+        if (!rc) rc = dvs_packed_fill_from_host(ctx, p, seqs);
+        if (!rc) {
+            sv.codes = p->d_codes;
+            sv.mask = p->d_mask;
+            rc = mash_sketch_view(ctx, sv, offsets, nseq, k, sketch_size, num_states, mash_canonical, d_sk_out, d_lens_out);
+        }
+        if (p) {
+            (void)hipStreamSynchronize(ctx->stream);
+            dvs_packed_destroy(p);
+        }
+        return rc;
+    }
+    PooledBuf d_own{ctx};
+    int rc = dvs_dev_alloc(ctx, &d_own.p, nbytes ? nbytes : 16, "sequence upload buffer");
+    if (rc) return rc;
+    if (nbytes) DVS_HIP(ctx, hipMemcpyAsync(d_own.p, seqs, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    sv.seqs = d_own.as<uint8_t>();
+    rc = mash_sketch_view(ctx, sv, offsets, nseq, k, sketch_size, num_states, mash_canonical, d_sk_out, d_lens_out);
+    (void)hipStreamSynchronize(ctx->stream);  // (the upload buffer goes back to the cache)
+    return rc;
 }
 
 static int mash_check_args(dvs_ctx *ctx, const uint64_t *offsets, uint32_t k) {
@@ -813,6 +853,33 @@ extern "C" int dvs_sketches_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on
     if (nseq && sketch_size) {
         rc = mash_sketch_core(ctx, seqs, seqs_on_device, offsets, nseq, k, sketch_size, num_states, mash_canonical,
                               &sk->d_sk, &sk->d_lens);
+        if (rc) {
+            dvs_ctx_release(ctx);
+            delete sk;
+            return rc;
+        }
+    }
+    *out = sk;
+    return DVS_OK;
+}
+
+extern "C" int dvs_sketches_build_packed(dvs_ctx *ctx, const dvs_packed *p, const uint64_t *offsets, uint32_t nseq,
+                                         uint32_t k, uint32_t sketch_size, int mash_canonical, dvs_sketches **out) {
+    if (!out || !p) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    *out = nullptr;
+    int rc = mash_check_args(ctx, offsets, k);
+    if (rc) return rc;
+    dvs_sketches *sk = new dvs_sketches();
+    sk->ctx = ctx;
+    sk->nseq = nseq;
+    sk->stride = sketch_size;
+    dvs_ctx_retain(ctx);
+    if (nseq && sketch_size) {
+        dvs_seq_view sv;
+        sv.codes = p->d_codes;
+        sv.mask = p->d_mask;
+        sv.nbytes = p->nbases;
+        rc = mash_sketch_view(ctx, sv, offsets, nseq, k, sketch_size, 4, mash_canonical, &sk->d_sk, &sk->d_lens);
         if (rc) {
             dvs_ctx_release(ctx);
             delete sk;

@@ -1,11 +1,16 @@
-// Packed upload of four-state sequences handed over in host memory (dvs_matrix_build from a host pointer:
-// what diverse_seq._dvs.nmost_divergent / max_divergent do with a store's sequences, src/lib.rs:59-73,
-// src/record.rs:205-209).  The boundary's convention is one byte per base; on PCIe that is the whole cost
-// of the call (500 MB for 100k x 5 kb: ~10 ms, the selection itself takes 1.5).  So host threads pack the
-// stream chunk by chunk -- 2 bits per base + 1 "invalid" bit per base, 3/8 of the bytes -- into a pinned
-// staging block the context keeps, every chunk is sent as soon as it is packed (copy i + 1 runs beside the
-// packing of chunk i + 2), and one kernel expands the stream again to the one-byte form the histogram
-// reads (any symbol >= 4 comes back as 0xFF: the histogram only asks "valid or not").
+// Four-state sequences in HBM at 3 bits per base: 2-bit codes + a 1-bit "invalid" mask (dvs_packed,
+// dvs_internal.h).  The reference's convention is one byte per base (src/record.rs:205-209,
+// diverse_seq/util.py:32-45); a symbol carries two bits of it and "is this a gap / an ambiguity code".
+// The histogram and sketch kernels read the packed words AS THEY ARE (kmer_hist.hip, mash.hip) -- the
+// word layout is the one their index arithmetic uses internally -- so
+//   * sequences handed over in HOST memory (dvs_matrix_build from a host pointer: what
+//     diverse_seq._dvs.nmost_divergent / max_divergent do with a store's sequences, src/lib.rs:59-73)
+//     are packed by host threads chunk by chunk into a pinned staging block the context keeps, every
+//     chunk is sent as soon as it is packed (copy i + 1 runs beside the packing of chunk i + 2), and
+//     that is all: 3/8 of the bytes cross PCIe and nothing is expanded again;
+//   * sequences already in HBM one byte per base (a torch tensor, the ingest's output) can be packed
+//     once by pack_kernel (dvs_pack_sequences, dvs_seqbatch_pack) and then sit there at 3/8 of the
+//     bytes: a genome collection of 31.5 Gbases is 11.8 GB instead of 31.5.
 #include "dvs_internal.h"
 
 #include <algorithm>
@@ -16,35 +21,34 @@
 #include <thread>
 #include <vector>
 
-extern "C" void dvs_pack_bases(const uint8_t *src, size_t n, uint8_t *codes, uint8_t *mask);  // pack_host.cpp
+extern "C" void dvs_pack_bases(const uint8_t *src, size_t n, uint32_t *codes, uint16_t *mask);  // pack_host.cpp
 
 namespace {
 
-constexpr size_t PACK_CHUNK = size_t(4) << 20;                   // bases per chunk (a multiple of 32)
-constexpr size_t PACK_BLOCK = PACK_CHUNK / 4 + PACK_CHUNK / 8;   // a chunk's packed bytes: its codes, then its mask
+constexpr size_t PACK_CHUNK = size_t(4) << 20;  // bases per host-packed chunk (a multiple of 32)
+constexpr size_t PACK_CODE_BYTES = PACK_CHUNK / 4, PACK_MASK_BYTES = PACK_CHUNK / 8;
 
-// 16 bases per thread: one u32 of codes + one u16 of mask -> one 16-byte store
-__global__ __launch_bounds__(256) void unpack_kernel(const uint8_t *__restrict__ packed, uint8_t *__restrict__ out,
-                                                     uint64_t ngroups) {
-    const uint64_t t = uint64_t(blockIdx.x) * 256u + threadIdx.x;
-    if (t >= ngroups) return;
-    const uint64_t g = t * 16, c = g / PACK_CHUNK, r = g % PACK_CHUNK;
-    const uint8_t *blk = packed + c * PACK_BLOCK;
-    const uint32_t codes = *reinterpret_cast<const uint32_t *>(blk + r / 4);
-    const uint32_t m = *reinterpret_cast<const uint16_t *>(blk + PACK_CHUNK / 4 + r / 8);
-    uint32_t w[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        uint32_t word = 0;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int i = q * 4 + b;
-            const uint32_t v = ((m >> i) & 1u) ? 0xFFu : ((codes >> (2 * i)) & 3u);
-            word |= v << (8 * b);
-        }
-        w[q] = word;
+// bytes in HBM -> the two planes; 16 bases per thread: one 16-byte load, a 4-byte and a 2-byte store
+__global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ seqs, uint64_t nbytes,
+                                                   uint32_t *__restrict__ codes, uint16_t *__restrict__ mask,
+                                                   uint64_t nwords) {
+    const uint64_t w = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    if (w >= nwords) return;
+    const uint64_t a = w * 16;
+    uint4 v;
+    if (a + 16 <= nbytes) {
+        v = *reinterpret_cast<const uint4 *>(seqs + a);
+    } else {  // the ragged tail: positions behind the end are invalid
+        uint32_t q[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        for (int i = 0; i < 16; i++)
+            if (a + i < nbytes) {
+                q[i >> 2] &= ~(0xFFu << (8 * (i & 3)));
+                q[i >> 2] |= uint32_t(seqs[a + i]) << (8 * (i & 3));
+            }
+        v = make_uint4(q[0], q[1], q[2], q[3]);
     }
-    *reinterpret_cast<uint4 *>(out + g) = make_uint4(w[0], w[1], w[2], w[3]);
+    codes[w] = dvs_pack16(v);
+    mask[w] = uint16_t(dvs_inv16(v));
 }
 
 }  // namespace
@@ -69,18 +73,54 @@ bool dvs_packed_upload_wanted(const dvs_ctx *ctx, uint32_t num_states, uint64_t 
     return num_states == 4 && nbytes >= (uint64_t(32) << 20) && !ctx->knobs.no_packed_upload;
 }
 
-// seqs[0, nbytes) (host, one byte per base, four states) -> d_out[0, ceil16(nbytes)) on the context's
-// stream; symbols >= 4 and the positions behind nbytes up to the next multiple of 16 become 0xFF.
-int dvs_upload_packed(dvs_ctx *ctx, const uint8_t *seqs, uint64_t nbytes, uint8_t *d_out) {
+int dvs_packed_alloc(dvs_ctx *ctx, uint64_t nbases, dvs_packed **out) {
+    *out = nullptr;
+    dvs_packed *p = new dvs_packed();
+    p->ctx = ctx;
+    p->nbases = nbases;
+    p->nwords = (nbases + 15) / 16;
+    dvs_ctx_retain(ctx);
+    // (+ 4 words: the kernels' 16-byte and look-ahead reads near the end stay inside the planes)
+    int rc = dvs_dev_alloc(ctx, (void **)&p->d_codes, (p->nwords + 4) * 4, "packed sequences (codes)");
+    if (!rc) rc = dvs_dev_alloc(ctx, (void **)&p->d_mask, (p->nwords + 8) * 2, "packed sequences (mask)");
+    if (rc) {
+        dvs_packed_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return DVS_OK;
+}
+
+extern "C" void dvs_packed_destroy(dvs_packed *p) {
+    if (!p) return;
+    dvs_dev_free(p->ctx, p->d_codes);
+    dvs_dev_free(p->ctx, p->d_mask);
+    dvs_ctx_release(p->ctx);
+    delete p;
+}
+
+int dvs_packed_fill_from_device(dvs_ctx *ctx, dvs_packed *p, const uint8_t *d_seqs) {
+    if (!p->nwords) return DVS_OK;
+    hipLaunchKernelGGL(pack_kernel, dim3(uint32_t((p->nwords + 255) / 256)), dim3(256), 0, ctx->stream, d_seqs, p->nbases,
+                       p->d_codes, p->d_mask, p->nwords);
+    DVS_HIP(ctx, hipGetLastError());
+    return DVS_OK;
+}
+
+// seqs[0, nbases) (host, one byte per base) -> the planes, enqueued on the context's stream; returns when the
+// last chunk's copy has been ENQUEUED (the staging block is protected by ctx->pack_ev).
+int dvs_packed_fill_from_host(dvs_ctx *ctx, dvs_packed *p, const uint8_t *seqs) {
+    const uint64_t nbytes = p->nbases;
+    if (!nbytes) return DVS_OK;
     const size_t nchunks = size_t((nbytes + PACK_CHUNK - 1) / PACK_CHUNK);
-    const size_t packed_bytes = nchunks * PACK_BLOCK;
+    const size_t stage_bytes = nchunks * (PACK_CODE_BYTES + PACK_MASK_BYTES);
     // the staging block: nobody may still be reading it (the previous call's last copy)
     if (ctx->pack_ev) (void)hipEventSynchronize(ctx->pack_ev);
-    if (ctx->h_pack_cap < packed_bytes) {
+    if (ctx->h_pack_cap < stage_bytes) {
         if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
         ctx->h_pack = nullptr;
         ctx->h_pack_cap = 0;
-        const size_t cap = packed_bytes + packed_bytes / 8;
+        const size_t cap = stage_bytes + stage_bytes / 8;
         const hipError_t he = hipHostMalloc(&ctx->h_pack, cap, hipHostMallocDefault);
         if (he != hipSuccess) {
             ctx->h_pack = nullptr;
@@ -88,22 +128,24 @@ int dvs_upload_packed(dvs_ctx *ctx, const uint8_t *seqs, uint64_t nbytes, uint8_
         }
         ctx->h_pack_cap = cap;
     }
-    uint8_t *stage = static_cast<uint8_t *>(ctx->h_pack);
-    uint8_t *d_packed = nullptr;
-    int rc = dvs_dev_alloc(ctx, (void **)&d_packed, packed_bytes, "packed sequences");
-    if (rc) return rc;
+    // staging layout: every chunk's codes, then every chunk's masks (the planes as they lie on the device)
+    uint8_t *stage_codes = static_cast<uint8_t *>(ctx->h_pack);
+    uint8_t *stage_mask = stage_codes + nchunks * PACK_CODE_BYTES;
     std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[nchunks]);
     for (size_t c = 0; c < nchunks; c++) done[c].store(0, std::memory_order_relaxed);
     std::atomic<size_t> next{0};
+    auto pack_chunk = [&](size_t c) {
+        const uint64_t a = uint64_t(c) * PACK_CHUNK;
+        const size_t n = size_t(std::min<uint64_t>(PACK_CHUNK, nbytes - a));
+        dvs_pack_bases(seqs + a, n, reinterpret_cast<uint32_t *>(stage_codes + c * PACK_CODE_BYTES),
+                       reinterpret_cast<uint16_t *>(stage_mask + c * PACK_MASK_BYTES));
+        done[c].store(1, std::memory_order_release);
+    };
     auto work = [&]() {
         for (;;) {
             const size_t c = next.fetch_add(1, std::memory_order_relaxed);
             if (c >= nchunks) return;
-            const uint64_t a = uint64_t(c) * PACK_CHUNK;
-            const size_t n = size_t(std::min<uint64_t>(PACK_CHUNK, nbytes - a));
-            uint8_t *blk = stage + c * PACK_BLOCK;
-            dvs_pack_bases(seqs + a, n, blk, blk + PACK_CHUNK / 4);
-            done[c].store(1, std::memory_order_release);
+            pack_chunk(c);
         }
     };
     const unsigned nthr = unsigned(std::min<size_t>(dvs_host_threads(), nchunks));
@@ -116,33 +158,68 @@ int dvs_upload_packed(dvs_ctx *ctx, const uint8_t *seqs, uint64_t nbytes, uint8_
                 // nothing to send yet: pack a chunk here instead of spinning
                 const size_t mine = next.fetch_add(1, std::memory_order_relaxed);
                 if (mine < nchunks) {
-                    const uint64_t a = uint64_t(mine) * PACK_CHUNK;
-                    const size_t n = size_t(std::min<uint64_t>(PACK_CHUNK, nbytes - a));
-                    uint8_t *blk = stage + mine * PACK_BLOCK;
-                    dvs_pack_bases(seqs + a, n, blk, blk + PACK_CHUNK / 4);
-                    done[mine].store(1, std::memory_order_release);
+                    pack_chunk(mine);
                     continue;
                 }
             }
             std::this_thread::yield();
         }
-        e = hipMemcpyAsync(d_packed + c * PACK_BLOCK, stage + c * PACK_BLOCK, PACK_BLOCK, hipMemcpyHostToDevice, ctx->stream);
+        const uint64_t a = uint64_t(c) * PACK_CHUNK;
+        const size_t words = size_t((std::min<uint64_t>(PACK_CHUNK, nbytes - a) + 15) / 16);
+        e = hipMemcpyAsync(reinterpret_cast<uint8_t *>(p->d_codes) + c * PACK_CODE_BYTES, stage_codes + c * PACK_CODE_BYTES,
+                           words * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(reinterpret_cast<uint8_t *>(p->d_mask) + c * PACK_MASK_BYTES, stage_mask + c * PACK_MASK_BYTES,
+                               words * 2, hipMemcpyHostToDevice, ctx->stream);
     }
     for (std::thread &t : pool) t.join();
     if (e == hipSuccess) {
         if (!ctx->pack_ev) (void)hipEventCreateWithFlags(&ctx->pack_ev, hipEventDisableTiming);
         if (ctx->pack_ev) e = hipEventRecord(ctx->pack_ev, ctx->stream);
     }
-    if (e == hipSuccess) {
-        const uint64_t ngroups = (nbytes + 15) / 16;
-        hipLaunchKernelGGL(unpack_kernel, dim3(uint32_t((ngroups + 255) / 256)), dim3(256), 0, ctx->stream, d_packed, d_out,
-                           ngroups);
-        e = hipGetLastError();
-    }
-    dvs_dev_free(ctx, d_packed);  // (back to the pool: stream order protects it until the kernel has run)
     if (e != hipSuccess) {
         (void)hipStreamSynchronize(ctx->stream);
         return dvs_hip_fail(ctx, e, "packed sequence upload");
     }
+    return DVS_OK;
+}
+
+// ---- C ABI (include/dvs_hip.h)
+extern "C" int dvs_pack_sequences(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, uint64_t nbases,
+                                  dvs_packed **out) {
+    if (!ctx || !out || (!seqs && nbases)) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    *out = nullptr;
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    if (seqs_on_device && (reinterpret_cast<uintptr_t>(seqs) & 15))
+        return dvs_set_error(ctx, DVS_ERR_VALUE, "device sequence buffer must be 16-byte aligned");
+    dvs_packed *p = nullptr;
+    int rc = dvs_packed_alloc(ctx, nbases, &p);
+    if (rc) return rc;
+    rc = seqs_on_device ? dvs_packed_fill_from_device(ctx, p, seqs) : dvs_packed_fill_from_host(ctx, p, seqs);
+    if (!rc && !seqs_on_device && hipStreamSynchronize(ctx->stream) != hipSuccess)  // (the caller's buffer is free again)
+        rc = dvs_set_error(ctx, DVS_ERR_RUNTIME, "packed sequence upload failed");
+    if (rc) {
+        dvs_packed_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return DVS_OK;
+}
+
+extern "C" int dvs_packed_info(const dvs_packed *p, uint64_t *nbases, uint64_t *nwords) {
+    if (!p) return DVS_ERR_VALUE;
+    if (nbases) *nbases = p->nbases;
+    if (nwords) *nwords = p->nwords;
+    return DVS_OK;
+}
+extern "C" const void *dvs_packed_dev_codes(const dvs_packed *p) { return p ? p->d_codes : nullptr; }
+extern "C" const void *dvs_packed_dev_mask(const dvs_packed *p) { return p ? p->d_mask : nullptr; }
+
+extern "C" int dvs_packed_get(dvs_ctx *ctx, const dvs_packed *p, uint32_t *codes_out, uint16_t *mask_out) {
+    if (!ctx || !p) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (!p->nwords) return DVS_OK;
+    if (codes_out) DVS_HIP(ctx, hipMemcpyAsync(codes_out, p->d_codes, p->nwords * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (mask_out) DVS_HIP(ctx, hipMemcpyAsync(mask_out, p->d_mask, p->nwords * 2, hipMemcpyDeviceToHost, ctx->stream));
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return DVS_OK;
 }

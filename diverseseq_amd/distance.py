@@ -52,6 +52,9 @@ def distances_from_sketches(sk: np.ndarray, lens: np.ndarray, k: int, sketch_siz
     sk = np.ascontiguousarray(sk, dtype=np.uint32)
     lens = np.ascontiguousarray(lens, dtype=np.uint32)
     n = sk.shape[0]
+    if out is not None and (not isinstance(out, np.ndarray) or out.shape != (n, n) or out.dtype != np.float64
+                            or not out.flags["C_CONTIGUOUS"]):
+        raise ValueError(f"out must be a C-contiguous float64 array of shape ({n}, {n})")
     dist = np.zeros((n, n), dtype=np.float64) if out is None else out
     ctx.check(ctx._L.dvs_mash_distances(ctx._h, _lib.ptr(sk, C.c_uint32), sk.shape[1],
                                         _lib.ptr(lens, C.c_uint32), n, k,
@@ -77,14 +80,17 @@ class Sketches:
     stages of ctree (diverse_seq/cluster.py:241-297) without a trip through the host"""
 
     def __init__(self, seqs, k: int, sketch_size: int, num_states: int = 4, mash_canonical: bool = False,
-                 ctx: engine.Context | None = None, dev_ptr: int | None = None, offsets=None):
-        self.ctx = ctx or engine.default_context()
-        if dev_ptr is None:
-            data, offsets = engine.concat(seqs)
-            src, on_dev = data.ctypes.data_as(C.c_void_p), 0
-        else:  # sequences already in HBM
+                 ctx: engine.Context | None = None, dev_ptr: int | None = None, offsets=None,
+                 packed: "engine.Packed | None" = None, batch: "engine.SeqBatch | None" = None):
+        """seqs: host sequences; or dev_ptr + offsets: bytes already in HBM; or packed + offsets: a packed batch
+        (engine.Packed); or batch: an ingested engine.SeqBatch (packed or not)"""
+        self.ctx = ctx or (batch.ctx if batch is not None else packed.ctx if packed is not None else engine.default_context())
+        if batch is not None:
+            offsets = batch.offsets
+        elif packed is not None or dev_ptr is not None:
             offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
-            src, on_dev = C.c_void_p(dev_ptr), 1
+        else:
+            data, offsets = engine.concat(seqs)
         self.n = offsets.size - 1
         lens_in = np.diff(offsets.astype(np.int64)) if self.n else np.zeros(0, dtype=np.int64)
         longest = int(max(0, (lens_in.max() if self.n else 0) - k + 1))
@@ -93,8 +99,22 @@ class Sketches:
         self.k, self.sketch_size = k, int(sketch_size)
         self.stride = max(1, min(int(sketch_size), longest)) if sketch_size else 0
         h = C.c_void_p()
-        self.ctx.check(self.ctx._L.dvs_sketches_build(self.ctx._h, src, on_dev, _lib.ptr(offsets, C.c_uint64), self.n, k,
-                                                      self.stride, num_states, int(bool(mash_canonical)), C.byref(h)))
+        L, flag = self.ctx._L, int(bool(mash_canonical))
+        if batch is not None:
+            self.ctx.check(L.dvs_sketches_build_from_seqbatch(self.ctx._h, batch._h, k, self.stride, num_states, flag,
+                                                             C.byref(h)))
+        elif packed is not None:
+            if num_states != 4:
+                raise ValueError("packed sequences have four states")
+            self.ctx.check(L.dvs_sketches_build_packed(self.ctx._h, packed._h, _lib.ptr(offsets, C.c_uint64), self.n, k,
+                                                      self.stride, flag, C.byref(h)))
+        else:
+            if dev_ptr is None:
+                src, on_dev = data.ctypes.data_as(C.c_void_p), 0
+            else:  # sequences already in HBM
+                src, on_dev = C.c_void_p(dev_ptr), 1
+            self.ctx.check(L.dvs_sketches_build(self.ctx._h, src, on_dev, _lib.ptr(offsets, C.c_uint64), self.n, k,
+                                               self.stride, num_states, flag, C.byref(h)))
         self._h = h
 
     def close(self):
@@ -117,6 +137,9 @@ class Sketches:
 
     def distances(self, *, row_start: int = 0, row_stride: int = 1, symmetric: bool = True,
                   out: np.ndarray | None = None) -> np.ndarray:
+        if out is not None and (not isinstance(out, np.ndarray) or out.shape != (self.n, self.n)
+                                or out.dtype != np.float64 or not out.flags["C_CONTIGUOUS"]):
+            raise ValueError(f"out must be a C-contiguous float64 array of shape ({self.n}, {self.n})")
         dist = np.zeros((self.n, self.n), dtype=np.float64) if out is None else out
         self.ctx.check(self.ctx._L.dvs_sketches_distances(self.ctx._h, self._h, self.k, min(self.sketch_size, _U32_MAX),
                                                           row_start, row_stride, int(symmetric), _lib.ptr(dist, C.c_double)))

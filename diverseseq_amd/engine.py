@@ -149,6 +149,30 @@ class Context:
                                             num_states, C.byref(h)))
         return CountMatrix(self, h, k, num_states)
 
+    # ---- packed sequences (3 bits per base in HBM: csrc/pack.hip) ------------------
+    def pack_device(self, dev_ptr: int, nbases: int) -> "Packed":
+        """four-state sequences resident in HBM one byte per base (16-byte aligned) -> the packed form; the
+        kernel is not waited for: keep the byte buffer until the next ctx.sync()"""
+        h = C.c_void_p()
+        self.check(self._L.dvs_pack_sequences(self._h, C.c_void_p(dev_ptr), 1, int(nbases), C.byref(h)))
+        return Packed(self, h)
+
+    def pack_host(self, data: np.ndarray) -> "Packed":
+        """host sequences (concatenated uint8) -> the packed form in HBM; 3/8 of the bytes cross PCIe"""
+        data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+        h = C.c_void_p()
+        self.check(self._L.dvs_pack_sequences(self._h, C.c_void_p(data.ctypes.data) if data.size else None, 0,
+                                              data.size, C.byref(h)))
+        return Packed(self, h)
+
+    def build_matrix_packed(self, packed: "Packed", offsets: np.ndarray, k: int) -> "CountMatrix":
+        """k-mer count matrix of a packed batch (the histogram kernel reads the packed words as they are)"""
+        h = C.c_void_p()
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.check(self._L.dvs_matrix_build_packed(self._h, packed._h, _lib.ptr(offsets, C.c_uint64), offsets.size - 1,
+                                                   k, C.byref(h)))
+        return CountMatrix(self, h, k, 4)
+
     # ---- ingest ---------------------------------------------------------------
     def encode_fasta(self, raw, join_records: bool = False, moltype: str = "dna",
                      dev_ptr: int | None = None, nbytes: int | None = None) -> "SeqBatch":
@@ -205,6 +229,44 @@ class Context:
             m.close()
 
 
+class Packed:
+    """four-state sequences in HBM at 3 bits per base (dvs_packed): code words (uint32 per 16 bases, the first
+    base in the top bit pair) and mask words (uint16 per 16 bases, bit 15 - i = base i invalid)"""
+
+    def __init__(self, ctx: Context, handle, owned: bool = True):
+        self.ctx, self._h, self._owned = ctx, handle, owned
+        nb, nw = C.c_uint64(), C.c_uint64()
+        ctx._L.dvs_packed_info(handle, C.byref(nb), C.byref(nw))
+        self.nbases, self.nwords = nb.value, nw.value
+
+    @property
+    def dev_codes(self) -> int:
+        return int(self.ctx._L.dvs_packed_dev_codes(self._h) or 0)
+
+    @property
+    def dev_mask(self) -> int:
+        return int(self.ctx._L.dvs_packed_dev_mask(self._h) or 0)
+
+    def planes(self) -> tuple[np.ndarray, np.ndarray]:
+        """(codes uint32 [nwords], mask uint16 [nwords]) copied to the host (tests)"""
+        codes = np.zeros(max(1, self.nwords), dtype=np.uint32)
+        mask = np.zeros(max(1, self.nwords), dtype=np.uint16)
+        self.ctx.check(self.ctx._L.dvs_packed_get(self.ctx._h, self._h, _lib.ptr(codes, C.c_uint32),
+                                                  _lib.ptr(mask, C.c_uint16)))
+        return codes[: self.nwords], mask[: self.nwords]
+
+    def close(self):
+        if getattr(self, "_h", None) and self._owned:
+            self.ctx._L.dvs_packed_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class SeqBatch:
     """index-coded sequences resident in HBM, as produced by Context.encode_fasta"""
 
@@ -254,6 +316,17 @@ class SeqBatch:
     def sequences(self) -> list:
         c = self.codes()
         return [c[int(a): int(b)] for a, b in zip(self.offsets[:-1], self.offsets[1:])]
+
+    def pack(self) -> "SeqBatch":
+        """re-state the batch's bases at 3 bits each and release the byte form (four-state use only: every
+        symbol >= 4 becomes "invalid"); build_matrix / sketches then read the packed words"""
+        self.ctx.check(self.ctx._L.dvs_seqbatch_pack(self.ctx._h, self._h))
+        return self
+
+    @property
+    def packed(self) -> "Packed | None":
+        h = self.ctx._L.dvs_seqbatch_packed(self._h)
+        return Packed(self.ctx, C.c_void_p(h), owned=False) if h else None
 
     def build_matrix(self, k: int, num_states: int = 4) -> "CountMatrix":
         """k-mer count matrix straight from the encoded bases in HBM (no host round trip)"""

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DVS_ABI_VERSION 2
+#define DVS_ABI_VERSION 3
 
 #define DVS_OK 0
 #define DVS_ERR_VALUE 1       /* the reference would panic -> python ValueError */
@@ -115,6 +115,33 @@ int dvs_kmer_counts(dvs_ctx *ctx, const uint8_t *seqs, const uint64_t *offsets,
                     uint32_t nseq, uint32_t k, uint32_t num_states,
                     uint32_t *counts_out, uint32_t *totals_out, double *entropy_out);
 
+/* ---- packed sequences ------------------------------------------------------ *
+ * Four-state sequences at 3 bits per base instead of the reference's one byte per base
+ * (src/record.rs:205-209, diverse_seq/util.py:32-45): the form the histogram (count_kmers,
+ * src/record.rs:41-84) and sketch (get_kmer_hashes, src/distance.rs:101-134) kernels read from HBM
+ * as it is.  Two planes over the CONCATENATED buffer -- positions, and therefore a batch's offsets,
+ * are the same as in the byte form:
+ *   codes: one uint32 per 16 bases; base 16 w + i in bits (31 - 2 i)..(30 - 2 i), value = index & 3
+ *          (the first base of a k-mer is its most significant digit, src/record.rs:18-29)
+ *   mask:  one uint16 per 16 bases; bit 15 - i set when base 16 w + i is >= 4 (gap / ambiguity /
+ *          behind the end): every window holding such a base is skipped (src/record.rs:47-64)
+ * dvs_pack_sequences packs nbases symbols -- a HOST buffer (host threads pack 4 Mi-base chunks beside
+ * their copies: 3/8 of the bytes cross PCIe; returns when the buffer may be reused) or a 16-byte-aligned
+ * DEVICE buffer (one kernel on the ctx stream, not waited for: keep the buffer until the next sync).
+ * Symbols of an alphabet with more than four states cannot be packed: use the byte form. */
+typedef struct dvs_packed dvs_packed;
+int dvs_pack_sequences(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, uint64_t nbases,
+                       dvs_packed **out);
+void dvs_packed_destroy(dvs_packed *p);
+int dvs_packed_info(const dvs_packed *p, uint64_t *nbases, uint64_t *nwords); /* nwords = ceil(nbases / 16) */
+const void *dvs_packed_dev_codes(const dvs_packed *p); /* uint32 [nwords] in HBM */
+const void *dvs_packed_dev_mask(const dvs_packed *p);  /* uint16 [nwords] in HBM */
+int dvs_packed_get(dvs_ctx *ctx, const dvs_packed *p, uint32_t *codes_out, uint16_t *mask_out);
+/* dvs_matrix_build / dvs_sketches_build over a packed batch (num_states is 4 by construction).
+ * Neither waits for its kernels; p must outlive them (until the next call that syncs). */
+int dvs_matrix_build_packed(dvs_ctx *ctx, const dvs_packed *p, const uint64_t *offsets, uint32_t nseq,
+                            uint32_t k, dvs_matrix **out);
+
 /* ---- ingest -------------------------------------- *
  * FASTA file bytes -> the data convention above, on the device: replaces, for the hot path's
  * input, the host-side parse + encode of diverse_seq/io.py:75-104 (dvs_load_seqs.main: records
@@ -137,6 +164,13 @@ const void *dvs_seqbatch_dev_codes(const dvs_seqbatch *b);                     /
 int dvs_seqbatch_get_codes(dvs_ctx *ctx, const dvs_seqbatch *b, uint8_t *codes_out);
 int dvs_matrix_build_from_seqbatch(dvs_ctx *ctx, const dvs_seqbatch *b, uint32_t k, uint32_t num_states,
                                    dvs_matrix **out);
+/* The batch's encoded bases re-stated in the packed form above and the byte form released: a genome
+ * collection then sits in HBM at 3/8 of the bytes, and dvs_matrix_build_from_seqbatch /
+ * dvs_sketches_build_from_seqbatch (num_states 4) read the packed words.  dvs_seqbatch_dev_codes returns
+ * NULL afterwards, dvs_seqbatch_get_codes unpacks (invalid symbols come back as 255), and
+ * dvs_seqbatch_packed hands out the planes (NULL before). */
+int dvs_seqbatch_pack(dvs_ctx *ctx, dvs_seqbatch *b);
+const dvs_packed *dvs_seqbatch_packed(const dvs_seqbatch *b);
 
 /* ---- greedy delta-JSD selection ------------------------------------------ *
  * replaces SummedRecords (src/records.rs:10-216), get_lowest_record_index
@@ -281,6 +315,11 @@ typedef struct dvs_sketches dvs_sketches;
 int dvs_sketches_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, const uint64_t *offsets,
                        uint32_t nseq, uint32_t k, uint32_t sketch_size, uint32_t num_states,
                        int mash_canonical, dvs_sketches **out);
+/* the same from a packed batch (k <= 32) and from an ingested batch (packed or not) */
+int dvs_sketches_build_packed(dvs_ctx *ctx, const dvs_packed *p, const uint64_t *offsets, uint32_t nseq,
+                              uint32_t k, uint32_t sketch_size, int mash_canonical, dvs_sketches **out);
+int dvs_sketches_build_from_seqbatch(dvs_ctx *ctx, const dvs_seqbatch *b, uint32_t k, uint32_t sketch_size,
+                                     uint32_t num_states, int mash_canonical, dvs_sketches **out);
 void dvs_sketches_destroy(dvs_sketches *sk);
 int dvs_sketches_get(dvs_ctx *ctx, const dvs_sketches *sk, uint32_t *sketches_out, uint32_t *lens_out);
 const void *dvs_sketches_dev(const dvs_sketches *sk);      /* uint32 [nseq x sketch_size] in HBM */

@@ -72,10 +72,23 @@ def select_case(name, nseq, lo, hi, k, mode, reps=3, composition=False, **kw):
         m.close()
 
     phase["hist_ms"] = round(timed(hist_only, reps)[0] * 1e3, 3)
+    # the same sequences resident in HBM in the packed form (3 bits per base, packed once outside the clock)
+    packed = ctx.pack_device(seqs.data_ptr(), int(offsets[-1])) if PACKED else None
+    if packed is not None:
+        ctx.sync()
+
+        def hist_packed():
+            m = ctx.build_matrix_packed(packed, offsets, k)
+            ctx.sync()
+            m.close()
+
+        phase["hist_packed_ms"] = round(timed(hist_packed, reps)[0] * 1e3, 3)
+        phase["input_form"] = "packed"
 
     def run():
         # as a caller runs it: the build does not wait for its kernels, the selection follows at once
-        m = ctx.build_matrix_device(seqs.data_ptr(), offsets, k, 4)
+        m = (ctx.build_matrix_packed(packed, offsets, k) if packed is not None
+             else ctx.build_matrix_device(seqs.data_ptr(), offsets, k, 4))
         sel = m.nmost(kw["n"]) if mode == "nmost" else m.max_divergent(kw["min_size"], nseq, "stdev")
         s = sel.summary()
         out = dict(size=s.size, accepts=s.n_accepts, rows_scored=s.rows_scored, rechecked=s.rows_rechecked, windows=s.n_windows, engine=s.engine,
@@ -89,6 +102,8 @@ def select_case(name, nseq, lo, hi, k, mode, reps=3, composition=False, **kw):
     rec = dict(config=name, nseq=nseq, length=[lo, hi], k=k, mode=mode, **kw, ms=round(dt * 1e3, 3),
                sequences_per_s=round(nseq / dt), gbases_per_s=round(float(offsets[-1]) / dt / 1e9, 2), **phase, **out)
     print(json.dumps(rec), flush=True)
+    if packed is not None:
+        packed.close()
     del seqs
     torch.cuda.empty_cache()
 
@@ -104,6 +119,22 @@ def mash_case(name, nseq, lo, hi, k, s, canonical, reps=2, composition=False):
                                          _lib.ptr(lens, C.c_uint32)))
 
     dt_s, _ = timed(sketch, reps)
+    extra = {}
+    if PACKED:  # the same sketches from the packed form (3 bits per base in HBM)
+        packed = ctx.pack_device(seqs.data_ptr(), int(offsets[-1]))
+        ctx.sync()
+
+        def sketch_packed():
+            r = distance.Sketches(None, k, s, 4, canonical, ctx=ctx, packed=packed, offsets=offsets)
+            return r
+
+        dt_k, r = timed(sketch_packed, reps)
+        sk2, lens2 = r.to_host()
+        r.close()
+        sketch()
+        assert np.array_equal(lens, lens2) and np.array_equal(sk, sk2)
+        extra = dict(sketch_packed_ms=round(dt_k * 1e3, 2))
+        packed.close()
     dt_p, d = timed(lambda: distance.distances_from_sketches(sk, lens, k, s, ctx=ctx), reps)
     # the ctree path: the sketches stay in HBM between the two stages (distance.mash_distances)
     res = distance.Sketches(None, k, s, 4, canonical, ctx=ctx, dev_ptr=seqs.data_ptr(), offsets=offsets)
@@ -116,7 +147,7 @@ def mash_case(name, nseq, lo, hi, k, s, canonical, reps=2, composition=False):
                sketch_ms=round(dt_s * 1e3, 2), gbases_per_s=round(float(offsets[-1]) / dt_s / 1e9, 2),
                pairs=nseq * (nseq - 1) // 2, pairs_ms=round(dt_r * 1e3, 2),
                pairs_ms_from_host_sketches=round(dt_p * 1e3, 2), pairs_ms_into_a_kept_matrix=round(dt_o * 1e3, 2),
-               mean_distance=float(d[np.tril_indices(nseq, -1)].mean()))
+               mean_distance=float(d[np.tril_indices(nseq, -1)].mean()), **extra)
     print(json.dumps(rec), flush=True)
     del seqs
     torch.cuda.empty_cache()
@@ -157,8 +188,13 @@ def ingest_case(name, nrec, length, reps=3):
                           host_ms=round(dt_h * 1e3, 3), host_gbytes_per_s=round(raw.size / dt_h / 1e9, 1))), flush=True)
 
 
+PACKED = False
+
 if __name__ == "__main__":
     which = set(sys.argv[1:])
+    if "PACKED" in which:  # every case also from the packed form of its sequences
+        which.discard("PACKED")
+        PACKED = True
     def want(n):
         return not which or n in which
     if want("C2"):

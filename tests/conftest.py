@@ -72,6 +72,20 @@ def synth_seqs(nseq, length, seed, invalid_frac=0.0, ragged=False):
     return out
 
 
+def pack_reference(src: np.ndarray):
+    """numpy statement of the packed sequence form (include/dvs_hip.h "packed sequences"): per 16 bases a uint32
+    of 2-bit codes with the FIRST base in bits 31..30 and a uint16 whose bit 15 - i flags base i as invalid
+    (>= 4, or behind the end)"""
+    n = src.size
+    nw = (n + 15) // 16
+    pad = np.full(nw * 16, 255, np.uint8)
+    pad[:n] = src
+    g = pad.reshape(nw, 16).astype(np.uint32)
+    codes = ((g & 3) << (30 - 2 * np.arange(16, dtype=np.uint32))).sum(axis=1).astype(np.uint32)
+    mask = ((g > 3).astype(np.uint32) << (15 - np.arange(16, dtype=np.uint32))).sum(axis=1).astype(np.uint16)
+    return codes, mask
+
+
 def clades(newick_or_tuple) -> set[frozenset]:
     """the set of leaf sets below every internal node (for topology comparison)"""
     def parse(text: str):

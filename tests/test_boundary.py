@@ -12,6 +12,7 @@ import pytest
 
 from conftest import ROOT
 
+from conftest import pack_reference
 from diverseseq_amd import _dvs, _lib, engine
 
 
@@ -28,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(str(_lib.LIB_PATH))
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in dvs_hip.h but not exported"
-    assert _lib.load().dvs_abi_version() == 2
+    assert _lib.load().dvs_abi_version() == 3
 
 
 def test_product_never_imports_oracle():
@@ -160,23 +161,22 @@ def test_concat():
 
 def test_host_packer_of_the_packed_upload():
     """csrc/pack_host.cpp (AVX2 + BMI2 when the CPU has them, scalar otherwise): 2 bits per base + 1
-    invalid bit per base, positions behind the end of a ragged tail marked invalid -- against a numpy
-    restatement, at every length around the 32-base groups"""
+    invalid bit per base in the kernels' own word layout (uint32 of codes per 16 bases with the FIRST base in
+    the top bit pair, uint16 of mask with the first base in bit 15), positions behind the end of a ragged tail
+    marked invalid -- against a numpy restatement, at every length around the 16- and 32-base groups"""
     lib = ctypes.CDLL(str(_lib.LIB_PATH))
     f = lib.dvs_pack_bases
     f.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
     f.restype = None
     rng = np.random.default_rng(3)
-    for n in (0, 1, 31, 32, 33, 63, 64, 65, 1000, 4099, 1 << 16):
+    for n in (0, 1, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 1000, 4099, 1 << 16):
         src = rng.integers(0, 4, size=n, dtype=np.uint8)
         if n:
             src[rng.integers(0, n, size=n // 10 + 1)] = rng.integers(4, 256, size=n // 10 + 1, dtype=np.uint8)
-        n32 = (n + 31) // 32
-        codes = np.zeros(max(1, n32 * 8), np.uint8)
-        mask = np.zeros(max(1, n32 * 4), np.uint8)
+        nw = (n + 15) // 16
+        codes = np.full(nw + 4, 0xDEADBEEF, np.uint32)
+        mask = np.full(nw + 4, 0xBEEF, np.uint16)
         f(src.ctypes.data, n, codes.ctypes.data, mask.ctypes.data)
-        pad = np.full(n32 * 32, 255, np.uint8)
-        pad[:n] = src
-        ec = ((pad & 3).reshape(-1, 4).astype(np.uint32) << (2 * np.arange(4, dtype=np.uint32))).sum(axis=1).astype(np.uint8)
-        em = np.packbits((pad > 3).astype(np.uint8), bitorder="little")
-        assert (codes[: n32 * 8] == ec).all() and (mask[: n32 * 4] == em).all(), n
+        ec, em = pack_reference(src)
+        assert (codes[:nw] == ec).all() and (mask[:nw] == em).all(), n
+        assert (codes[nw:] == 0xDEADBEEF).all() and (mask[nw:] == 0xBEEF).all(), n  # nothing written behind the last word
