@@ -131,6 +131,7 @@ __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
     for (int i = tid; i < CLOG_TBL; i += nthreads) tbl[i] = clog_tbl[i];  // c log2 c, c < 256 (clog_tbl_kernel)
     __syncthreads();
 
+    uint32_t nvalid = 0;  // windows this thread counted
     const uint64_t abase = t.begin & ~15ull;
     const uint64_t nchunks = t.end > t.begin ? (t.end - abase + 15) >> 4 : 0;
     const uint32_t bmask = uint32_t(B - 1);  // NS4: B = 4^k, power of two (k = 16 -> 2^32 - 1)
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
             const uint32_t hi = t.end > A ? uint32_t(t.end - A < 16 ? t.end - A : 16) : 0u;
             const uint32_t R = (live && hi > lo) ? ((0xFFFFu >> lo) & ~(0xFFFFu >> hi)) : 0u;
             const uint32_t ok = R & ~W & 0xFFFFu;
+            nvalid += __popc(ok);  // (the row total: every counted window, not a second pass over the bins)
             if (__ballot(ok != 0xFFFFu) == 0) {  // every window of the wave's 1 KiB counts
                 if constexpr (PK16) {
                     // packed counters, four instructions a window: with P2 = P << 1, t = P2 >> s holds the
@@ -247,7 +249,10 @@ __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
                 run = ok ? run + 1 : 0u;
                 if (q >= 16) {
                     const uint64_t p = A + (q - 16);
-                    if (p >= t.begin && p < t.end && run >= k) bump<LDS_HIST, PK16>(hist, idx);
+                    if (p >= t.begin && p < t.end && run >= k) {
+                        bump<LDS_HIST, PK16>(hist, idx);
+                        nvalid++;
+                    }
                 }
             }
         }
@@ -272,9 +277,11 @@ __global__ __launch_bounds__(HIST_MAX_THREADS) void kmer_hist_kernel(
                     else __builtin_nontemporal_store((u32x2){w.x, w.y}, reinterpret_cast<u32x2 *>(r2 + u));
                 } else if (t.row < hot_rows) r4[u] = v;
                 else __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4 *>(r4 + u));
-                sv[half] += clog2c(v.x, tbl) + clog2c(v.y, tbl) + clog2c(v.z, tbl) + clog2c(v.w, tbl);
-                tv[half] += double(v.x) + double(v.y) + double(v.z) + double(v.w);
+                // (one test per four bins: a count of 256 or more is what the table does not hold)
+                if (((w.x | w.y) & 0xFF00FF00u) == 0) sv[half] += ((tbl[v.x] + tbl[v.y]) + tbl[v.z]) + tbl[v.w];
+                else sv[half] += clog2c(v.x, tbl) + clog2c(v.y, tbl) + clog2c(v.z, tbl) + clog2c(v.w, tbl);
             }
+        tv[0] = double(nvalid);  // (integers: exact in any order, the same total as the sum over the bins)
         const int lane = tid & 63, wave = tid >> 6;  // (two real waves = virtual waves {0, 2} and {1, 3})
         double sums[2];
 #pragma unroll

@@ -182,10 +182,19 @@ __device__ __forceinline__ uint32_t mash_round_k(uint32_t h, uint32_t kk) {  // 
 // do and the CU holds eight workgroups, which hides the serial chain of the rounds much better.
 // PACKED: the sequences are the planes of the packed form (dvs_packed: `seqs` points at the code words,
 // `pmask` at the mask words), whose words are this kernel's LDS words: staging a tile is two loads per 16 bases.
+//
+// Round 4: what the counters said (profiles/r04_pmc_hash_*.csv: the SIMDs issue vector instructions 92 % of the
+// kernel's cycles) and what was cut.  A lane used to take ONE window per step: three 8-byte LDS reads and a
+// 64-bit funnel shift to cut it out of the packed words, a 48-bit mask extraction for its validity, and per
+// round an address computation and a 4-byte LDS read for the round's constant.  Now a lane takes the SIXTEEN
+// windows that start in one packed word: the three words are read once, the validity of all sixteen is one
+// smear of the (almost always zero) mask bits, a window is one v_alignbit with an immediate shift, and the
+// constants of FOUR rounds come from one 16-byte LDS read of a 256-entry table indexed by the next four bases
+// (its address does not depend on the hash, so the reads run ahead of the serial chain).
 template <bool K16, uint32_t TBLW, bool PACKED = false>  // K16: k <= 16, a window fits 32 bits
 __global__ __launch_bounds__(MASH_THREADS) void hash_filter_dna_kernel(
     const uint8_t *__restrict__ seqs, const uint16_t *__restrict__ pmask, uint64_t nbytes_all,
-    const MTile *__restrict__ tiles, uint32_t k,
+    const MTile *__restrict__ tiles, uint32_t ntiles, uint32_t k,
     int canonical, const long long *__restrict__ lo, const uint32_t *__restrict__ hi,
     const uint8_t *__restrict__ active, uint32_t *__restrict__ cand,
     const uint64_t *__restrict__ cand_off, const uint32_t *__restrict__ cand_cap,
@@ -194,12 +203,25 @@ __global__ __launch_bounds__(MASH_THREADS) void hash_filter_dna_kernel(
     __shared__ uint2 pk[NW];  // x: 16 bases packed, y: their invalid mask
     __shared__ uint32_t tbl[TBLW];
     __shared__ uint32_t s_max_seen;
-    __shared__ uint32_t s_kk[4];
-    const MTile t = tiles[blockIdx.x];
-    if (!active[t.seq]) return;
-    if (threadIdx.x < 4)
-        s_kk[threadIdx.x] = threadIdx.x == 0 ? mash_round_const(0) : threadIdx.x == 1 ? mash_round_const(1)
-                          : threadIdx.x == 2 ? mash_round_const(2) : mash_round_const(3);
+    // The round constants of FOUR consecutive bases (first base in the top bit pair), 256 entries of 16 bytes: one
+    // address computation and one LDS read per four rounds.  The lanes' entries are as good as random, so the
+    // reads meet bank conflicts (64 % of the LDS cycles, profiles/r04_pmc_hash_t4_a.csv) -- the conflict-free
+    // alternative, sixteen 8-byte entries for two bases, needs twice the address arithmetic and measured slower
+    // (9.95 against 8.83 ms for C5, profiles/r04_pmc_hash_t2_a.csv: the vector ALU is what is left to save).
+    __shared__ uint4 s_t4[256];
+    {
+        const uint32_t v = threadIdx.x;  // (MASH_THREADS == 256: one entry a thread)
+        s_t4[v] = make_uint4(mash_round_const(v >> 6), mash_round_const((v >> 4) & 3u), mash_round_const((v >> 2) & 3u),
+                             mash_round_const(v & 3u));
+    }
+    // A workgroup takes tiles blockIdx.x, + gridDim.x, ...: a tile is ~13 us of work, and with one tile per
+    // workgroup the 366 000 workgroups of 1000 genomes were dispatched no faster than the chip could finish
+    // them -- 4.7 of 8 waves a SIMD resident, the shader engines idle 28 % of the kernel
+    // (profiles/r04_pmc_hash_before_*.csv).
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const MTile t = tiles[tile];
+    if (!active[t.seq]) continue;
+    if (tile != blockIdx.x) __syncthreads();  // (the previous tile's words and hash set have been read)
     const uint64_t base_al = t.begin & ~15ull;
     const uint32_t nbytes = t.count + k - 1;
     const uint32_t nwords = uint32_t((t.begin - base_al + nbytes + 15) >> 4);
@@ -236,51 +258,12 @@ __global__ __launch_bounds__(MASH_THREADS) void hash_filter_dna_kernel(
     const uint32_t cap = cand_cap[t.seq];
     uint32_t *out = cand + cand_off[t.seq];
     const uint32_t rel0 = uint32_t(t.begin - base_al);
+    const uint32_t rel_end = rel0 + t.count;            // windows start at rel0 .. rel_end - 1 (relative to base_al)
+    const uint32_t ngroups = (rel_end + 15) >> 4;       // a group: the sixteen windows starting in one packed word
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
-    for (uint32_t i = threadIdx.x; i < t.count; i += MASH_THREADS) {
-        const uint32_t rel = rel0 + i, j = rel >> 4, sh = rel & 15u;
-        const uint2 w0 = pk[j], w1 = pk[j + 1], w2 = pk[j + 2];
-        // 48 bases from position j * 16; the window is bases sh .. sh + k - 1 of them
-        const uint64_t hi64 = (uint64_t(w0.x) << 32) | w1.x;
-        const uint64_t V = sh ? ((hi64 << (2 * sh)) | (uint64_t(w2.x) >> (32 - 2 * sh))) : hi64;
-        const uint64_t K = V >> (64 - 2 * k);  // first base in the top pair of the low 2k bits
-        const uint64_t I48 = (uint64_t(w0.y) << 32) | (uint64_t(w1.y) << 16) | w2.y;
-        const uint64_t Iw = ((I48 << (16 + sh)) >> (64 - k));  // invalid flags of the window's bases
-        if (Iw) continue;
-        uint64_t X = K;
-        if (canonical) {
-            // reverse complement: pairs in reverse order, each base + 2 mod 4 (= its top bit flipped)
-            uint64_t R = __brevll(K);  // pair order reversed, bits inside a pair swapped
-            R = ((R >> 1) & 0x5555555555555555ull) | ((R & 0x5555555555555555ull) << 1);
-            R = (R >> (64 - 2 * k)) ^ (0xAAAAAAAAAAAAAAAAull & kmask);
-            if (R < K) X = R;  // lexicographic order of the bases = numeric order (distance.rs:69-78)
-        }
-        uint32_t h = 0x9747B28Cu ^ k;
-        if (K16) {
-            uint32_t xt = uint32_t(X) << (32 - 2 * k);
-            uint32_t b = 0;
-            for (; b + 4 <= k; b += 4) {  // (four rounds per trip: the loop control of a round costs a fifth of it)
-                // the four round constants come from a 4-word LDS table (their addresses do not depend
-                // on h, so the reads run ahead of the serial chain); the selects cost six instructions
-                const uint32_t k0 = s_kk[xt >> 30], k1 = s_kk[(xt >> 28) & 3u], k2 = s_kk[(xt >> 26) & 3u],
-                               k3 = s_kk[(xt >> 24) & 3u];
-                h = mash_round_k(h, k0);
-                h = mash_round_k(h, k1);
-                h = mash_round_k(h, k2);
-                h = mash_round_k(h, k3);
-                xt <<= 8;
-            }
-            for (; b < k; b++) {
-                h = mash_round(h, xt >> 30);
-                xt <<= 2;
-            }
-        } else {
-            uint64_t xt = X << (64 - 2 * k);
-            for (uint32_t b = 0; b < k; b++) {
-                h = mash_round(h, uint32_t(xt >> 62));
-                xt <<= 2;
-            }
-        }
+    const uint32_t h0 = 0x9747B28Cu ^ k;
+    const uint32_t k4 = k & ~3u, krem = k & 3u;
+    auto emit = [&](uint32_t h) {
         h = fmix32(h);
         if ((long long)h > lo_q && h <= hi_q) {
             bool fresh;
@@ -291,7 +274,102 @@ __global__ __launch_bounds__(MASH_THREADS) void hash_filter_dna_kernel(
                 if (slot < cap) out[slot] = h;
             }
         }
+    };
+    for (uint32_t g = threadIdx.x; g < ngroups; g += MASH_THREADS) {
+        const uint2 w0 = pk[g], w1 = pk[g + 1], w2 = pk[g + 2];
+        // bit 15 - sh of ok: the window starting at base sh of this word lies in the tile and holds no invalid base
+        const uint32_t sh_lo = g == 0 ? rel0 : 0u;
+        const uint32_t left = rel_end - (g << 4);
+        const uint32_t sh_hi = left < 16u ? left : 16u;
+        uint32_t ok = (0xFFFFu >> sh_lo) & ~(0xFFFFu >> sh_hi) & 0xFFFFu;
+        const uint64_t I48 = (uint64_t(w0.y) << 32) | (uint64_t(w1.y) << 16) | w2.y;  // bit 47 - p: base p of the 48 is invalid
+        if (I48) {  // bit 47 - p of S: some base of p .. p + k - 1 is invalid
+            uint64_t S = I48;
+            uint32_t cover = 1;
+            while (2 * cover <= k) {
+                S |= S << cover;
+                cover *= 2;
+            }
+            if (cover < k) S |= S << (k - cover);
+            ok &= ~uint32_t(S >> 32);
+        }
+        if (!ok) continue;
+        // The sixteen hashes first -- pure arithmetic with no side effect, so the compiler interleaves the serial
+        // chains of several windows and issues their table reads ahead (a lone chain waits an LDS round trip
+        // per four rounds: with ~5 waves a SIMD the counters showed no instruction in flight 39 % of the time) --
+        // then the few that fall into the range.  A window that does not count is hashed anyway and dropped.
+        uint32_t hs[16];
+        // four rounds from one table entry
+        auto r4 = [&](uint32_t h, const uint4 q) {
+            h = mash_round_k(h, q.x);
+            h = mash_round_k(h, q.y);
+            h = mash_round_k(h, q.z);
+            return mash_round_k(h, q.w);
+        };
+        auto rrem = [&](uint32_t h, const uint4 q) {  // the last k % 4 rounds
+            h = mash_round_k(h, q.x);
+            if (krem > 1) h = mash_round_k(h, q.y);
+            if (krem > 2) h = mash_round_k(h, q.z);
+            return h;
+        };
+        if constexpr (K16) {
+            const uint32_t c0 = w0.x, c1 = w1.x;
+            const uint32_t kmask32 = uint32_t(kmask);
+#pragma unroll
+            for (int sh = 0; sh < 16; sh++) {
+                // the window, left-aligned (its first base in the top bit pair; what follows its last base is never looked at)
+                uint32_t xt = sh ? __builtin_amdgcn_alignbit(c0, c1, (32 - 2 * sh) & 31) : c0;
+                if (canonical) {
+                    // reverse complement: pairs in reverse order, each base + 2 mod 4 (= its top bit flipped);
+                    // lexicographic order of the bases = numeric order (distance.rs:69-78)
+                    const uint32_t K = xt >> (32 - 2 * k);
+                    uint32_t R = __brev(K);  // pair order reversed, bits inside a pair swapped
+                    R = ((R >> 1) & 0x55555555u) | ((R & 0x55555555u) << 1);
+                    R = (R >> (32 - 2 * k)) ^ (0xAAAAAAAAu & kmask32);
+                    xt = (R < K ? R : K) << (32 - 2 * k);
+                }
+                // every table entry the window needs is requested before the first round (the addresses depend on
+                // the bases alone); k <= 16: at most four, and none that no round will use
+                const uint4 q0 = s_t4[xt >> 24];
+                const uint4 q1 = k > 4 ? s_t4[(xt >> 16) & 255u] : q0;
+                const uint4 q2 = k > 8 ? s_t4[(xt >> 8) & 255u] : q0;
+                const uint4 q3 = k > 12 ? s_t4[xt & 255u] : q0;
+                uint32_t h = h0;
+                if (k4 >= 4) h = r4(h, q0);
+                if (k4 >= 8) h = r4(h, q1);
+                if (k4 >= 12) h = r4(h, q2);
+                if (k4 >= 16) h = r4(h, q3);
+                if (krem) h = rrem(h, k4 == 0 ? q0 : k4 == 4 ? q1 : k4 == 8 ? q2 : q3);
+                hs[sh] = h;
+            }
+        } else {
+            const uint32_t c0 = w0.x, c1 = w1.x, c2 = w2.x;
+#pragma unroll
+            for (int sh = 0; sh < 16; sh++) {
+                const uint32_t vh = sh ? __builtin_amdgcn_alignbit(c0, c1, (32 - 2 * sh) & 31) : c0;
+                const uint32_t vl = sh ? __builtin_amdgcn_alignbit(c1, c2, (32 - 2 * sh) & 31) : c1;
+                uint64_t xt = (uint64_t(vh) << 32) | vl;  // left-aligned, 17 <= k <= 32
+                if (canonical) {
+                    const uint64_t K = xt >> (64 - 2 * k);
+                    uint64_t R = __brevll(K);
+                    R = ((R >> 1) & 0x5555555555555555ull) | ((R & 0x5555555555555555ull) << 1);
+                    R = (R >> (64 - 2 * k)) ^ (0xAAAAAAAAAAAAAAAAull & kmask);
+                    xt = (R < K ? R : K) << (64 - 2 * k);
+                }
+                uint32_t h = h0;
+                for (uint32_t b = 0; b < k4; b += 4) {
+                    h = r4(h, s_t4[uint32_t(xt >> 56)]);
+                    xt <<= 8;
+                }
+                if (krem) h = rrem(h, s_t4[uint32_t(xt >> 56)]);
+                hs[sh] = h;
+            }
+        }
+#pragma unroll
+        for (int sh = 0; sh < 16; sh++)
+            if ((ok >> (15 - sh)) & 1u) emit(hs[sh]);
     }
+    }  // tiles
 }
 
 // One workgroup per listed sequence: bitonic sort of <= SORT_CAP candidates in LDS,
@@ -638,12 +716,16 @@ static int mash_sketch_view(dvs_ctx *ctx, const dvs_seq_view &sv, const uint64_t
             hi[q] = tv >= 4294967295.0L ? 0xFFFFFFFFu : uint32_t(tv);
         }
         coff[q + 1] = coff[q] + cap[q];
-        for (uint64_t b = 0; b < w; b += MASH_TILE) {
+        // (every tile but a sequence's first begins on a packed word -- an absolute position that is a
+        // multiple of 16 -- and a full tile ends on one: its windows are exactly 512 groups of sixteen, two
+        // rounds of the DNA kernel's 256 lanes with no straggler)
+        for (uint64_t b = 0; b < w;) {
             MTile t;
             t.begin = offsets[q] + b;
-            t.count = uint32_t(std::min<uint64_t>(MASH_TILE, w - b));
+            t.count = uint32_t(std::min<uint64_t>(MASH_TILE - (t.begin & 15), w - b));
             t.seq = q;
             tiles.push_back(t);
+            b += t.count;
         }
     }
     DevBuf d_tiles, d_lo, d_hi, d_cap, d_coff, d_cnt, d_active, d_cand, d_list, d_status;
@@ -701,9 +783,11 @@ static int mash_sketch_view(dvs_ctx *ctx, const dvs_seq_view &sv, const uint64_t
                 const long double frac = ((long double)hi[q] - (long double)lo[q]) / 4294967296.0L;
                 if (frac * MASH_TILE > 512.0L) small = false;
             }
+            // (sixteen workgroups' worth of tiles per CU at most: every workgroup loops over its share)
+            const uint32_t dna_grid = uint32_t(std::min<size_t>(tiles.size(), size_t(ctx->n_cu) * 16));
 #define DVS_LAUNCH_DNA(K16, TBLW, PKD)                                                                         \
-    hipLaunchKernelGGL((hash_filter_dna_kernel<K16, TBLW, PKD>), dim3(uint32_t(tiles.size())), dim3(MASH_THREADS), 0, \
-                       ctx->stream, d_seqs, d_pmask, nbytes, d_tiles.as<MTile>(), k, mash_canonical, d_lo.as<long long>(), \
+    hipLaunchKernelGGL((hash_filter_dna_kernel<K16, TBLW, PKD>), dim3(dna_grid), dim3(MASH_THREADS), 0, \
+                       ctx->stream, d_seqs, d_pmask, nbytes, d_tiles.as<MTile>(), uint32_t(tiles.size()), k, mash_canonical, d_lo.as<long long>(), \
                        d_hi.as<uint32_t>(), d_active.as<uint8_t>(), d_cand.as<uint32_t>(), d_coff.as<uint64_t>(), \
                        d_cap.as<uint32_t>(), d_cnt.as<uint32_t>())
 #define DVS_LAUNCH_DNA_ANY(PKD)                                  \

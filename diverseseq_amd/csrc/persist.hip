@@ -802,6 +802,11 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     // candidate's row, its frequencies, this workgroup's leave-one-out job) are taken while the window's
     // rendezvous is still completing (see the event loop)
     constexpr bool SPEC = CACHED && !MAXM && sizeof(T) <= 4;
+    // SPEC_BIG: the same idea for count rows that do not fit the register cache (4^7 bins and beyond): this
+    // workgroup's leave-one-out job for the candidate the event record names is worked out while the
+    // rendezvous completes -- at 4^7 bins a job is sixteen bins a thread in f64 plus 2 x 32 KB of counts from
+    // L2, 6 us that used to follow the release
+    constexpr bool SPEC_BIG = !CACHED && !MAXM && sizeof(T) <= 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint64_t B0 = d.B;
     const uint64_t B = B0;  // (the event loop below takes its own, laundered copy)
@@ -1321,6 +1326,108 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 }
             }
         };
+        // the same job for rows beyond the register cache: candidate q (its counts at rq, total tq) as member
+        // n_ - 1 of the new order; member r's replica arrays at index `at`.  Eight chunks at a time: sixteen loads
+        // in flight per thread, then the bins WITHOUT a test inside (the job's kind is the workgroup's; as tests
+        // and branches per bin, and with four chunks a time, a job of sixteen chunks at 4^7 bins took 8.6 us) and
+        // their logarithms in three passes (all table reads together).  A term that is zero is multiplied out
+        // (log2_tab of a tiny number is finite).
+        [[maybe_unused]] auto big_job = [&](uint32_t r, uint32_t part_i, uint32_t at, uint32_t n_, const T *rq, double tq,
+                                            double rtq, double &th, double &ts) {
+            const double dn_ = double(n_), rn_ = 1.0 / dn_, rdiv_ = 1.0 / (dn_ - 1.0);
+            const bool is_new = r == n_ - 1;
+            const bool need_m = r < n_ && !is_new;
+            const T *mrow = mat + (need_m ? s_pos[at] : 0) * B;
+            const double mtot = need_m ? s_tot[at] : 1.0, mrt = need_m ? s_rt[at] : 1.0;
+            double h = 0.0, sv = 0.0;
+            constexpr int NQ = sizeof(T) <= 4 ? 8 : 4;
+            for (uint32_t c0 = part_i; c0 < nchunk; c0 += NQ * K) {
+                T cv[NQ], mv[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const uint64_t i = uint64_t(c0 + q * K) * P_THREADS + tid;
+                    if (c0 + q * K < nchunk && i < B) {
+                        cv[q] = rq[i];
+                        if (need_m) mv[q] = mrow[i];
+                    }
+                }
+                double u[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const uint64_t i = uint64_t(c0 + q * K) * P_THREADS + tid;
+                    u[q] = 0.0;
+                    if (c0 + q * K < nchunk && i < B) {
+                        double v = sl[i];
+                        if (v <= DVS_EPS) v = 0.0;
+                        const double f = count_freq_x(cv[q], tq, rtq);
+                        u[q] = v + f;  // S' of the bin
+                    }
+                }
+                if (r == n_) {  // the whole set
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) u[q] = fmax(u[q] * rn_, 0.0);
+                } else if (is_new) {  // without the new member itself
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) {
+                        const uint64_t i = uint64_t(c0 + q * K) * P_THREADS + tid;
+                        if (c0 + q * K < nchunk && i < B) {
+                            double x = (u[q] - count_freq_x(cv[q], tq, rtq)) * rdiv_;
+                            if (x <= DVS_EPS) x = 0.0;
+                            u[q] = x;
+                        }
+                    }
+                } else {  // without member r
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) {
+                        const uint64_t i = uint64_t(c0 + q * K) * P_THREADS + tid;
+                        if (c0 + q * K < nchunk && i < B) {
+                            double x = (u[q] - count_freq_x(mv[q], mtot, mrt)) * rdiv_;
+                            if (x <= DVS_EPS) x = 0.0;
+                            u[q] = x;
+                        }
+                    }
+                }
+                double mnt[NQ];
+                int ex[NQ];
+                double2 tb[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const double x = fmax(u[q], 1e-300);
+                    mnt[q] = __builtin_amdgcn_frexp_mant(x);
+                    ex[q] = __builtin_amdgcn_frexp_exp(x);
+                    tb[q] = s_ltab[(uint32_t(__double2hiint(mnt[q])) >> 13) & 127u];
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const double r_ = fma(mnt[q], tb[q].y, -1.0);
+                    double pl = 1.0 / 7.0;
+                    pl = fma(pl, r_, -1.0 / 6.0);
+                    pl = fma(pl, r_, 1.0 / 5.0);
+                    pl = fma(pl, r_, -1.0 / 4.0);
+                    pl = fma(pl, r_, 1.0 / 3.0);
+                    pl = fma(pl, r_, -1.0 / 2.0);
+                    pl = fma(pl, r_, 1.0);
+                    const double lg = fma(pl * r_, 1.4426950408889634, double(ex[q]) + tb[q].x);
+                    h -= u[q] * lg;
+                    sv += u[q];
+                }
+            }
+            h = dvs_wave_sum_dpp(h);
+            sv = dvs_wave_sum_dpp(sv);
+            __syncthreads();  // (scratch[64..] of an earlier use has been read)
+            if (lane == 0) {
+                scratch[64 + wave] = h;
+                scratch[80 + wave] = sv;
+            }
+            __syncthreads();
+            th = ts = 0.0;
+            if (tid < 8) {
+                for (uint32_t w = 0; w < P_THREADS / 64; w++) {
+                    th += scratch[64 + w];
+                    ts += scratch[80 + w];
+                }
+            }
+        };
         if constexpr (SPEC) {
             const uint64_t guess = p_ev_pos(__hip_atomic_load(evp, RLX_AGENT));
             if (guess != SEL_NONE) fetch_raw(guess);  // (per wave: whatever it saw when it left the scan)
@@ -1370,6 +1477,17 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                             small_job(r, blockIdx.x % K, r < st.li ? r : r + 1, st.n, spec_th, spec_ts);
                             spec_job_pos = seen;
                         }
+                        worked = true;
+                    }
+                }
+                if constexpr (SPEC_BIG) {
+                    const uint64_t seen = p_ev_pos(hard_w);
+                    if (seen != SEL_NONE && seen != spec_job_pos && one_job && has_job && !lead && st.n < 128 &&
+                        (sync->no_coarse & 16u) == 0) {
+                        const uint32_t r = blockIdx.x / K;
+                        const double tq = double(d.totals[seen]);
+                        big_job(r, blockIdx.x % K, r < st.li ? r : r + 1, st.n, mat + seen * B, tq, 1.0 / tq, spec_th, spec_ts);
+                        spec_job_pos = seen;
                         worked = true;
                     }
                 }
@@ -2117,7 +2235,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // SPEC: a leave-one-out job worked out for this very candidate while the rendezvous was completing
         // goes out FIRST -- its memory-side additions travel while the member arrays are shifted below
         [[maybe_unused]] bool job_published = false;
-        if constexpr (SPEC) {
+        if constexpr (SPEC || SPEC_BIG) {
             if (one_job && has_job && !lead && spec_job_pos == p) {
                 if (tid < 8) {  // lane g adds the job's words to group g's replica
                     unsigned long long *dst = part + uint64_t(acc_slot) * 8 * (maxn + 1) * 2 +
@@ -2291,84 +2409,27 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                         bin(i, fr[j], fm);
                     }
                 }
-            } else {
-                const bool need_m = r < n && !is_new;
-                // Eight chunks at a time: sixteen loads in flight per thread, then the bins WITHOUT a test inside
-                // (the job's kind is the workgroup's; as tests and branches per bin, and with four chunks a time,
-                // a job of sixteen chunks at 4^7 bins took 8.6 us) and their logarithms in three passes (all table
-                // reads together).  A term that is zero is multiplied out (log2_tab of a tiny number is finite).
-                constexpr int NQ = sizeof(T) <= 4 ? 8 : 4;
-                for (uint32_t c0 = part_i; c0 < nchunk; c0 += NQ * K) {
-                    T cv[NQ], mv[NQ];
-#pragma unroll
-                    for (int q = 0; q < NQ; q++) {
-                        const uint64_t i = uint64_t(c0 + q * K) * P_THREADS + tid;
-                        if (c0 + q * K < nchunk && i < B) {
-                            cv[q] = rp[i];
-                            if (need_m) mv[q] = mrow[i];
-                        }
-                    }
-                    double u[NQ];
-#pragma unroll
-                    for (int q = 0; q < NQ; q++) {
-                        const uint64_t i = uint64_t(c0 + q * K) * P_THREADS + tid;
-                        u[q] = 0.0;
-                        if (c0 + q * K < nchunk && i < B) {
-                            double v = sl[i];
-                            if (v <= DVS_EPS) v = 0.0;
-                            const double f = count_freq_x(cv[q], tot, rtot);
-                            u[q] = v + f;  // S' of the bin
-                        }
-                    }
-                    if (r == n) {  // the whole set
-#pragma unroll
-                        for (int q = 0; q < NQ; q++) u[q] = fmax(u[q] * rn, 0.0);
-                    } else if (is_new) {  // without the new member itself
-#pragma unroll
-                        for (int q = 0; q < NQ; q++) {
-                            const uint64_t i = uint64_t(c0 + q * K) * P_THREADS + tid;
-                            if (c0 + q * K < nchunk && i < B) {
-                                double x = (u[q] - count_freq_x(cv[q], tot, rtot)) * rdiv;
-                                if (x <= DVS_EPS) x = 0.0;
-                                u[q] = x;
-                            }
-                        }
-                    } else {  // without member r
-#pragma unroll
-                        for (int q = 0; q < NQ; q++) {
-                            const uint64_t i = uint64_t(c0 + q * K) * P_THREADS + tid;
-                            if (c0 + q * K < nchunk && i < B) {
-                                double x = (u[q] - count_freq_x(mv[q], mtot, mrt)) * rdiv;
-                                if (x <= DVS_EPS) x = 0.0;
-                                u[q] = x;
-                            }
-                        }
-                    }
-                    double mnt[NQ];
-                    int ex[NQ];
-                    double2 tb[NQ];
-#pragma unroll
-                    for (int q = 0; q < NQ; q++) {
-                        const double x = fmax(u[q], 1e-300);
-                        mnt[q] = __builtin_amdgcn_frexp_mant(x);
-                        ex[q] = __builtin_amdgcn_frexp_exp(x);
-                        tb[q] = s_ltab[(uint32_t(__double2hiint(mnt[q])) >> 13) & 127u];
-                    }
-#pragma unroll
-                    for (int q = 0; q < NQ; q++) {
-                        const double r_ = fma(mnt[q], tb[q].y, -1.0);
-                        double pl = 1.0 / 7.0;
-                        pl = fma(pl, r_, -1.0 / 6.0);
-                        pl = fma(pl, r_, 1.0 / 5.0);
-                        pl = fma(pl, r_, -1.0 / 4.0);
-                        pl = fma(pl, r_, 1.0 / 3.0);
-                        pl = fma(pl, r_, -1.0 / 2.0);
-                        pl = fma(pl, r_, 1.0);
-                        const double lg = fma(pl * r_, 1.4426950408889634, double(ex[q]) + tb[q].x);
-                        h -= u[q] * lg;
-                        sv += u[q];
-                    }
+            } else if constexpr (SPEC_BIG) {
+                // (the workgroup's one job may already be there, worked out for this very candidate while
+                // the rendezvous was completing)
+                if (job_published) continue;
+                double th, ts;
+                big_job(r, part_i, r, n, rp, tot, rtot, th, ts);
+                if (tid < 8) {  // lane g adds the job's words to group g's replica
+                    unsigned long long *dst = acc_all + (uint64_t(tid) * (maxn + 1) + r) * 2;
+                    p_acc_add(dst, th, ts);
                 }
+                first_job = false;
+                continue;
+            } else {
+                double th, ts;  // (frequency rows beyond the register cache: chunk-merge matrices of 4^7 bins)
+                big_job(r, part_i, r, n, rp, tot, rtot, th, ts);
+                if (tid < 8) {
+                    unsigned long long *dst = acc_all + (uint64_t(tid) * (maxn + 1) + r) * 2;
+                    p_acc_add(dst, th, ts);
+                }
+                first_job = false;
+                continue;
             }
             h = dvs_wave_sum_dpp(h);
             sv = dvs_wave_sum_dpp(sv);
@@ -2692,7 +2753,8 @@ static int persist_prepare(dvs_ctx *ctx, dvs_select *s, uint32_t head_stop, hipS
     if (ctx->knobs.persist_wg_scale > 0.0) init.wg_scale = float(ctx->knobs.persist_wg_scale);
     init.no_coarse = (ctx->knobs.persist_no_coarse ? 1u : 0u) | (ctx->knobs.persist_no_events ? 2u : 0u) |
                      (ctx->knobs.persist_no_burst_drop ? 8u : 0u) |
-                     (ctx->knobs.persist_no_speculation ? 16u : 0u);  // (nothing is worked out ahead of the release)
+                     (ctx->knobs.persist_no_speculation ? 16u : 0u) |  // (nothing is worked out ahead of the release)
+                     0u;
     init.small_rows = s->persist_small ? s->persist_small_rows : 0u;
     DVS_HIP(ctx, hipMemcpyAsync(head_stop ? s->psync_head : s->psync, &init, sizeof init, hipMemcpyHostToDevice, on));
     DVS_HIP(ctx, hipMemsetAsync(head_stop ? s->ppart_head : s->ppart, 0, p_acc_bytes(s->persist_maxn), on));
