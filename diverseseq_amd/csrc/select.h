@@ -4,6 +4,7 @@
 #include "dvs_internal.h"
 
 #define SEL_NONE 0xFFFFFFFFFFFFFFFFull
+#define SEL_SEEDS_AT 512  // byte offset of the seed list inside the 4 KiB control allocation (and its pinned mirror)
 
 enum : uint32_t { SEL_RUN = 0, SEL_DONE = 1, SEL_ARBITER = 2, SEL_ERROR = 3,
                   SEL_NEED_SETUP = 4 };  // a seeded persistent launch left the initial set to the set-up kernels
@@ -124,6 +125,10 @@ struct dvs_select {
     bool used_side_streams = false;   // work of this selection was queued on ctx->stream_head / stream2 (sel_free waits)
     hipEvent_t ev_side_done = nullptr;  // the set-up kernels on the context's second stream have run
     void *d_seed_list = nullptr;  // the seed positions on the device (kept until the selection goes: two streams read it)
+    bool seed_list_in_ctl = false;  // ... inside the control allocation, behind the control block (one upload for both)
+    bool inset_clean = false;       // the label flags are still as they were cleared at allocation time
+    hipStream_t setup_side = nullptr;  // the side stream the set-up goes to (NULL: the context's stream), sel_plan_setup_stream
+    bool head_phase = false;           // ... and whether the engine starts with a head phase on the head CUs
     int batch = 16;
     // timing
     bool time_scan = false;

@@ -1040,7 +1040,7 @@ static void sel_free(dvs_select *s) {
     dvs_dev_free(s->ctx, s->ppart);
     dvs_dev_free(s->ctx, s->psync_head);
     dvs_dev_free(s->ctx, s->ppart_head);
-    dvs_dev_free(s->ctx, s->d_seed_list);
+    if (!s->seed_list_in_ctl) dvs_dev_free(s->ctx, s->d_seed_list);
     if (s->ev_side_done) dvs_event_put(s->ctx, s->ev_side_done);
     dvs_select_arbiter_free(s);
     dvs_ctx_release(s->ctx);
@@ -1296,28 +1296,33 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
     }
 }
 
-template <typename T>
-static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat) {
-    // When the rest of the matrix is still being built on the context's stream (a split build,
-    // kmer_hist.hip: the head rows are finished, the host has their totals), the set-up kernels of the
-    // selection -- which read only the seed rows -- go to the second stream and run beside that launch
-    // instead of queueing behind it; the engine itself is launched on the first stream behind both.
-    hipStream_t side = nullptr;
-    bool head_phase = false;
+// The stream a selection's set-up (control block, seed list, set-up kernels) goes to, decided once per
+// selection (the label flags are cleared on it ahead of time).  When the rest of the matrix is still being
+// built on the context's stream (a split build, kmer_hist.hip: the head rows are finished, the host has their
+// totals), the set-up -- which reads only the seed rows -- goes to a side stream and runs beside that launch
+// instead of queueing behind it; the engine itself is launched on the first stream behind both.
+// HEAD PHASE: that launch runs on the context's stream_rest and leaves the head CUs alone (CU split), so the
+// persistent engine starts on them right behind the set-up and walks the rows that are already built -- the
+// event-dense head of the stream, a chain of hand-overs that needs no more than a few workgroups -- while
+// the histogram runs; the launch over the full grid then carries on from the state it mirrors.  (nmost; a
+// set whose leave-one-out jobs fit the head grid one per workgroup.)
+static void sel_plan_setup_stream(dvs_ctx *ctx, dvs_select *s) {
+    s->setup_side = nullptr;
+    s->head_phase = false;
     if (s->mat->head_rows_built && s->params.n_seed <= s->mat->head_rows_built && s->h_order.empty() &&
         !(s->params.flags & DVS_SELECT_STEPWISE) && !ctx->knobs.no_side_stream) {
-        // HEAD PHASE: that launch runs on the context's stream_rest and leaves the head CUs alone (CU
-        // split), so the persistent engine starts on them right behind the set-up kernels and walks
-        // the rows that are already built -- the event-dense head of the stream, a chain of
-        // hand-overs that needs no more than a few workgroups -- while the histogram runs; the launch
-        // over the full grid then carries on from the state it mirrors.  (nmost; a set whose
-        // leave-one-out jobs fit the head grid one per workgroup.)
-        head_phase = s->mat->rest_beside_head && ctx->stream_head && s->persist &&
-                     s->params.mode == DVS_MODE_NMOST && s->params.window == 0 &&
-                     s->cap + 2 <= uint32_t(ctx->head_cus) && s->npos > 4ull * s->mat->head_rows_built &&
-                     s->params.n_seed + 64 <= s->mat->head_rows_built && !ctx->knobs.no_head_phase;
-        side = head_phase ? ctx->stream_head : dvs_ctx_stream2(ctx);
+        s->head_phase = s->mat->rest_beside_head && ctx->stream_head && s->persist &&
+                        s->params.mode == DVS_MODE_NMOST && s->params.window == 0 &&
+                        s->cap + 2 <= uint32_t(ctx->head_cus) && s->npos > 4ull * s->mat->head_rows_built &&
+                        s->params.n_seed + 64 <= s->mat->head_rows_built && !ctx->knobs.no_head_phase;
+        s->setup_side = s->head_phase ? ctx->stream_head : dvs_ctx_stream2(ctx);
     }
+}
+
+template <typename T>
+static int sel_start(dvs_ctx *ctx, dvs_select *s, const T *mat) {
+    hipStream_t side = s->setup_side;
+    const bool head_phase = s->head_phase;
     hipStream_t st = side ? side : ctx->stream;
     if (side) s->used_side_streams = true;
     int rc = sel_seed<T>(ctx, s, mat, st, s->seeded_start);
@@ -1366,15 +1371,23 @@ static int sel_seed(dvs_ctx *ctx, dvs_select *s, const T *mat, hipStream_t st, b
     // (the control block travels through the pinned mirror: a pageable source would have to stay
     // alive until the copy has been performed)
     *s->h_ctl = c;
-    DVS_HIP(ctx, hipMemsetAsync(d.inset, 0, std::max<size_t>(d.nlabels, 1), st));
-    DVS_HIP(ctx, hipMemcpyAsync(d.ctl, s->h_ctl, sizeof c, hipMemcpyHostToDevice, st));
+    // (a restart, or a start on another stream than the planned one: the flags are cleared here)
+    if (!s->inset_clean || st != (s->setup_side ? s->setup_side : ctx->stream))
+        DVS_HIP(ctx, hipMemsetAsync(d.inset, 0, std::max<size_t>(d.nlabels, 1), st));
+    s->inset_clean = false;
     if (!s->d_seed_list) {
         int rc0 = dvs_dev_alloc(ctx, &s->d_seed_list, seeds.size() * sizeof(uint64_t), "seed list");
         if (rc0) return rc0;
     }
     uint64_t *d_seed = static_cast<uint64_t *>(s->d_seed_list);
-    DVS_HIP(ctx, hipMemcpyAsync(d_seed, seeds.data(), seeds.size() * sizeof(uint64_t),
-                                hipMemcpyHostToDevice, st));
+    if (s->seed_list_in_ctl) {  // control block + seed list: one block, one copy
+        std::memcpy(reinterpret_cast<unsigned char *>(s->h_ctl) + SEL_SEEDS_AT, seeds.data(), seeds.size() * sizeof(uint64_t));
+        DVS_HIP(ctx, hipMemcpyAsync(d.ctl, s->h_ctl, SEL_SEEDS_AT + seeds.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    } else {
+        DVS_HIP(ctx, hipMemcpyAsync(d.ctl, s->h_ctl, sizeof c, hipMemcpyHostToDevice, st));
+        DVS_HIP(ctx, hipMemcpyAsync(d_seed, seeds.data(), seeds.size() * sizeof(uint64_t),
+                                    hipMemcpyHostToDevice, st));
+    }
     if (light) {
         DVS_HIP(ctx, hipGetLastError());
         return DVS_OK;
@@ -1516,7 +1529,9 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
             return rc__;                                             \
         }                                                            \
     } while (0)
-    SEL_ALLOC(d.ctl, sizeof(SelCtl));
+    // (the control block and, behind it, the seed list: ONE upload per selection, sel_seed)
+    static_assert(sizeof(SelCtl) <= SEL_SEEDS_AT, "the seed list starts behind the control block");
+    SEL_ALLOC(d.ctl, 4096);
     SEL_ALLOC(d.S, B * 8);
     SEL_ALLOC(d.Stmp, B * 8);
     SEL_ALLOC(d.base, B * 8);
@@ -1552,6 +1567,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     }
 #undef SEL_ALLOC
     SEL_HIP(hipMemsetAsync(d.wg_rows, 0, size_t(s->scan_grid) * 8, ctx->stream));
+
     static_assert(sizeof(SelCtl) <= 4096, "control block must fit a cached pinned block");
     {
         int prc = dvs_pinned_get(ctx, (void **)&s->h_ctl);
@@ -1568,6 +1584,13 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
             return prc;
         }
     }
+    // The label flags are cleared NOW, on the stream the set-up will use (same stream: ordered in front of
+    // everything that sets one): nothing about them depends on the seeds, so the fill runs while the matrix's
+    // head rows are still being built, not between the host's wake-up and the first launch.
+    sel_plan_setup_stream(ctx, s);
+    if (s->setup_side) s->used_side_streams = true;
+    SEL_HIP(hipMemsetAsync(d.inset, 0, std::max<size_t>(nlabels, 1), s->setup_side ? s->setup_side : ctx->stream));
+    s->inset_clean = true;
     // SEEDED start (persist.hip): an nmost selection whose state fits the persistent kernel's register
     // cache is begun by that kernel itself -- S, the entropy sum, the leave-one-out pass and the first
     // lowest member from nothing but the seed positions -- instead of four launches in front of it
@@ -1577,7 +1600,10 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     s->seeded_start = s->persist && params->mode == DVS_MODE_NMOST && B <= 4096 && !order && !labels &&
                       !(s->params.flags & DVS_SELECT_STEPWISE) && n_seed >= 2 && (n_seed <= 32 || ctx->knobs.persist_seeded_any) && !ctx->knobs.persist_no_seeded;
     s->persist_seeded = s->seeded_start;
-    if (s->seeded_start) {
+    if (size_t(n_seed) * sizeof(uint64_t) <= 4096 - SEL_SEEDS_AT) {
+        s->d_seed_list = reinterpret_cast<unsigned char *>(d.ctl) + SEL_SEEDS_AT;
+        s->seed_list_in_ctl = true;
+    } else if (s->seeded_start) {
         int arc = dvs_dev_alloc(ctx, &s->d_seed_list, size_t(n_seed) * sizeof(uint64_t), "seed list");
         if (arc) {
             sel_free(s);
