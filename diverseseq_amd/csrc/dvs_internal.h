@@ -270,6 +270,20 @@ __device__ __forceinline__ double dvs_wave_min(double v) {
     for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
     return v;
 }
+// the same minimum by DPP (the minimum does not depend on the order it is taken in: the same bits)
+__device__ __forceinline__ double dvs_wave_min_dpp(double v) {
+    v = fmin(v, dvs_dpp_mov<0xB1>(v));
+    v = fmin(v, dvs_dpp_mov<0x4E>(v));
+    v = fmin(v, dvs_dpp_mov<0x141>(v));
+    v = fmin(v, dvs_dpp_mov<0x140>(v));
+    const long long b = __double_as_longlong(v);
+    const int lo = int(b), hi = int(b >> 32);
+    auto row = [&](int l) {
+        return __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, l) << 32) |
+                                                (unsigned)__builtin_amdgcn_readlane(lo, l)));
+    };
+    return fmin(fmin(row(0), row(16)), fmin(row(32), row(48)));
+}
 __device__ __forceinline__ unsigned long long dvs_wave_sum_u64(unsigned long long v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

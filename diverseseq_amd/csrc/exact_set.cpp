@@ -19,6 +19,8 @@
 
 #include "select.h"
 
+#include <cstddef>
+
 unsigned dvs_host_threads();  // pack.hip: host cores this process may use (cgroup quota respected), at most 16
 
 namespace {
@@ -356,12 +358,18 @@ int fetch_dev_row(dvs_ctx *ctx, const dvs_select *s, uint64_t p, const double *d
 // second time (same answer, twice the work; found by repeating one selection 600 times,
 // scripts/micro/c4_repeat.py).
 int write_forced(dvs_ctx *ctx, dvs_select *s, uint32_t forced, uint32_t forced_lowest) {
+    // status, arb_stage, forced and forced_lowest are neighbours in the control block: one copy on the selection's
+    // own stream from the pinned mirror (the host has just read it; arb_stage goes back as it came), and a wait
+    // for THAT stream -- the kernels launched behind this call see the decision, and nothing else on the device
+    // (a histogram on the side stream, another stream's collective) is waited for
+    static_assert(offsetof(SelCtl, forced_lowest) - offsetof(SelCtl, status) == 12, "status .. forced_lowest are contiguous");
     SelCtl *d = s->dev.ctl;
-    const uint32_t run = SEL_RUN;
-    DVS_HIP(ctx, hipMemcpy(&d->forced, &forced, 4, hipMemcpyHostToDevice));
-    DVS_HIP(ctx, hipMemcpy(&d->forced_lowest, &forced_lowest, 4, hipMemcpyHostToDevice));
-    DVS_HIP(ctx, hipMemcpy(&d->status, &run, 4, hipMemcpyHostToDevice));
-    DVS_HIP(ctx, hipDeviceSynchronize());
+    SelCtl *h = s->h_ctl;
+    h->status = SEL_RUN;
+    h->forced = forced;
+    h->forced_lowest = forced_lowest;
+    DVS_HIP(ctx, hipMemcpyAsync(&d->status, &h->status, 16, hipMemcpyHostToDevice, ctx->stream));
+    DVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return DVS_OK;
 }
 

@@ -26,17 +26,29 @@
 // inside the rounding band stops the kernel with SEL_ARBITER; the host arbitrates and
 // runs that one event through the multi-launch kernels, then relaunches this one.
 //
-// Inter-workgroup protocol (MI355X: 8 XCDs, private L2s).  Nothing a workgroup stores
-// with plain stores is read by another workgroup during the launch: the matrix, totals
-// and row entropies are read-only (a member's frequency row is re-derived from its matrix
-// row, whose position every workgroup keeps in LDS), the set state is replicated, and the
-// only words that cross workgroups -- the event words and the leave-one-out partials --
-// are agent-scope atomics whose RMW result the writer consumes before it arrives at the
-// barrier.  So the barrier needs no fences (no L2 write-back / invalidate), only a
-// rendezvous: two-level monotonic arrival counters (per group of blockIdx % 8, then one
-// top counter) and a generation word per group, all on their own cache lines, zeroed by
-// the host before every launch; every spin is bounded (a grid that is not fully resident
-// ends with SEL_ERROR instead of hanging).
+// Inter-workgroup protocol (MI355X: 8 XCDs, private L2s; written down in DESIGN.md 4.3c).  Nothing a
+// workgroup stores with plain stores is read by another workgroup during the launch: the matrix, totals
+// and row entropies are read-only (a member's frequency row is re-derived from its matrix row, whose
+// position every workgroup keeps in LDS) and the set state is replicated.  What crosses workgroups are
+// single 64-bit words, read and written with relaxed agent-scope atomics, and every one of them carries
+// in itself what a reader needs to know that it is the word it is waiting for -- no word's meaning depends
+// on the order in which stores to two different addresses become visible:
+//   * WINDOW words carry the window's number in their top bits (p_word).  A workgroup that has scanned its
+//     share stores ONE arrival record (its first event, how many near-threshold candidates it listed); the
+//     mirror block, which scans nothing, polls the records, and when all carry the window's number stores
+//     the release word (the window's first event) to eight copies that the others poll.  Events found
+//     early also go, by atomicMin, to a hint word beside the release word so that waves can stop scanning
+//     rows behind them; a newer window's tag is SMALLER, so a straggler of an older window never wins, and
+//     nothing is ever cleared.  The outcome never depends on a hint: a wave only skips rows behind a hint
+//     of the current window, and whoever posted that hint has the same event in its record.
+//   * LEAVE-ONE-OUT sums are added to monotonic accumulators (fixed point + a contribution count in the low
+//     bits, p_acc_word) that are never cleared: every workgroup remembers the totals it read at the previous
+//     use (LDS) and takes the difference; the count's difference says when the K contributions are in.
+// The counter barrier below (grid_barrier) is a pure rendezvous for the few places that still want one (the
+// seeded start, `max` batches): two-level monotonic arrival counters (per group of blockIdx % 8, then one
+// top counter) and a generation word per group, all on their own cache lines, zeroed by the host before
+// every launch; every spin is bounded (a grid that is not fully resident ends with SEL_ERROR instead of
+// hanging).
 #include "select_dev.h"
 
 #include <algorithm>
@@ -52,7 +64,7 @@ constexpr int P_J = 8;                      // bins per thread kept in registers
 constexpr int P_CH = 16;                    // row chunks requested per burst (4096 bins)
 constexpr uint32_t P_MAXN = 512;            // members the LDS replica holds when 4^k <= 4096 ...
 constexpr uint32_t P_MAXN_BIG = 256;        // ... and beyond (k = 7: 128 KB of LDS go to the set state)
-constexpr uint32_t P_MAXN_MAX = 1024;       // ... `max` with 4^k <= 4096 (sets grow; nmost's scan loop pays for the constant in scratch)
+constexpr uint32_t P_MAXN_MAX = 896;        // ... `max` with 4^k <= 4096 (sets grow; what 160 KB of LDS hold beside S, sl and the batches)
 constexpr uint32_t p_maxn(bool cached, bool maxm = false) { return cached ? (maxm ? P_MAXN_MAX : P_MAXN) : P_MAXN_BIG; }
 // SMALL sets (nmost over 16-bit count rows of 4096 bins): the members' count rows live in every
 // workgroup's LDS (see the kernel)
@@ -60,39 +72,35 @@ constexpr uint32_t P_SMALLN = 16;      // members the replica arrays of a SMALL 
 constexpr uint32_t P_SMALL_ROWS = 13;  // ... and rows (8 KB each) that fit beside the state in 160 KB of LDS
 // leave-one-out jobs per event: (n + 1) * K <= max(G - 1, n + 1) <= maxn + 1 (G <= maxn + 2 is checked)
 constexpr uint32_t p_maxjobs(bool cached, bool maxm = false) { return p_maxn(cached, maxm) + 1; }
-// leave-one-out accumulators: P_ACC_SLOTS slots (accept % P_ACC_SLOTS) x 8 group replicas x (maxn + 1) members x
-// 2 words.  Sixteen slots, not three: a slot is cleared (plain stores by the mirror block) EIGHT accepts before
-// it is used again -- tens of microseconds, where a clear one accept ahead had to be verified before the
-// next rendezvous (1600 memory-side round trips at n = 100 behind the mirror block's own 256 KB of stores:
-// +1.3 us per accept) or, unverified, lost a race now and then.  The readers check contribution counts
-// (p_acc_complete), so a clear that did come too late would end in a time-out, not in a wrong total.
-constexpr uint32_t P_ACC_SLOTS = 16;
-constexpr size_t p_acc_bytes(uint32_t maxn) { return size_t(P_ACC_SLOTS) * 8 * (maxn + 1) * 2 * sizeof(unsigned long long); }
-// A leave-one-out accumulator word = (2^-50 fixed-point sum << 6) + number of contributions: a
-// reader that finds the count at K knows the sum is complete -- no barrier between the jobs and
-// the workgroups that need their totals.  Sums of such words add sums and counts independently
-// (two's complement, counts <= 32 < 64); |sum| < 64 keeps the word inside 63 bits.
+// leave-one-out accumulators: 8 group replicas x (maxn + 1) members x 2 words, zeroed by the host before the
+// launch and never cleared again.  A word = (2^-50 fixed-point sum << 6) + number of contributions, added to
+// by every job of every use; a reader keeps the totals it read at the previous use (LDS, p_prev) and works
+// with the DIFFERENCE: its low six bits are the contributions of this use -- complete at K -- and the rest
+// is their sum (two's complement: wrap-around cancels in the difference; |sum| < 64 per use and K <= 32
+// keep one use inside the word).  Integer addition is associative, so the totals do not depend on the order
+// the jobs arrive in; nothing is ever reset, so there is no clear that a late add could race with, and an
+// add can never be mistaken for one of an earlier use: the earlier use was complete, in every replica,
+// when it was read (each job adds the same word to all eight replicas).
+constexpr size_t p_acc_bytes(uint32_t maxn) { return size_t(8) * (maxn + 1) * 2 * sizeof(unsigned long long); }
 __device__ __forceinline__ unsigned long long p_acc_word(double v) {
     return ((unsigned long long)__double2ll_rn(v * 0x1p50) << 6) + 1ull;
 }
 __device__ __forceinline__ double p_acc_value(unsigned long long w) { return double((long long)w >> 6) * 0x1p-50; }
-// A job's two words added to an accumulator pair: non-returning adds, merely SENT when the adding thread's
-// workgroup arrives at the next barrier (a returning atomic overtakes them now and then) -- which is why
-// every reader checks the contribution count in the words' low bits (p_acc_complete), barrier or not.
+// A job's two words added to an accumulator pair (non-returning adds: the readers wait for the counts)
 __device__ __forceinline__ void p_acc_add(unsigned long long *dst, double th, double ts) {
     atomicAdd(dst, p_acc_word(th));
     atomicAdd(dst + 1, p_acc_word(ts));
 }
 __device__ __forceinline__ uint32_t p_acc_count(unsigned long long w) { return uint32_t(w & 63ull); }
-// an accumulator word once all K contributions are in (bounded spin: ok = false on a time-out -- also what a
-// slot that was not cleared in time ends in: an error and the multi-launch kernels, never a wrong total)
-__device__ __forceinline__ unsigned long long p_acc_complete(const unsigned long long *w, uint32_t K, bool &ok) {
+// this use's share of an accumulator word once all K contributions are in: (total now) - (total at the previous
+// use, *prev, which is brought up to date).  Bounded spin: ok = false on a time-out (an error and the
+// multi-launch kernels, never a wrong total).
+__device__ __forceinline__ unsigned long long p_acc_complete(const unsigned long long *w, unsigned long long *prev,
+                                                             uint32_t K, bool &ok) {
+    const unsigned long long before = *prev;
     unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t spins = 0;
-#ifndef DVS_P_VERIFY_COUNTS
-#define DVS_P_VERIFY_COUNTS 1
-#endif
-    while (DVS_P_VERIFY_COUNTS && uint32_t(v & 63ull) != K) {
+    while (uint32_t((v - before) & 63ull) != K) {
         if (++spins > (1u << 20)) {
             ok = false;
             break;
@@ -100,14 +108,14 @@ __device__ __forceinline__ unsigned long long p_acc_complete(const unsigned long
         __builtin_amdgcn_s_sleep(1);
         v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    return v;
+    *prev = v;
+    return v - before;
 }
 constexpr uint32_t P_SPIN_LIMIT = 1u << 22;  // ~0.5 s of polling
-#ifndef DVS_P_FLAT_GRID
-#define DVS_P_FLAT_GRID 64
-#endif
-constexpr uint32_t P_FLAT_GRID = DVS_P_FLAT_GRID;  // grids of up to this many workgroups rendezvous on one counter
-constexpr uint32_t P_SOFT = 64;              // uncertain candidates listed per window (more become plain events)
+constexpr uint32_t P_MAXG = 256;             // workgroups a launch may have (one arrival record each)
+constexpr uint32_t P_FLAT_GRID = 64;         // counter barrier: grids of up to this many workgroups use one counter
+constexpr uint32_t P_WINWORDS = 64;          // LDS words of a window's bookkeeping (s_win)
+constexpr uint32_t P_LIST = 2;               // near-threshold candidates a workgroup lists per window (more become plain events)
 // MODE_MAX, growth phase: consecutive rows evaluated against the same set in one go (see the kernel)
 constexpr uint32_t P_BATCH = 32;             // rows per batch at most
 constexpr uint32_t P_BATCH_MEMBERS = 256;    // set size + 2 up to which batches are formed (4 members per lane)
@@ -118,12 +126,17 @@ struct PLine {  // a polled word on a cache line of its own (256 B apart)
     uint32_t v;
     uint32_t pad[63];
 };
+struct PRel {  // what a waiting workgroup polls with ONE 16-byte load, on a cache line of its own
+    unsigned long long rel;   // the release word of the current window: its first event (window word, below)
+    unsigned long long hint;  // events posted so far (atomicMin of window words; starts as all ones)
+    unsigned long long pad[30];
+};
 
 struct PSync {
-    uint32_t count;  // top-level arrivals (one per group and barrier), monotonic over the launch
+    uint32_t count;  // counter barrier: top-level arrivals (one per group and barrier), monotonic over the launch
     uint32_t pad0[63];
-    PLine gcount[8];  // arrivals of group g = blockIdx % 8 (workgroups are dealt round-robin to the 8 XCDs)
-    PLine ggen[8];    // completed barriers, one copy per group so 32 pollers share a line, not 256
+    PLine gcount[8];  // ... arrivals of group g = blockIdx % 8 (workgroups are dealt round-robin to the 8 XCDs)
+    PLine ggen[8];    // ... completed barriers, one copy per group so 32 pollers share a line, not 256
     uint32_t timeout;
     uint32_t wg_thresh;  // windows of up to wg_thresh rows per workgroup are scanned a row per WORKGROUP (0: never)
     float wg_scale;      // ... and are cursor * wg_scale / size rows long (rounded up to whole rounds)
@@ -132,17 +145,11 @@ struct PSync {
     uint32_t seeded;     // the set is still only its seed positions: the launch works the initial state out itself
     const unsigned long long *seed_list;  // ... those positions (ctl->size of them)
     uint32_t small_rows;  // SMALL instantiation: member rows the LDS replica has room for
-    uint32_t pad2[55];
-    // event records, slot = epoch % 3, one copy per group g = blockIdx % 8 on a cache line of its own (a
-    // wave polls before every row: one word for the whole grid serialises those loads at the memory
-    // side).  A record is 16 bytes that ONE load reads: ev[s][32 g] = {u32 generation of the rendezvous
-    // that ended the slot's window, u32 "candidates were listed" flag}, ev[s][32 g + 1] = the window's first
-    // event as (position << 1) | (1 if it is not a sure one) -- so the workgroup that sees the release
-    // has the window's outcome in the same round trip.
-    unsigned long long ev[3][8 * 32];
-    // candidates whose fast score is within FAST_BAND of the threshold: count at [s][0], positions
-    // from [s][8]; the workgroups re-evaluate them in f64 after the rendezvous, in stream order
-    unsigned long long soft[3][8 + 64];
+    uint32_t lds_bytes;   // the launch's dynamic LDS (a -DDVS_PERSIST_STAMPS build keeps its ticks in the last 128 bytes)
+    uint32_t pad2[54];
+    PRel rel[8];                            // one copy per group g = blockIdx % 8
+    unsigned long long wrec[P_MAXG];        // arrival record of every workgroup (a window word)
+    unsigned long long soft[P_MAXG][P_LIST];  // the candidates a workgroup listed in the current window (window words)
     unsigned long long dbg2[16];   // block 0 (owns a job): phase ticks
     unsigned long long dbg[16];    // mirror block: 100 MHz ticks per phase (scan, bar1, resolve, loo, bar2, finalize)
 };
@@ -153,7 +160,6 @@ struct PState {  // replicated scalars (identical in every workgroup)
     uint32_t n, li;
     double sumH, total_jsd, thr, band, wscale;
     uint32_t n_windows, n_events, n_accepts;
-    uint32_t n_loo;  // leave-one-out rounds of this launch (accumulator slot = n_loo % P_ACC_SLOTS)
     // MODE_MAX: the set grows while it is below max_size (tentative pushes, records.rs:427-451)
     uint32_t max_size, stat;
     double mean_d, std_d, cov_d;  // statistics of the current set's delta_jsd
@@ -161,26 +167,37 @@ struct PState {  // replicated scalars (identical in every workgroup)
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
+// ---- window words.  [63:40] tag = P_TAG0 - window number (a NEWER window has the SMALLER tag: an atomicMin
+// prefers it and a straggler of an older window can never replace it; all ones -- the hint words' initial
+// value -- and zero -- everything else's -- are no window's tag), [39:3] stream position (all ones: none),
+// [2:1] candidates listed (arrival record: how many this workgroup listed; release word: non-zero if anybody
+// did), [0] set when the event is not a sure one (its exact score decides).
+constexpr uint32_t P_TAG0 = 0xFFFFFEu;
+constexpr uint32_t P_EPOCH_MAX = 0xFFFFF0u;  // windows a launch may walk (it leaves with status RUN there)
+constexpr unsigned long long P_POS_NONE = (1ull << 37) - 1;
+__device__ __forceinline__ unsigned long long p_word(uint32_t epoch, uint64_t pos, bool sure) {
+    return ((unsigned long long)(P_TAG0 - epoch) << 40) | ((pos == SEL_NONE ? P_POS_NONE : pos) << 3) | (sure ? 0ull : 1ull);
+}
+__device__ __forceinline__ bool p_word_is(unsigned long long w, uint32_t epoch) { return uint32_t(w >> 40) == P_TAG0 - epoch; }
+// the position a word of window `epoch` names (SEL_NONE: none, or a word of another window)
+__device__ __forceinline__ uint64_t p_word_pos(unsigned long long w, uint32_t epoch) {
+    const unsigned long long pos = (w >> 3) & P_POS_NONE;
+    return (!p_word_is(w, epoch) || pos == P_POS_NONE) ? SEL_NONE : uint64_t(pos);
+}
+__device__ __forceinline__ bool p_word_sure(unsigned long long w) { return (w & 1ull) == 0; }
+__device__ __forceinline__ uint32_t p_word_listed(unsigned long long w) { return uint32_t(w >> 1) & 3u; }
+
 // returns false on timeout (every thread of the block gets the same answer).
 // Two levels: a workgroup arrives on its group's counter, the last of a group arrives on the top
 // counter, the last group publishes the generation to all eight group words.  Measured on MI355X
 // (scripts/micro/barrier_bench.hip, 256 workgroups): 1.9 us against 3.7 us for one counter + one
 // word -- the 256 same-address atomics serialise at ~11 ns each.
-// The barrier is a pure rendezvous: no fences.  Everything handed between workgroups across it
-// is an agent-scope atomic word whose RMW result the writer consumed before arriving (the event
-// words, the leave-one-out partials); the matrix is read-only for the whole launch, and what the
-// mirror block stores to global memory is read by nobody before the kernel ends.  (An agent-scope
-// release + acquire pair around the barrier -- L2 write-back and invalidate on every XCD -- cost
-// another 4 us per barrier.)
-// "Consumed" is meant literally: a non-returning atomic add or a plain atomic store that the writer merely
-// ISSUED before thread 0's arrival below (a returning atomic) is NOT necessarily performed when that
-// arrival comes back -- returns overtake the acknowledgements of earlier non-returning operations now and
-// then.  One selection in a hundred at 4^7 bins and n = 100 lost a leave-one-out partial that way (the reader
-// behind the barrier saw the accumulator without it; the sum check caught it and sent the argmin to the
-// arbiter, but total_jsd came from the same accumulators: scripts/micro/c4_repeat.py, 3000 repetitions of
-// one selection, found 22 such runs and 6 wrong answers).  Hence p_acc_add(settle) and the exchanges with
-// consumed results wherever the readers only pass this barrier.  (Waiting for vmcnt(0) here instead would
-// also hold the mirror block until its 256 KB of stores per accept are acknowledged: +7 us per accept.)
+// The barrier is a pure rendezvous: no fences.  What is handed across it are atomic words whose readers
+// can tell that they are complete (the accumulators' contribution counts) or whose writer consumed the
+// result of the exchange that put them there (the `max` batches' results); the matrix is read-only for the
+// whole launch, and what the mirror block stores to global memory is read by nobody before the kernel
+// ends.  (An agent-scope release + acquire pair around the barrier -- L2 write-back and invalidate on
+// every XCD -- cost another 4 us per barrier.)
 __device__ bool grid_barrier(PSync *sync, uint32_t G, uint32_t &gen, int *s_ok) {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -216,65 +233,66 @@ __device__ bool grid_barrier(PSync *sync, uint32_t G, uint32_t &gen, int *s_ok) 
     return *s_ok != 0;
 }
 
-// A window's rendezvous comes in two halves, for work that can be done while the others are still on their
-// way: grid_arrive announces this workgroup (and releases everybody if it is the last); the event loop
-// itself waits for the release (it has work to do meanwhile).
-// 16 bytes in one agent-scope load (one request: a consistent view of a record)
+// 16 bytes in one agent-scope load (one request for a PRel's two words; each word validates itself)
 __device__ __forceinline__ uint4 p_load16_agent(const void *ptr) {
     uint4 v;
     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(ptr) : "memory");
     return v;
 }
-// The release of a WINDOW's rendezvous is the generation word of the window's event records (evs: the
-// slot, eight group copies): whoever polls it reads the window's first event and the "listed" flag
-// in the same 16-byte load.
-__device__ void grid_arrive(PSync *sync, uint32_t G, uint32_t gen, unsigned long long *evs) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t target = gen + 1;
-        const uint32_t x = blockIdx.x & 7u, ng = G < 8u ? G : 8u;
-        const uint32_t gsz = (G - x + 7u) >> 3;
-        // (small grids -- the head phase's 64 workgroups -- arrive on ONE counter: 64 same-address
-        // atomics cost less than the second level's round trip; its words are the top counter's)
-        const bool last = G <= P_FLAT_GRID
-                              ? __hip_atomic_fetch_add(&sync->count, 1u, RLX_AGENT) == G * target - 1
-                              : (__hip_atomic_fetch_add(&sync->gcount[x].v, 1u, RLX_AGENT) == gsz * target - 1 &&
-                                 __hip_atomic_fetch_add(&sync->count, 1u, RLX_AGENT) == ng * target - 1);
-        if (last) {
-            for (uint32_t g = 0; g < 8u; g++)
-                __hip_atomic_store(reinterpret_cast<uint32_t *>(evs + g * 32), target, RLX_AGENT);
-        }
-    }
+
+// What a scanning wave needs of the window it is in (uniform values).
+struct PWin {
+    uint32_t epoch;               // the window's number
+    const unsigned long long *hintp;  // this group's hint word
+    PRel *rel;                    // the eight group copies (hints are posted to all of them)
+    unsigned long long *wgev;     // LDS: this workgroup's first event so far (becomes its arrival record)
+    uint32_t *nlist;              // LDS: candidates this workgroup has listed in this window
+    unsigned long long *mysoft;   // this workgroup's list entries (sync->soft[blockIdx.x])
+};
+// the first event posted so far in this window, as far as this group's hint word knows
+__device__ __forceinline__ uint64_t p_hint_pos(const PWin &w) {
+    return p_word_pos(__hip_atomic_load(w.hintp, RLX_AGENT), w.epoch);
 }
-// publishing an event: every group copy of the slot (evs = its base)
-__device__ __forceinline__ unsigned long long p_ev_word(uint64_t p, bool sure) {
-    return ((unsigned long long)p << 1) | (sure ? 0ull : 1ull);
+// An event found by a wave (called by its lanes 0..7 at least): into the workgroup's record (LDS) and, as a
+// hint for the waves still scanning, into every group's hint word -- fire and forget, nothing waits for it.
+__device__ __forceinline__ void p_post_event_wave(const PWin &w, uint64_t p, bool sure, uint32_t lane) {
+    const unsigned long long word = p_word(w.epoch, p, sure);
+    if (lane == 0) atomicMin(w.wgev, word);
+    if (lane < 8) atomicMin(&w.rel[lane].hint, word);
 }
-__device__ __forceinline__ uint64_t p_ev_pos(unsigned long long w) { return w == SEL_NONE ? SEL_NONE : uint64_t(w >> 1); }
-// (the results are CONSUMED: the minimum has been taken at the memory side when the posting thread goes on,
-// hence before its workgroup's arrival at the window's rendezvous -- a non-returning atomic is merely on its
-// way then, see grid_barrier)
-#ifndef DVS_P_POST_CONSUME
-#define DVS_P_POST_CONSUME 1
-#endif
-__device__ __forceinline__ void p_post_event_wave(unsigned long long *evs, uint64_t p, bool sure, uint32_t lane) {
-    if (lane < 8) {
-        const unsigned long long old = atomicMin(evs + lane * 32 + 1, p_ev_word(p, sure));
-        if (DVS_P_POST_CONSUME) asm volatile("" ::"v"(old) : "memory");
-    }
+__device__ __forceinline__ void p_post_event_thread(const PWin &w, uint64_t p, bool sure) {
+    const unsigned long long word = p_word(w.epoch, p, sure);
+    atomicMin(w.wgev, word);
+    for (uint32_t g = 0; g < 8; g++) atomicMin(&w.rel[g].hint, word);
 }
-__device__ __forceinline__ void p_post_event_thread(unsigned long long *evs, uint64_t p, bool sure) {
-    unsigned long long seen = 0;
-    for (uint32_t g = 0; g < 8; g++) seen |= atomicMin(evs + g * 32 + 1, p_ev_word(p, sure));
-    if (DVS_P_POST_CONSUME) asm volatile("" ::"v"(seen) : "memory");
+// A candidate whose fast score is within FAST_BAND of the threshold: listed, not an event -- the scan goes on
+// and the workgroups settle it in f64 after the rendezvous.  A workgroup's list holds P_LIST entries per
+// window (window words: a reader knows which window an entry belongs to); the count travels in its arrival
+// record.  A full list makes the candidate a plain (unsure) event.  One thread.
+__device__ __forceinline__ void p_list_candidate(const PWin &w, uint64_t p) {
+    const uint32_t idx = atomicAdd(w.nlist, 1u);
+    if (idx < P_LIST) __hip_atomic_store(w.mysoft + idx, p_word(w.epoch, p, false), RLX_AGENT);
+    else p_post_event_thread(w, p, false);
 }
-// a candidate was listed: the flag of every group's record (the results are consumed: performed before
-// this thread's workgroup can arrive at the rendezvous)
-__device__ __forceinline__ void p_flag_listed(unsigned long long *evs, unsigned long long *softp) {
-    uint32_t seen = 0;
-    for (uint32_t g = 0; g < 8; g++)
-        seen |= __hip_atomic_fetch_or(reinterpret_cast<uint32_t *>(evs + g * 32) + 1, 1u, RLX_AGENT);
-    if (seen == 0xDEADBEEFu) softp[7] = 1;  // (never)
+// wave-wide minimum of 64-bit words by DPP (register cross-lane moves, as dvs_wave_sum_dpp): every lane gets it
+template <int CTRL>
+__device__ __forceinline__ unsigned long long p_dpp_mov_u64(unsigned long long v) {
+    int lo = int(uint32_t(v)), hi = int(uint32_t(v >> 32));
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return ((unsigned long long)uint32_t(hi) << 32) | uint32_t(lo);
+}
+__device__ __forceinline__ unsigned long long p_wave_min_u64(unsigned long long v) {
+    auto mn = [](unsigned long long a, unsigned long long b) { return b < a ? b : a; };
+    v = mn(v, p_dpp_mov_u64<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = mn(v, p_dpp_mov_u64<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = mn(v, p_dpp_mov_u64<0x141>(v));  // row_half_mirror
+    v = mn(v, p_dpp_mov_u64<0x140>(v));  // row_mirror: every lane holds the minimum of its row of 16
+    const int lo = int(uint32_t(v)), hi = int(uint32_t(v >> 32));
+    auto row = [&](int l) {
+        return ((unsigned long long)uint32_t(__builtin_amdgcn_readlane(hi, l)) << 32) | uint32_t(__builtin_amdgcn_readlane(lo, l));
+    };
+    return mn(mn(row(0), row(16)), mn(row(32), row(48)));
 }
 
 // One wave's share of the window, as scan_rows_hot but against the unscaled vector sl:
@@ -284,8 +302,7 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                                             const uint32_t *__restrict__ totals,
                                             const double *__restrict__ rowH, const double *sl,
                                             const float *slf, uint64_t B, const PState &st, double he_base,
-                                            unsigned long long *evp, unsigned long long *evs,
-                                            unsigned long long *softp,
+                                            const PWin &win,
                                             uint64_t first, uint64_t stride, uint64_t nrows,
                                             uint32_t lane, uint32_t &nread,
                                             uint32_t &nprecise, uint32_t &nmid, bool coarse_on,
@@ -300,7 +317,7 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
     for (uint64_t r = first; r < nrows; r += stride) {
         const uint64_t p = st.cursor + r;
         const T *rp = mat + p * B;
-        const unsigned long long ev = p_ev_pos(__hip_atomic_load(evp, RLX_AGENT));
+        const uint64_t ev = p_hint_pos(win);
         const uint32_t tot = totals[p];
         const double hrow = rowH[p];
         if (ev < p) break;
@@ -341,7 +358,7 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                 uint64_t i0 = 0;
                 bool dropped = false;
                 for (; i0 < full; i0 += 256 * C_CH) {
-                    if (i0 && burst_drop && p_ev_pos(__hip_atomic_load(evp, RLX_AGENT)) < p) {
+                    if (i0 && burst_drop && p_hint_pos(win) < p) {
                         dropped = true;
                         break;
                     }
@@ -374,7 +391,7 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
                 const double jf0 = -dvs_wave_sum_dpp(c0 + c1) - mean_entropy;
                 if (!(jf0 > thr_c_lo)) continue;  // (NaN: a negative bin, rejected as the reference does)
                 if (jf0 > thr_c_hi) {
-                    p_post_event_wave(evs, p, true, lane);
+                    p_post_event_wave(win, p, true, lane);
                     continue;
                 }
                 nmid++;
@@ -430,21 +447,14 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
         const double jf = hf - mean_entropy;
         if (!(mn < 0.0) && jf > thr_sure) {
             // above the threshold by more than every error bound: no f64 re-evaluation needed
-            p_post_event_wave(evs, p, true, lane);
+            p_post_event_wave(win, p, true, lane);
         } else if (!(mn < 0.0) && jf > thr_fast && lane == 0) {
             {
                 // within FAST_BAND of the threshold: listed, not an event -- the scan goes on and
                 // the workgroups settle it in f64 after the rendezvous (a wave doing that alone
                 // would hold the whole grid at the barrier for 4^k f64 logarithms)
                 nprecise++;
-                const unsigned long long idx = atomicAdd(softp, 1ull);
-                if (idx < P_SOFT) {
-                    if (__hip_atomic_exchange(softp + 8 + idx, (unsigned long long)p, RLX_AGENT) == 1ull)
-                        softp[7] = 1;  // (never: position 1 is a seed; consumes the result)
-                    p_flag_listed(evs, softp);
-                } else {
-                    p_post_event_thread(evs, p, false);  // list full: a plain (unsure) event
-                }
+                p_list_candidate(win, p);
             }
         }
     }
@@ -460,8 +470,7 @@ template <typename T, bool COARSE>
 __device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const uint32_t *__restrict__ totals,
                                                const double *__restrict__ rowH, const double *sl,
                                                const float *slf, uint64_t B,
-                                               const PState &st, double he_base, unsigned long long *evp,
-                                               unsigned long long *evs, unsigned long long *softp,
+                                               const PState &st, double he_base, const PWin &win,
                                                uint64_t first, uint64_t stride,
                                                uint64_t nrows, double *red, uint32_t &nread,
                                                uint32_t &nprecise, uint32_t &nmid, bool coarse_on,
@@ -476,7 +485,7 @@ __device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const 
     for (uint64_t r = first; r < nrows; r += stride, par ^= 1) {
         const uint64_t p = st.cursor + r;
         const T *rp = mat + p * B;
-        const unsigned long long ev = wave == 0 ? p_ev_pos(__hip_atomic_load(evp, RLX_AGENT)) : 0ull;
+        const uint64_t ev = wave == 0 ? p_hint_pos(win) : 0ull;
         const uint32_t tot = totals[p];
         const double hrow = rowH[p];
         const double rt = tot ? 1.0 / double(tot) : 0.0;
@@ -510,7 +519,7 @@ __device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const 
                 if (tid == 0) nread++;
                 if (!(jf0 > thr_c_lo)) continue;
                 if (jf0 > thr_c_hi) {
-                    if (tid < 8) p_post_event_wave(evs, p, true, tid);  // (eight lanes, one instruction: every thread knows the score)
+                    if (tid < 8) p_post_event_wave(win, p, true, tid);  // (eight lanes, one instruction: every thread knows the score)
                     continue;
                 }
                 if (tid == 0) {
@@ -571,21 +580,14 @@ __device__ __forceinline__ void p_scan_rows_wg(const T *__restrict__ mat, const 
         }
         const double jf = hf - (he_base + hrow) / dn;
         // (a sure event goes out from eight lanes in one instruction: every thread knows the score)
-        if (tid < 8 && neg == 0.0 && jf > thr_fast && jf > thr_sure) p_post_event_wave(evs, p, true, tid);
+        if (tid < 8 && neg == 0.0 && jf > thr_fast && jf > thr_sure) p_post_event_wave(win, p, true, tid);
         if (tid == 0) {
             nread++;
             if (neg == 0.0 && jf > thr_fast) {
                 if (jf > thr_sure) {
                 } else {
                     nprecise++;
-                    const unsigned long long idx = atomicAdd(softp, 1ull);
-                    if (idx < P_SOFT) {
-                        if (__hip_atomic_exchange(softp + 8 + idx, (unsigned long long)p, RLX_AGENT) == 1ull)
-                            softp[7] = 1;  // (never: position 1 is a seed; consumes the result)
-                        p_flag_listed(evs, softp);
-                    } else {
-                        p_post_event_thread(evs, p, false);  // list full: a plain (unsure) event
-                    }
+                    p_list_candidate(win, p);
                 }
             }
         }
@@ -602,8 +604,7 @@ __device__ __forceinline__ void p_scan_rows_wg_stream(const T *__restrict__ mat,
                                                       const uint32_t *__restrict__ totals,
                                                       const double *__restrict__ rowH, const double *sl,
                                                       const float *slf, const PState &st, double he_base,
-                                                      unsigned long long *evp, unsigned long long *evs,
-                                                      unsigned long long *softp, uint64_t first,
+                                                      const PWin &win, uint64_t first,
                                                       uint64_t stride, uint64_t nrows, double *red,
                                                       uint32_t &nread, uint32_t &nprecise, uint32_t &nmid,
                                                       bool no_first_poll = true) {
@@ -636,7 +637,7 @@ __device__ __forceinline__ void p_scan_rows_wg_stream(const T *__restrict__ mat,
         w.tot = totals[p];
         if (wave == 0) {  // the row's entropy and the event word travel through LDS with the partial sums
             w.hrow = rowH[p];
-            w.ev = poll ? p_ev_pos(__hip_atomic_load(evp, RLX_AGENT)) : SEL_NONE;
+            w.ev = poll ? p_hint_pos(win) : SEL_NONE;
         }
     };
     uint32_t par = 0;
@@ -676,7 +677,7 @@ __device__ __forceinline__ void p_scan_rows_wg_stream(const T *__restrict__ mat,
         if (tid == 0) nread++;
         if (!(jf0 > thr_c_lo)) return true;  // (NaN: a negative bin, rejected as the reference does)
         if (jf0 > thr_c_hi) {
-            if (tid < 8) p_post_event_wave(evs, p, true, tid);  // (eight lanes, one instruction: every thread knows the score)
+            if (tid < 8) p_post_event_wave(win, p, true, tid);  // (eight lanes, one instruction: every thread knows the score)
             return true;
         }
         if (tid == 0) {
@@ -684,7 +685,7 @@ __device__ __forceinline__ void p_scan_rows_wg_stream(const T *__restrict__ mat,
             nread--;  // counted again by the FAST pass
         }
         uint32_t nm = 0;
-        p_scan_rows_wg<T, false>(mat, totals, rowH, sl, slf, B, st, he_base, evp, evs, softp, r, nrows, nrows, red,
+        p_scan_rows_wg<T, false>(mat, totals, rowH, sl, slf, B, st, he_base, win, r, nrows, nrows, red,
                                  nread, nprecise, nm, false);
         return true;
     };
@@ -776,7 +777,7 @@ __device__ __forceinline__ void p_argmin(const double *s_dl, const double *s_ds,
 }
 
 // LDS: [sl B f64][scratch 128 f64][s_mH, s_tot, s_rt, s_dl, s_ds maxn f64][s_pos maxn u64]
-//      [s_slot maxn u32][s_soft P_SOFT u64][flags]
+//      [s_slot maxn u32][s_win P_WINWORDS u64][flags][log2 table][s_prev (maxn + 1) x 2 u64]
 // maxn = p_maxn(CACHED): compile-time offsets (runtime ones cost registers the scan loop needs),
 // smaller beyond 4096 bins so that 4^7 bins (128 KB of sl) still fit.
 // CACHED: B <= P_J * 512, so a thread's share of the candidate row stays in registers
@@ -807,6 +808,15 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     // rendezvous completes -- at 4^7 bins a job is sixteen bins a thread in f64 plus 2 x 32 KB of counts from
     // L2, 6 us that used to follow the release
     constexpr bool SPEC_BIG = !CACHED && !MAXM && sizeof(T) <= 4;
+    // OWN (nmost over count rows in the register cache, sets too large for SMALL): the leave-one-out jobs are
+    // dealt by member SLOT, not by member order -- a slot keeps its member until that member is replaced, so
+    // a workgroup serves the same member accept after accept and keeps that member's count row in its LDS
+    // (s_own, thread-major like the candidate's registers; refreshed from the candidate's registers when the
+    // slot changes hands): a job never waits for a row from memory.  The accumulators are indexed by slot too.
+    // (Tried on top of it, round 4: an LDS cache of the rows of the members closest to being the lowest, filled by
+    // LDS-DMA, for the rebuild of sl -- 97 % of the accepts found their row there and the step did not move: the
+    // wait at that point is not for the row.  DESIGN.md 4.3.)
+    constexpr bool OWN = SPEC && !SMALL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint64_t B0 = d.B;
     const uint64_t B = B0;  // (the event loop below takes its own, laundered copy)
@@ -824,24 +834,42 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     double *s_ds = s_dl + maxn;   // sum of each member's mean vector
     uint64_t *s_pos = reinterpret_cast<uint64_t *>(s_ds + maxn);  // matrix row of each member
     uint32_t *s_slot = reinterpret_cast<uint32_t *>(s_pos + maxn);
-    uint64_t *s_soft = reinterpret_cast<uint64_t *>(s_slot + maxn + (maxn & 1));  // this window's listed candidates
-    int *s_flag = reinterpret_cast<int *>(s_soft + P_SOFT);
-    static_assert(maxn % 4 == 0 && P_SOFT % 2 == 0, "s_ltab below must sit on a 16-byte boundary");
-    double2 *s_ltab = reinterpret_cast<double2 *>(s_soft + P_SOFT + 2);  // log2_tab's 128 entries
-    [[maybe_unused]] uint16_t *s_rows = reinterpret_cast<uint16_t *>(s_ltab + 128);  // SMALL: member count rows by slot
+    // the window's words: [0] this workgroup's first event (its arrival record), [1] candidates it listed,
+    // [2] scratch minimum of the listed candidates' walk, [8..15] / [16..23] the gathering waves' minima and flags
+    unsigned long long *s_win = reinterpret_cast<unsigned long long *>(s_slot + maxn + (maxn & 1));
+    int *s_flag = reinterpret_cast<int *>(s_win + P_WINWORDS);
+    static_assert(maxn % 4 == 0 && P_WINWORDS % 2 == 0, "s_ltab below must sit on a 16-byte boundary");
+    double2 *s_ltab = reinterpret_cast<double2 *>(s_win + P_WINWORDS + 2);  // log2_tab's 128 entries
+    // the leave-one-out accumulators' totals as of their previous use, this group's replica (p_acc_complete)
+    unsigned long long *s_prev = reinterpret_cast<unsigned long long *>(s_ltab + 128);
+    unsigned char *s_tail = reinterpret_cast<unsigned char *>(s_prev + uint64_t(maxn + 1) * 2);
+    [[maybe_unused]] uint16_t *s_rows = reinterpret_cast<uint16_t *>(s_tail);  // SMALL: member count rows by slot
+    // OWN: slot -> member order, this workgroup's own member's counts
+    [[maybe_unused]] uint32_t *s_inv = reinterpret_cast<uint32_t *>(s_tail);
+    [[maybe_unused]] T *s_own = reinterpret_cast<T *>(s_inv + maxn);
     // MAXM: a batch's row totals, row entropies and decisions (12 doubles per row)
-    [[maybe_unused]] double *s_bt = reinterpret_cast<double *>(s_ltab + 128);
+    [[maybe_unused]] double *s_bt = reinterpret_cast<double *>(s_tail);
     [[maybe_unused]] double *s_bH = s_bt + P_BATCH;
     [[maybe_unused]] double *s_bev = s_bH + P_BATCH;
     [[maybe_unused]] double *s_bpart = s_bev + 12 * P_BATCH;  // a batch job's sums by wave: [row][3][8 waves]
     if (threadIdx.x < 128) log2_tab_fill(s_ltab, threadIdx.x);
+    for (uint32_t i = threadIdx.x; i < (maxn + 1) * 2; i += P_THREADS) s_prev[i] = 0ull;  // (the host zeroed the accumulators)
     SelCtl *ctl = d.ctl;
     const int tid0 = threadIdx.x;
     const int tid = tid0;
     [[maybe_unused]] const uint32_t lane = tid & 63, wave = tid >> 6;
     // the LAST block mirrors the state into global memory: with n < G it owns no member in
     // the leave-one-out pass, so its extra stores overlap the other blocks' arithmetic
-    const bool lead = blockIdx.x == G - 1;
+    // Two workgroups scan nothing (grids of three and more): the last one GATHERS the arrival records of every
+    // window and stores its release word -- it stores nothing else, so no store of its own ever sits in front of
+    // its polling loads --, the one before it MIRRORS the state into global memory (`lead`).  The mirror
+    // block's stores (64 KB per accept at 4^6 bins) used to sit in front of the same block's arrival: every
+    // window waited ~3 us for them to drain (profiles/r04_d stamps).  It announces itself for the NEXT window as
+    // soon as it has read everything the others wrote in this one, before it stores anything (see early_rec).
+    const bool two_roles = G >= 3;
+    const bool gath = blockIdx.x == G - 1;
+    const bool lead = blockIdx.x == (two_roles ? G - 2 : G - 1);
+    const uint32_t n_work = G > 1 ? G - (two_roles ? 2u : 1u) : 1u;  // workgroups that scan and take single jobs
 
     // ---- replica of the state (global memory is quiescent: written by earlier launches)
     PState st;
@@ -859,7 +887,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     st.thr = ctl->thr;
     st.band = ctl->band;
     st.wscale = ctl->wscale;
-    st.n_windows = st.n_events = st.n_accepts = st.n_loo = 0;
+    st.n_windows = st.n_events = st.n_accepts = 0;
     st.max_size = MAXM ? ctl->max_size : st.n;
     st.stat = ctl->stat;
     st.mean_d = ctl->mean_delta;
@@ -908,9 +936,19 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     uint32_t pend_kind = 0;  // ev_kind left pending for the multi-launch kernels (finalize tie)
     bool bail = false;       // leave with the state as it stands and status RUN (MAXM: an undecidable push)
     [[maybe_unused]] uint32_t mx_batch = 1;  // MAXM: rows the next tentative push takes along (identical in every workgroup)
-    uint32_t acc_cleared_for = 0xFFFFFFFFu;  // mirror block: the accept whose accumulators have been cleared
+    // the mirror block (two_roles): the window whose arrival record it has already stored -- at the end of the
+    // window before, the moment it had read the last word another workgroup wrote for that window (the release,
+    // the listed candidates, the leave-one-out totals), ahead of its own stores
+    uint32_t early_rec = 0xFFFFFFFFu;
+    auto announce_early = [&](uint32_t next_epoch) {
+        if (lead && two_roles && !MAXM) {
+            if (threadIdx.x == 0)
+                __hip_atomic_store(&sync->wrec[blockIdx.x], p_word(next_epoch, SEL_NONE, false), RLX_AGENT);
+            early_rec = next_epoch;
+        }
+    };
     const uint64_t wpb = P_THREADS / 64;
-    const uint32_t nwg = G > 1 ? G - 1 : 1;           // scanning workgroups
+    const uint32_t nwg = n_work;                      // scanning workgroups
     const uint64_t nwaves = uint64_t(nwg) * wpb;      // scanning waves
     const uint32_t wg_thresh = sync->wg_thresh;       // (written by the host before the launch)
     const double wg_scale = double(sync->wg_scale);
@@ -926,10 +964,10 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     bool one_job = false, has_job = false;
     auto set_geometry = [&](uint32_t members) {  // (again after every kept push: MAXM sets grow)
         K = 1;
-        const uint32_t kmax = (members + 1 < G) ? (G - 1) / (members + 1) : 1u;
+        const uint32_t kmax = (members + 1 <= n_work) ? n_work / (members + 1) : 1u;
         while (K * 2 <= kmax && K * 2 <= nchunk && K * 2 <= 32u) K *= 2;
         jobs = (members + 1) * K;
-        one_job = jobs <= G - 1;  // at most one job per workgroup, none for the mirror block
+        one_job = jobs <= n_work && G > 1;  // at most one job per workgroup, none for the mirror and the gathering block
         has_job = one_job ? (blockIdx.x < jobs) : true;
     };
     set_geometry(st.n);
@@ -981,11 +1019,11 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             }
         }
         __syncthreads();
-        unsigned long long *acc_all = part;  // accumulator slot 0 (cleared by the host before the launch)
+        unsigned long long *acc_all = part;  // the accumulators (zeroed by the host before the launch)
         const unsigned long long *acc = acc_all + uint64_t(blockIdx.x & 7u) * (maxn + 1) * 2;
         bool first_job = true;
         for (uint32_t job = blockIdx.x; job < jobs && has_job; job += G) {
-            if (lead && one_job) break;
+            if ((lead || gath) && one_job) break;
             const uint32_t r = job / K, part_i = job % K;
             const T *mrow = mat + (r < n ? s_pos[r] : 0) * B;
             const double mtot = r < n ? s_tot[r] : 1.0, mrt = r < n ? s_rt[r] : 1.0;
@@ -1030,8 +1068,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         }
         bool acc_ok = true;
         for (uint32_t r = tid; r <= n; r += P_THREADS) {
-            const double h = p_acc_value(p_acc_complete(acc + uint64_t(r) * 2, K, acc_ok));
-            const double sv = p_acc_value(p_acc_complete(acc + uint64_t(r) * 2 + 1, K, acc_ok));
+            const double h = p_acc_value(p_acc_complete(acc + uint64_t(r) * 2, s_prev + uint64_t(r) * 2, K, acc_ok));
+            const double sv = p_acc_value(p_acc_complete(acc + uint64_t(r) * 2 + 1, s_prev + uint64_t(r) * 2 + 1, K, acc_ok));
             if (r == n) {
                 scratch[110] = h;
                 scratch[111] = sv;
@@ -1067,7 +1105,6 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         st.mean_d = mean0;
         st.std_d = sd0;
         st.cov_d = sd0 / mean0;
-        st.n_loo = 1;  // (slot 0 is in use; the first accept takes slot 1)
         {   // sl <- S - lowest (no clamp: what the set-up kernels' base vector holds)
             const T *lrow = mat + s_pos[low0] * B;
             const double ltot = s_tot[low0], lrt = s_rt[low0];
@@ -1129,6 +1166,28 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     }
     }
 
+    [[maybe_unused]] const uint32_t own_slot = one_job ? blockIdx.x / K : 0u;  // OWN: the slot this workgroup's job serves (n: the whole set)
+    [[maybe_unused]] const bool use_own = OWN && one_job;
+    if constexpr (OWN) {
+        bool slots_ok = true;
+        for (uint32_t r = tid; r < st.n; r += P_THREADS) {
+            const uint32_t a = s_slot[r];
+            if (a < st.n) s_inv[a] = r;
+            else slots_ok = false;
+        }
+        if (__syncthreads_or(slots_ok ? 0 : 1)) {  // (never: an nmost set occupies slots 0 .. n - 1)
+            if (lead && tid == 0) ctl->why[7]++;
+            return;
+        }
+        if (use_own && has_job && own_slot < st.n) {
+            const T *mrow = mat + s_pos[s_inv[own_slot]] * B;
+#pragma unroll
+            for (int j = 0; j < P_J; j++) {
+                const uint64_t i = uint64_t(j) * P_THREADS + tid;
+                s_own[uint32_t(tid) * P_J + j] = i < B ? mrow[i] : T(0);
+            }
+        }
+    }
     // SMALL: the members' count rows into LDS, thread-major (see above).  A slot the replica has no room
     // for (never: an nmost set occupies slots 0 .. n - 1) leaves the launch with the state untouched;
     // the host then carries on with the multi-launch kernels.
@@ -1154,9 +1213,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
 #ifdef DVS_PERSIST_STAMPS  // per-phase in-kernel timing (DVS_PERSIST_DEBUG prints it): costs registers
     // (accumulated in LDS by thread 0 of block 0 and of the mirror block, written out when the launch
     // ends: a stamp costs a clock read and an LDS add, not a memory round trip)
-    unsigned long long *s_dbg = SMALL ? reinterpret_cast<unsigned long long *>(s_rows + uint64_t(sync->small_rows) * 4096)
-                                      : reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(s_ltab + 128) +
-                                                                               (MAXM ? p_batch_lds() : 0));
+    unsigned long long *s_dbg = reinterpret_cast<unsigned long long *>(smem + sync->lds_bytes - 128);  // (the last 128 bytes)
     if (tid < 16) s_dbg[tid] = 0ull;
     __syncthreads();
     unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
@@ -1168,8 +1225,18 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             t_prev = t_now;                                                \
         }                                                                  \
     } while (0)
+// (block 0 only: finer stamps inside a phase -- slots 9..14 are the mirror block's window statistics)
+#define P_STAMP_B0(k)                                                      \
+    do {                                                                   \
+        if (blockIdx.x == 0 && !lead && tid == 0) {                        \
+            const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); \
+            s_dbg[k] += t_now - t_prev;                                    \
+            t_prev = t_now;                                                \
+        }                                                                  \
+    } while (0)
 #else
 #define P_STAMP(k) do { } while (0)
+#define P_STAMP_B0(k) do { } while (0)
 #endif
     for (;;) {
         // The loop body's view of the bin count and the thread index goes through an empty asm:
@@ -1181,35 +1248,24 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         asm volatile("" : "+s"(B));
         asm volatile("" : "+v"(tid));
         const uint32_t lane = uint32_t(tid) & 63u, wave = uint32_t(tid) >> 6;
-        unsigned long long *evs = &sync->ev[epoch % 3][0];            // the slot: eight group copies
-        unsigned long long *evrec = evs + (blockIdx.x & 7u) * 32;    // this workgroup's copy of the record ...
-        unsigned long long *evp = evrec + 1;                          // ... and its event word
-        // the slot of the NEXT epoch is cleared now (event words, listed flags, the list's count -- not the
-        // generations), by exchanges whose results are consumed: PERFORMED before this thread's arrival at the
-        // window's rendezvous below, i.e. before anybody can leave that rendezvous and post to the slot.
-        // (They were plain stores for a while this round, on the assumption that a wave's memory operations
-        // are acknowledged in order; the returning arrival overtakes non-returning operations now and then --
-        // see grid_barrier.  The mirror block scans nothing, so the round trip costs the window nothing.)
-#ifndef DVS_P_SLOT_EXCH
-#define DVS_P_SLOT_EXCH 1
-#endif
-        if (lead && tid < 17) {
-            unsigned long long *nx = &sync->ev[(epoch + 1) % 3][0];
-            unsigned long long seen;
-            if (tid < 8) seen = __hip_atomic_exchange(nx + tid * 32 + 1, SEL_NONE, RLX_AGENT);
-            else if (tid < 16) seen = __hip_atomic_exchange(reinterpret_cast<uint32_t *>(nx + (tid - 8) * 32) + 1, 0u, RLX_AGENT);
-            else seen = __hip_atomic_exchange(&sync->soft[(epoch + 1) % 3][0], 0ull, RLX_AGENT);
-            if (DVS_P_SLOT_EXCH) asm volatile("" ::"v"(seen) : "memory");
+        if (epoch >= P_EPOCH_MAX) {  // (window words have 24 bits for the window's number: the host launches again)
+            bail = true;
+            break;
         }
-        // ... and the leave-one-out accumulators eight accepts AHEAD (plain stores, once per accept: see
-        // P_ACC_SLOTS; that slot's last readers passed a rendezvous eight accepts ago)
-        if (lead && acc_cleared_for != st.n_loo) {
-            acc_cleared_for = st.n_loo;
-            unsigned long long *nx = part + uint64_t((st.n_loo + P_ACC_SLOTS / 2) % P_ACC_SLOTS) * 8 * (maxn + 1) * 2;
-            const uint32_t ne = (st.n + P_ACC_SLOTS <= maxn + 1 ? st.n + P_ACC_SLOTS : maxn + 1) * 2u;  // (max mode: the set may grow by then)
-            for (uint32_t i = tid; i < 8u * ne; i += P_THREADS)
-                __hip_atomic_store(nx + (uint64_t(i / ne) * (maxn + 1)) * 2 + i % ne, 0ull, RLX_AGENT);
+        PRel *myrel = &sync->rel[blockIdx.x & 7u];  // this group's copy of the release word and the hints
+        PWin win;
+        win.epoch = epoch;
+        win.hintp = &myrel->hint;
+        win.rel = sync->rel;
+        win.wgev = s_win;
+        win.nlist = reinterpret_cast<uint32_t *>(s_win + 1);
+        win.mysoft = &sync->soft[blockIdx.x][0];
+        if (tid == 0) {  // (the previous window's words were last read before the barrier that ended its walk)
+            s_win[0] = p_word(epoch, SEL_NONE, false);
+            *win.nlist = 0u;
         }
+        __syncthreads();
+        P_STAMP_B0(9);  // (the top of the window: its barrier)
 #ifdef DVS_PERSIST_STAMPS
         const unsigned long long t_window = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1218,20 +1274,17 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // ================= scan
         // (the mirror block scans nothing when there are other blocks: its global stores of the
         // previous event overlap the others' scan instead of delaying the rendezvous)
-        if (!lead || G == 1) {
+        if ((!lead && !gath) || G == 1) {
             if (wgmode && COARSE && B == 4096 && coarse_on) {
                 if constexpr (COARSE)
-                    p_scan_rows_wg_stream<T>(mat, d.totals, d.rowH, sl, slf, st, st.sumH - s_mH[st.li], evp, evs,
-                                             &sync->soft[epoch % 3][0], blockIdx.x, nwg, nrows, scratch + 32,
-                                             nread, nprecise, nmid);
+                    p_scan_rows_wg_stream<T>(mat, d.totals, d.rowH, sl, slf, st, st.sumH - s_mH[st.li], win,
+                                             blockIdx.x, nwg, nrows, scratch + 32, nread, nprecise, nmid);
             } else if (wgmode)
-                p_scan_rows_wg<T, COARSE>(mat, d.totals, d.rowH, sl, slf, B, st, st.sumH - s_mH[st.li], evp, evs,
-                                          &sync->soft[epoch % 3][0], blockIdx.x, nwg, nrows, scratch + 32,
-                                          nread, nprecise, nmid, coarse_on);
+                p_scan_rows_wg<T, COARSE>(mat, d.totals, d.rowH, sl, slf, B, st, st.sumH - s_mH[st.li], win,
+                                          blockIdx.x, nwg, nrows, scratch + 32, nread, nprecise, nmid, coarse_on);
             else
-                p_scan_rows<T, COARSE>(mat, d.totals, d.rowH, sl, slf, B, st, st.sumH - s_mH[st.li], evp, evs,
-                                       &sync->soft[epoch % 3][0], uint64_t(blockIdx.x) * wpb + wave, nwaves,
-                                       nrows, lane, nread, nprecise, nmid, coarse_on,
+                p_scan_rows<T, COARSE>(mat, d.totals, d.rowH, sl, slf, B, st, st.sumH - s_mH[st.li], win,
+                                       uint64_t(blockIdx.x) * wpb + wave, nwaves, nrows, lane, nread, nprecise, nmid, coarse_on,
                                        (sync->no_coarse & 8u) == 0);
         }
         // SPEC: the candidate this window will most likely end with -- the event word as it stands when
@@ -1281,6 +1334,9 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                     for (int j = 0; j < P_J; j++) mcv[j] = (qw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                } else if (use_own) {  // (the member this workgroup's slot holds: its counts are here)
+#pragma unroll
+                    for (int j = 0; j < P_J; j++) mcv[j] = uint32_t(s_own[uint32_t(tid) * P_J + j]);
                 } else {
                     const T *mrow = mat + s_pos[at] * B;
 #pragma unroll
@@ -1428,72 +1484,141 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 }
             }
         };
-        if constexpr (SPEC) {
-            const uint64_t guess = p_ev_pos(__hip_atomic_load(evp, RLX_AGENT));
-            if (guess != SEL_NONE) fetch_raw(guess);  // (per wave: whatever it saw when it left the scan)
-        }
+        P_STAMP_B0(10);  // (this workgroup's rows scanned)
         P_STAMP(0);
-        grid_arrive(sync, G, gen, evs);
-        // ---- wait for the release.  Thread 0 polls this group's record (16 bytes: generation, listed flag,
-        // first event) and hands every look to the workgroup; SPEC: as soon as the record names a
-        // candidate -- usually well before the last workgroup has arrived -- the workgroup takes it up.
-        unsigned long long hard_w = SEL_NONE;
-        bool any_listed = false, bar_ok = true;
+        // ---- the window's rendezvous.  Every workgroup stores ONE arrival record -- its first event and how
+        // many candidates it listed, tagged with the window's number --; the mirror block, which has scanned
+        // nothing, waits for all of them (thread t polls workgroup t's) and stores the release word: the
+        // window's first event.  The others poll their group's copy of it together with the hint word beside
+        // it (one 16-byte load; each word says itself which window it belongs to).
+        __syncthreads();  // (every wave's events and listings are in s_win)
+        unsigned long long rel_w = 0ull;
+        bool bar_ok = true;
         {
-            const uint32_t target = gen + 1;
-            uint32_t spins = 0;
-            for (;;) {
-                if (tid == 0) {
-                    const uint4 v = p_load16_agent(evrec);
-                    int ok = 1;
-                    if (v.x < target && (++spins & 255u) == 0 &&
-                        (spins > P_SPIN_LIMIT || __hip_atomic_load(&sync->timeout, RLX_AGENT))) {
-                        __hip_atomic_store(&sync->timeout, 1u, RLX_AGENT);
-                        ok = 0;
+            const uint32_t nl = *win.nlist;
+            const unsigned long long own = s_win[0] | ((unsigned long long)(nl < P_LIST ? nl : P_LIST) << 1);
+            if (tid == 0 && early_rec != epoch) __hip_atomic_store(&sync->wrec[blockIdx.x], own, RLX_AGENT);
+            P_STAMP_B0(11);  // (the look at the hint, the candidate's row requested, the workgroup's barrier, the record stored)
+            if (gath) {
+                // ONE wave gathers: lane l waits for the records of workgroups l, l + 64, l + 128, l + 192 (four loads in
+                // flight per look), the minimum is taken by DPP, lanes 0..7 store the release word -- no LDS, no
+                // barrier between the last record's arrival and the release
+                if (wave == 0) {
+                    constexpr uint32_t Q = P_MAXG / 64;
+                    unsigned long long w[Q];
+                    bool have[Q];
+#pragma unroll
+                    for (uint32_t q = 0; q < Q; q++) {
+                        w[q] = ~0ull;
+                        have[q] = lane + 64 * q >= G - 1;  // (this workgroup's own record is `own`)
                     }
-                    scratch[121] = __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z));
-                    scratch[122] = double(v.y);
-                    scratch[123] = v.x >= target ? 1.0 : 0.0;
-                    s_flag[0] = ok;
+                    uint32_t spins = 0;
+                    bool ok = true;
+                    for (;;) {
+                        unsigned long long got[Q];
+#pragma unroll
+                        for (uint32_t q = 0; q < Q; q++)
+                            got[q] = have[q] ? 0ull : __hip_atomic_load(&sync->wrec[lane + 64 * q], RLX_AGENT);
+                        bool all = true;
+#pragma unroll
+                        for (uint32_t q = 0; q < Q; q++) {
+                            if (!have[q] && p_word_is(got[q], epoch)) {
+                                w[q] = got[q];
+                                have[q] = true;
+                            }
+                            all = all && have[q];
+                        }
+                        if (__ballot(!all) == 0ull) break;
+                        if ((++spins & 255u) == 0 &&
+                            (spins > P_SPIN_LIMIT || __hip_atomic_load(&sync->timeout, RLX_AGENT))) {
+                            ok = false;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    unsigned long long m = own & ~6ull, fl = own & 6ull;
+#pragma unroll
+                    for (uint32_t q = 0; q < Q; q++)
+                        if (lane + 64 * q < G - 1 && have[q]) {
+                            m = (w[q] & ~6ull) < m ? (w[q] & ~6ull) : m;
+                            fl |= w[q] & 6ull;
+                        }
+                    m = p_wave_min_u64(m);
+                    const bool anyl = __ballot(fl != 0ull) != 0ull;
+                    const unsigned long long relw = m | (anyl ? 2ull : 0ull);
+                    if (ok && lane < 8) __hip_atomic_store(&sync->rel[lane].rel, relw, RLX_AGENT);
+                    if (!ok && lane == 0) __hip_atomic_store(&sync->timeout, 1u, RLX_AGENT);
+                    if (lane == 0) {
+                        s_win[4] = relw;
+                        s_flag[0] = ok ? 1 : 0;
+                    }
                 }
                 __syncthreads();
-                hard_w = (unsigned long long)__double_as_longlong(scratch[121]);
-                any_listed = scratch[122] != 0.0;
-                const bool released = scratch[123] != 0.0;
+                rel_w = s_win[4];
                 bar_ok = s_flag[0] != 0;
-                __syncthreads();  // (thread 0 rewrites the slots in the next round)
-                if (released || !bar_ok) break;
-                bool worked = false;
-                if constexpr (SPEC) {
-                    const uint64_t seen = p_ev_pos(hard_w);
-                    if (seen != SEL_NONE && seen != fr_pos && (sync->no_coarse & 16u) == 0) {
-                        fetch_raw(seen);
-                        const double t_ = double(craw_tot), rt_ = 1.0 / t_;
-#pragma unroll
-                        for (int j = 0; j < P_J; j++) fr[j] = count_freq_x(craw[j], t_, rt_);
-                        fr_pos = seen;
-                        if (one_job && has_job && !lead && st.n < 128) {
-                            const uint32_t r = blockIdx.x / K;
-                            small_job(r, blockIdx.x % K, r < st.li ? r : r + 1, st.n, spec_th, spec_ts);
-                            spec_job_pos = seen;
+                __syncthreads();  // (the words are rewritten in the next window)
+            } else {
+                // Thread 0 polls and hands every look to the workgroup; SPEC: as soon as the hint names a candidate
+                // -- usually well before the last workgroup has arrived -- the workgroup takes it up.
+                uint32_t spins = 0;
+                for (;;) {
+                    if (tid == 0) {
+                        const uint4 v = p_load16_agent(myrel);
+                        const unsigned long long r_ = ((unsigned long long)v.y << 32) | v.x;
+                        const bool rel_ = p_word_is(r_, epoch);
+                        int ok = 1;
+                        if (!rel_ && (++spins & 255u) == 0 &&
+                            (spins > P_SPIN_LIMIT || __hip_atomic_load(&sync->timeout, RLX_AGENT))) {
+                            __hip_atomic_store(&sync->timeout, 1u, RLX_AGENT);
+                            ok = 0;
                         }
-                        worked = true;
+                        s_win[4] = r_;
+                        s_win[5] = ((unsigned long long)v.w << 32) | v.z;
+                        s_win[6] = rel_ ? 1ull : 0ull;
+                        s_flag[0] = ok;
                     }
-                }
-                if constexpr (SPEC_BIG) {
-                    const uint64_t seen = p_ev_pos(hard_w);
-                    if (seen != SEL_NONE && seen != spec_job_pos && one_job && has_job && !lead && st.n < 128 &&
-                        (sync->no_coarse & 16u) == 0) {
-                        const uint32_t r = blockIdx.x / K;
-                        const double tq = double(d.totals[seen]);
-                        big_job(r, blockIdx.x % K, r < st.li ? r : r + 1, st.n, mat + seen * B, tq, 1.0 / tq, spec_th, spec_ts);
-                        spec_job_pos = seen;
-                        worked = true;
+                    __syncthreads();
+                    rel_w = s_win[4];
+                    const uint64_t seen = p_word_pos(s_win[5], epoch);  // the first event posted so far
+                    const bool released = s_win[6] != 0ull;
+                    bar_ok = s_flag[0] != 0;
+                    __syncthreads();  // (thread 0 rewrites the words in the next round)
+                    if (released || !bar_ok) break;
+                    bool worked = false;
+                    if constexpr (SPEC) {
+                        if (seen != SEL_NONE && seen != fr_pos && (sync->no_coarse & 16u) == 0) {
+                            fetch_raw(seen);
+                            const double t_ = double(craw_tot), rt_ = 1.0 / t_;
+#pragma unroll
+                            for (int j = 0; j < P_J; j++) fr[j] = count_freq_x(craw[j], t_, rt_);
+                            fr_pos = seen;
+                            if (one_job && has_job && st.n < 128) {
+                                if constexpr (OWN) {  // this workgroup's slot: the whole set, the member to be replaced, or a member that stays
+                                    const uint32_t at = own_slot < st.n ? s_inv[own_slot] : st.n;
+                                    const uint32_t r = own_slot == st.n ? st.n : at == st.li ? st.n - 1 : at < st.li ? at : at - 1;
+                                    small_job(r, blockIdx.x % K, at, st.n, spec_th, spec_ts);
+                                } else {
+                                    const uint32_t r = blockIdx.x / K;
+                                    small_job(r, blockIdx.x % K, r < st.li ? r : r + 1, st.n, spec_th, spec_ts);
+                                }
+                                spec_job_pos = seen;
+                            }
+                            worked = true;
+                        }
                     }
+                    if constexpr (SPEC_BIG) {
+                        if (seen != SEL_NONE && seen != spec_job_pos && one_job && has_job && st.n < 128 &&
+                            (sync->no_coarse & 16u) == 0) {
+                            const uint32_t r = blockIdx.x / K;
+                            const double tq = double(d.totals[seen]);
+                            big_job(r, blockIdx.x % K, r < st.li ? r : r + 1, st.n, mat + seen * B, tq, 1.0 / tq, spec_th, spec_ts);
+                            spec_job_pos = seen;
+                            worked = true;
+                        }
+                    }
+                    if (!worked) __builtin_amdgcn_s_sleep(1);
                 }
-                if (!worked) __builtin_amdgcn_s_sleep(1);
             }
-            gen++;
         }
         if (!bar_ok) { exit_status = SEL_ERROR; break; }
         P_STAMP(1);
@@ -1507,9 +1632,9 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
 #endif
         // the window's outcome came with the release (grid_wait): no further round trip, except for the
         // list of near-threshold candidates when there is one
-        const uint64_t hard = p_ev_pos(hard_w);
-        const bool hard_is_sure = hard_w != SEL_NONE && (hard_w & 1ull) == 0;
-        const uint64_t nlisted = any_listed ? __hip_atomic_load(&sync->soft[epoch % 3][0], RLX_AGENT) : 0ull;
+        const uint64_t hard = p_word_pos(rel_w, epoch);
+        const bool hard_is_sure = hard != SEL_NONE && p_word_sure(rel_w);
+        const bool any_listed = p_word_listed(rel_w) != 0u;
         st.n_windows++;
         // this workgroup's leave-one-out job, should the window end in an accept: the member's
         // counts are requested now (its row does not depend on the event), in the same memory
@@ -1574,17 +1699,47 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // listed candidates ahead of the first event, in stream order: the first one whose exact
         // score beats the threshold is the event; a rejected one changes nothing, so the window's
         // other scores stay valid and nothing is scanned again
-        if (nlisted) {
-            const uint32_t ns = nlisted < P_SOFT ? uint32_t(nlisted) : P_SOFT;
-            if (tid < ns) s_soft[tid] = __hip_atomic_load(&sync->soft[epoch % 3][8 + tid], RLX_AGENT);
-            __syncthreads();
+        bool list_ok = true;
+        if (any_listed) {
+            // every scanning workgroup's list: thread t takes workgroup t's arrival record (the count) and its
+            // entries.  (The gathering block saw the record before it released the window; an entry is waited
+            // for until it carries the window's number.)
+            unsigned long long le[P_LIST];
+#pragma unroll
+            for (uint32_t i = 0; i < P_LIST; i++) le[i] = SEL_NONE;
+            if (uint32_t(tid) < n_work) {  // (only the scanning workgroups list; the mirror block's record may be a window ahead)
+                auto tagged = [&](const unsigned long long *src) {
+                    unsigned long long w = __hip_atomic_load(src, RLX_AGENT);
+                    uint32_t spins = 0;
+                    while (!p_word_is(w, epoch)) {
+                        if (++spins > (1u << 20)) {
+                            list_ok = false;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                        w = __hip_atomic_load(src, RLX_AGENT);
+                    }
+                    return w;
+                };
+                const unsigned long long rec = tagged(&sync->wrec[tid]);
+                const uint32_t c = list_ok ? p_word_listed(rec) : 0u;
+#pragma unroll
+                for (uint32_t i = 0; i < P_LIST; i++)
+                    if (i < c) le[i] = p_word_pos(tagged(&sync->soft[tid][i]), epoch);
+            }
+            list_ok = __syncthreads_or(list_ok ? 0 : 1) == 0;
             uint64_t floor = st.cursor;
-            for (;;) {
-                uint64_t cand = SEL_NONE;
-                for (uint32_t i = 0; i < ns; i++) {
-                    const uint64_t v = s_soft[i];
-                    if (v >= floor && v < hard && v < cand) cand = v;
-                }
+            while (list_ok) {
+                if (tid == 0) s_win[2] = SEL_NONE;
+                __syncthreads();
+                unsigned long long mine = SEL_NONE;
+#pragma unroll
+                for (uint32_t i = 0; i < P_LIST; i++)
+                    if (le[i] != SEL_NONE && le[i] >= floor && le[i] < hard && le[i] < mine) mine = le[i];
+                if (mine != SEL_NONE) atomicMin(s_win + 2, mine);
+                __syncthreads();
+                const uint64_t cand = s_win[2];
+                __syncthreads();  // (thread 0 resets the word in the next round)
                 if (cand == SEL_NONE) break;
                 evaluate(cand);
                 p = cand;
@@ -1599,13 +1754,14 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 }
                 floor = cand + 1;
             }
-            __syncthreads();  // s_soft is rewritten in the next window
         }
+        if (!list_ok) { exit_status = SEL_ERROR; break; }
         if (!accepted && !to_arbiter) {
             if (hard == SEL_NONE) {
                 st.cursor = end;
                 if (end >= st.npos) { exit_status = SEL_DONE; break; }
                 st.window = p_next_window(st, nwg, wg_thresh, wg_scale, wgmode);
+                announce_early(epoch + 1);
                 epoch++;
                 continue;
             }
@@ -1650,6 +1806,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 if (!(jsd > st.thr)) {  // rejected (NaN included, records.rs:91)
                     st.cursor = p + 1;
                     if (st.cursor >= st.npos) { exit_status = SEL_DONE; break; }
+                    announce_early(epoch + 1);
                     epoch++;
                     continue;
                 }
@@ -2053,15 +2210,13 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 if (exit_status == SEL_ERROR || bail || (left && exit_status == SEL_DONE)) break;
                 if (left) continue;
                 } else {
-                const uint32_t slot_t = st.n_loo % P_ACC_SLOTS;
-                st.n_loo++;
                 uint32_t K1 = 1;
                 {
-                    const uint32_t kmax = (n1 + 1 < G) ? (G - 1) / (n1 + 1) : 1u;
+                    const uint32_t kmax = (n1 + 1 <= n_work) ? n_work / (n1 + 1) : 1u;
                     while (K1 * 2 <= kmax && K1 * 2 <= nchunk && K1 * 2 <= 32u) K1 *= 2;
                 }
                 const uint32_t jobs1 = (n1 + 1) * K1;
-                const bool one1 = jobs1 <= G - 1;
+                const bool one1 = jobs1 <= n_work && G > 1;
                 __syncthreads();  // every thread has read the member arrays of the resolve phase
                 if (tid == 0) {   // the candidate as member n (harmless beyond the set if rolled back)
                     s_slot[n] = n;
@@ -2071,11 +2226,11 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     s_rt[n] = rtot;
                 }
                 __syncthreads();
-                unsigned long long *accw = part + uint64_t(slot_t) * 8 * (maxn + 1) * 2;
+                unsigned long long *accw = part;
                 const unsigned long long *accr = accw + uint64_t(blockIdx.x & 7u) * (maxn + 1) * 2;
                 bool first1 = true;
                 for (uint32_t job = blockIdx.x; job < jobs1; job += G) {
-                    if (lead && one1) break;
+                    if ((lead || gath) && one1) break;
                     const uint32_t r = job / K1, part_i = job % K1;
                     const T *mrow = mat + (r < n ? s_pos[r] : 0) * B;
                     const double mtot = r < n ? s_tot[r] : 1.0, mrt = r < n ? s_rt[r] : 1.0;
@@ -2120,8 +2275,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
                 bool acc_ok = true;
                 for (uint32_t r = tid; r <= n1; r += P_THREADS) {
-                    const double h = p_acc_value(p_acc_complete(accr + uint64_t(r) * 2, K1, acc_ok));
-                    const double sv = p_acc_value(p_acc_complete(accr + uint64_t(r) * 2 + 1, K1, acc_ok));
+                    const double h = p_acc_value(p_acc_complete(accr + uint64_t(r) * 2, s_prev + uint64_t(r) * 2, K1, acc_ok));
+                    const double sv = p_acc_value(p_acc_complete(accr + uint64_t(r) * 2 + 1, s_prev + uint64_t(r) * 2 + 1, K1, acc_ok));
                     if (r == n1) {
                         scratch[110] = h;
                         scratch[111] = sv;
@@ -2229,8 +2384,6 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             }
         }
         // ================= replace_lowest (records.rs:94-147) + leave-one-out
-        const uint32_t acc_slot = st.n_loo % P_ACC_SLOTS;
-        st.n_loo++;
         st.n_accepts++;
         // SPEC: a leave-one-out job worked out for this very candidate while the rendezvous was completing
         // goes out FIRST -- its memory-side additions travel while the member arrays are shifted below
@@ -2238,8 +2391,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         if constexpr (SPEC || SPEC_BIG) {
             if (one_job && has_job && !lead && spec_job_pos == p) {
                 if (tid < 8) {  // lane g adds the job's words to group g's replica
-                    unsigned long long *dst = part + uint64_t(acc_slot) * 8 * (maxn + 1) * 2 +
-                                              (uint64_t(tid) * (maxn + 1) + blockIdx.x / K) * 2;
+                    unsigned long long *dst = part + (uint64_t(tid) * (maxn + 1) + blockIdx.x / K) * 2;
                     p_acc_add(dst, spec_th, spec_ts);
                 }
                 job_published = true;
@@ -2272,6 +2424,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     s_pos[i] = c;
                     s_tot[i] = t;
                     s_rt[i] = rt;
+                    if constexpr (OWN) s_inv[a] = i;
                 }
                 if (lane == 0) {
                     s_slot[n - 1] = slot_low;
@@ -2279,6 +2432,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     s_pos[n - 1] = p;
                     s_tot[n - 1] = tot;
                     s_rt[n - 1] = rtot;
+                    if constexpr (OWN) s_inv[slot_low] = n - 1;
                 }
             }
         } else {  // every thread moves its members one place down
@@ -2307,6 +2461,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     s_pos[i] = mv_pos[q];
                     s_tot[i] = mv_t[q];
                     s_rt[i] = mv_rt[q];
+                    if constexpr (OWN) s_inv[mv_slot[q]] = i;
                 }
             }
             if (tid == 0) {
@@ -2315,6 +2470,14 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 s_pos[n - 1] = p;
                 s_tot[n - 1] = tot;
                 s_rt[n - 1] = rtot;
+                if constexpr (OWN) s_inv[slot_low] = n - 1;
+            }
+        }
+        if constexpr (OWN) {
+            // the slot has changed hands: its workgroups' own row becomes the candidate's counts (registers)
+            if (use_own && has_job && own_slot == slot_low) {
+#pragma unroll
+                for (int j = 0; j < P_J; j++) s_own[uint32_t(tid) * P_J + j] = craw[j];
             }
         }
         __syncthreads();
@@ -2327,31 +2490,6 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             q.w = uint32_t(craw[6]) | (uint32_t(craw[7]) << 16);
             *reinterpret_cast<uint4 *>(s_rows + uint64_t(slot_low) * 4096 + uint32_t(tid) * 8) = q;
         }
-        // S_new_i = clamp(S_i - low_i) + f_i.  The mirror block writes it, and the new member's
-        // row, to global memory (it takes no job below, so this overlaps the others' arithmetic).
-        if (lead) {
-            for (uint64_t b0 = 0; b0 < B; b0 += uint64_t(P_J) * P_THREADS) {
-                T cv[P_J];
-                if (!CACHED) {
-#pragma unroll
-                    for (int j = 0; j < P_J; j++) {
-                        const uint64_t i = b0 + uint64_t(j) * P_THREADS + tid;
-                        if (i < B) cv[j] = rp[i];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < P_J; j++) {
-                    const uint64_t i = b0 + uint64_t(j) * P_THREADS + tid;
-                    if (i < B) {
-                        double v = sl[i];
-                        if (v <= DVS_EPS) v = 0.0;
-                        const double f = CACHED ? fr[j] : count_freq_x(cv[j], tot, rtot);
-                        d.S[i] = v + f;
-                        d.M[uint64_t(slot_low) * B + i] = f;
-                    }
-                }
-            }
-        }
         // ================= leave-one-out (get_lowest_record_index, records.rs:220-252, with
         // updated_mean_freqs :276-286) as (n + 1) * K jobs over the workgroups.  A job's two sums
         // (entropy terms, mean-vector total) are added to its member's accumulators as 2^-56
@@ -2360,11 +2498,11 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // (>= 2^-3) convert without rounding.  (Every term is >= 0: the clamps of the reference
         // leave no negative bin here, so there is no NaN to carry.)
         const double rdiv = 1.0 / (dn - 1.0);
-        unsigned long long *acc_all = part + uint64_t(acc_slot) * 8 * (maxn + 1) * 2;          // the slot's replicas
+        unsigned long long *acc_all = part;                                                    // the eight replicas
         const unsigned long long *acc = acc_all + uint64_t(blockIdx.x & 7u) * (maxn + 1) * 2;  // this group's
         bool first_job = true;
         for (uint32_t job = blockIdx.x; job < jobs && has_job; job += G) {
-            if (lead && one_job) break;
+            if ((lead || gath) && one_job) break;
             const uint32_t r = job / K, part_i = job % K;
             const bool is_new = r == n - 1;
             const bool pre = CACHED && !SPEC && one_job;  // member counts already requested above
@@ -2392,7 +2530,9 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 // the rendezvous was completing)
                 if (job_published) continue;
                 double th, ts;
-                small_job(r, part_i, r, n, th, ts);
+                // OWN: r is a SLOT (n: the whole set) -- the member it holds sits at s_inv[r] of the new order
+                const uint32_t ro = (OWN && r < n) ? s_inv[r] : r;
+                small_job(ro, part_i, ro, n, th, ts);
                 if (tid < 8) {  // lane g adds the job's words to group g's replica
                     unsigned long long *dst = acc_all + (uint64_t(tid) * (maxn + 1) + r) * 2;
                     p_acc_add(dst, th, ts);
@@ -2451,24 +2591,6 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             }
         }
         st.cursor = p + 1;
-        if (lead)
-            for (uint32_t i = tid; i < n; i += P_THREADS) d.ord[i] = s_slot[i];
-        if (lead && tid == 0) {  // post-resolve mirror (what resolve_kernel leaves behind)
-            ctl->sum_entropy = st.sumH;
-            ctl->s_is_resum = 0;
-            if (old_lab < d.nlabels) d.inset[old_lab] = 0;
-            if (uint32_t(p) < d.nlabels) d.inset[uint32_t(p)] = 1;
-            d.mH[slot_low] = cand_H;
-            d.mLabel[slot_low] = uint32_t(p);
-            d.mPos[slot_low] = p;
-            d.evlog_pos[ctl->n_logged] = p;
-            d.evlog_kind[ctl->n_logged] = 1;
-            ctl->n_logged++;
-            ctl->cursor = st.cursor;
-            ctl->event_pos = SEL_NONE;
-            ctl->last_jsd = jsd;
-            ctl->ev_n = n;
-        }
         P_STAMP(3);
         // ================= finalize (every workgroup): totals -> delta_jsd -> argmin (strict '<'
         // from 1e6, first index), all from the accumulators
@@ -2482,17 +2604,22 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             if (wave == 0) {
                 const uint32_t r0 = lane, r1 = lane + 64;
                 const bool valid0 = r0 <= n, valid1 = r1 <= n;
+                // (OWN: the accumulators are indexed by slot; entry n is the whole set either way)
+                const uint32_t a0 = (OWN && r0 < n) ? s_slot[r0] : r0, a1 = (OWN && r1 < n) ? s_slot[r1] : r1;
+                // (what the words held when the previous use was read; the differences are this use's)
+                const unsigned long long ph0 = valid0 ? s_prev[a0 * 2] : 0ull, ps0 = valid0 ? s_prev[a0 * 2 + 1] : 0ull;
+                const unsigned long long ph1 = valid1 ? s_prev[a1 * 2] : 0ull, ps1 = valid1 ? s_prev[a1 * 2 + 1] : 0ull;
                 unsigned long long wh0 = 0, ws0 = 0, wh1 = 0, ws1 = 0;
                 uint32_t spins = 0;
                 int ok = 1;
                 for (;;) {
                     if (valid0) {
-                        wh0 = __hip_atomic_load(acc + uint64_t(r0) * 2, RLX_AGENT);
-                        ws0 = __hip_atomic_load(acc + uint64_t(r0) * 2 + 1, RLX_AGENT);
+                        wh0 = __hip_atomic_load(acc + uint64_t(a0) * 2, RLX_AGENT) - ph0;
+                        ws0 = __hip_atomic_load(acc + uint64_t(a0) * 2 + 1, RLX_AGENT) - ps0;
                     }
                     if (valid1) {
-                        wh1 = __hip_atomic_load(acc + uint64_t(r1) * 2, RLX_AGENT);
-                        ws1 = __hip_atomic_load(acc + uint64_t(r1) * 2 + 1, RLX_AGENT);
+                        wh1 = __hip_atomic_load(acc + uint64_t(a1) * 2, RLX_AGENT) - ph1;
+                        ws1 = __hip_atomic_load(acc + uint64_t(a1) * 2 + 1, RLX_AGENT) - ps1;
                     }
                     if (__ballot((valid0 && (p_acc_count(wh0) != K || p_acc_count(ws0) != K)) ||
                                  (valid1 && (p_acc_count(wh1) != K || p_acc_count(ws1) != K))) == 0ull)
@@ -2504,6 +2631,14 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
+                }
+                if (valid0) {
+                    s_prev[a0 * 2] = ph0 + wh0;
+                    s_prev[a0 * 2 + 1] = ps0 + ws0;
+                }
+                if (valid1) {
+                    s_prev[a1 * 2] = ph1 + wh1;
+                    s_prev[a1 * 2 + 1] = ps1 + ws1;
                 }
                 P_STAMP(4);
                 const double h0 = p_acc_value(wh0), sv0 = p_acc_value(ws0);
@@ -2518,11 +2653,11 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 const double dl0 = mem0 ? tj - (h0 - (st.sumH - mH0) * rdiv) : 1e6;  // delta_jsd
                 const double dl1 = mem1 ? tj - (h1 - (st.sumH - mH1) * rdiv) : 1e6;
                 P_STAMP(6);
-                const double mn = dvs_wave_min(fmin(dl0, dl1));
+                const double mn = dvs_wave_min_dpp(fmin(dl0, dl1));
                 const unsigned long long at0 = __ballot(mem0 && dl0 == mn && mn < 1e6);
                 const unsigned long long at1 = __ballot(mem1 && dl1 == mn && mn < 1e6);
                 const uint32_t lw = at0 ? uint32_t(__builtin_ctzll(at0)) : at1 ? 64u + uint32_t(__builtin_ctzll(at1)) : 0u;
-                const double sec = dvs_wave_min(fmin((mem0 && r0 != lw) ? dl0 : 1e6, (mem1 && r1 != lw) ? dl1 : 1e6));
+                const double sec = dvs_wave_min_dpp(fmin((mem0 && r0 != lw) ? dl0 : 1e6, (mem1 && r1 != lw) ? dl1 : 1e6));
                 const bool anyr = __ballot((mem0 && sum_risky(sv0, B)) || (mem1 && sum_risky(sv1, B))) != 0ull;
                 if (lane == 0) {
                     scratch[100] = mn;
@@ -2565,14 +2700,13 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             ev_risky = scratch[105] != 0.0;
             if (scratch[106] == 0.0) { exit_status = SEL_ERROR; break; }
         } else {
-            // larger sets: a grid barrier, then the words are complete (the jobs' adds were
-            // acknowledged before their workgroups arrived)
-            if (!grid_barrier(sync, G, gen, s_flag)) { exit_status = SEL_ERROR; break; }
+            // larger sets: thread t waits for the words of members t, t + 512, ... (their contribution counts)
             P_STAMP(4);
             bool acc_ok = true;
             for (uint32_t r = tid; r <= n; r += P_THREADS) {
-                const double h = p_acc_value(p_acc_complete(acc + uint64_t(r) * 2, K, acc_ok));
-                const double sv = p_acc_value(p_acc_complete(acc + uint64_t(r) * 2 + 1, K, acc_ok));
+                const uint64_t a = (OWN && r < n) ? s_slot[r] : r;  // (OWN: the accumulators are indexed by slot)
+                const double h = p_acc_value(p_acc_complete(acc + a * 2, s_prev + a * 2, K, acc_ok));
+                const double sv = p_acc_value(p_acc_complete(acc + a * 2 + 1, s_prev + a * 2 + 1, K, acc_ok));
                 if (r == n) {
                     scratch[110] = h;
                     scratch[111] = sv;
@@ -2609,6 +2743,52 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 }
             }
             __syncthreads();  // scratch[100..] is rewritten by the next accept
+        }
+        // The mirror block has read the last word another workgroup wrote for this window: it announces itself
+        // for the next one now, ahead of its stores.  Then S_new_i = clamp(S_i - low_i) + f_i and the new
+        // member's row go to global memory (sl is still the old vector: the rebuild below rewrites it) -- what
+        // resolve_kernel would have left behind, also for the kernels that take over an argmin too close to call.
+        announce_early(epoch + 1);
+        if (lead)
+            for (uint32_t i = tid; i < n; i += P_THREADS) d.ord[i] = s_slot[i];
+        if (lead && tid == 0) {  // post-resolve mirror (what resolve_kernel leaves behind)
+            ctl->sum_entropy = st.sumH;
+            ctl->s_is_resum = 0;
+            if (old_lab < d.nlabels) d.inset[old_lab] = 0;
+            if (uint32_t(p) < d.nlabels) d.inset[uint32_t(p)] = 1;
+            d.mH[slot_low] = cand_H;
+            d.mLabel[slot_low] = uint32_t(p);
+            d.mPos[slot_low] = p;
+            d.evlog_pos[ctl->n_logged] = p;
+            d.evlog_kind[ctl->n_logged] = 1;
+            ctl->n_logged++;
+            ctl->cursor = st.cursor;
+            ctl->event_pos = SEL_NONE;
+            ctl->last_jsd = jsd;
+            ctl->ev_n = n;
+        }
+        if (lead) {
+            for (uint64_t b0 = 0; b0 < B; b0 += uint64_t(P_J) * P_THREADS) {
+                T cv[P_J];
+                if (!CACHED) {
+#pragma unroll
+                    for (int j = 0; j < P_J; j++) {
+                        const uint64_t i = b0 + uint64_t(j) * P_THREADS + tid;
+                        if (i < B) cv[j] = rp[i];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < P_J; j++) {
+                    const uint64_t i = b0 + uint64_t(j) * P_THREADS + tid;
+                    if (i < B) {
+                        double v = sl[i];
+                        if (v <= DVS_EPS) v = 0.0;
+                        const double f = CACHED ? fr[j] : count_freq_x(cv[j], tot, rtot);
+                        d.S[i] = v + f;
+                        d.M[uint64_t(slot_low) * B + i] = f;
+                    }
+                }
+            }
         }
         const double band = sel_band(st.total_jsd + st.sumH / dn, B);
         if (any_risky || ev_risky || (n > 1 && dsecond - dmin <= band && dsecond < 1e6)) {
@@ -2679,6 +2859,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         }
         __syncthreads();
         P_STAMP(5);
+        P_STAMP_B0(12);  // (behind the rebuild: the cache's decision)
         if (st.cursor >= st.npos) { exit_status = SEL_DONE; break; }
         st.window = p_next_window(st, nwg, wg_thresh, wg_scale, wgmode);
         epoch++;
@@ -2744,8 +2925,7 @@ static int persist_prepare(dvs_ctx *ctx, dvs_select *s, uint32_t head_stop, hipS
     init.stop_at = head_stop;
     init.seeded = s->persist_seeded ? 1u : 0u;  // (the first launch of a selection whose set-up kernels were skipped)
     init.seed_list = static_cast<const unsigned long long *>(s->d_seed_list);
-    for (int i = 0; i < 3; i++)
-        for (int g = 0; g < 8; g++) init.ev[i][g * 32 + 1] = SEL_NONE;  // (event words; generations and flags 0)
+    for (int g = 0; g < 8; g++) init.rel[g].hint = ~0ull;  // (atomicMin targets; every other word starts as zero)
     // a row per workgroup while a window is at most this many rounds of the grid (default policy only)
     init.wg_thresh = s->params.window ? 0u : 4u;
     init.wg_scale = 1.5f;
@@ -2756,6 +2936,7 @@ static int persist_prepare(dvs_ctx *ctx, dvs_select *s, uint32_t head_stop, hipS
                      (ctx->knobs.persist_no_speculation ? 16u : 0u) |  // (nothing is worked out ahead of the release)
                      0u;
     init.small_rows = s->persist_small ? s->persist_small_rows : 0u;
+    init.lds_bytes = uint32_t(s->persist_lds);
     DVS_HIP(ctx, hipMemcpyAsync(head_stop ? s->psync_head : s->psync, &init, sizeof init, hipMemcpyHostToDevice, on));
     DVS_HIP(ctx, hipMemsetAsync(head_stop ? s->ppart_head : s->ppart, 0, p_acc_bytes(s->persist_maxn), on));
     return DVS_OK;
@@ -2823,7 +3004,8 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     if (ctx->knobs.cu_mask_set) return DVS_OK;
     const bool maxm = s->params.mode == DVS_MODE_MAX && !ctx->knobs.no_persist_max;
     if ((s->params.mode != DVS_MODE_NMOST && !maxm) || !s->h_order.empty() || !s->h_labels.empty()) return DVS_OK;
-    s->persist_grid = uint32_t(ctx->n_cu);  // one 512-thread workgroup per CU: all resident
+    if (s->npos >= P_POS_NONE) return DVS_OK;  // (window words hold 37-bit positions)
+    s->persist_grid = uint32_t(std::min(ctx->n_cu, int(P_MAXG)));  // one 512-thread workgroup per CU: all resident
     if (ctx->knobs.persist_grid) s->persist_grid = uint32_t(std::max(2, std::min(ctx->n_cu, ctx->knobs.persist_grid)));  // (measurement knob)
     const bool cached = B <= uint64_t(P_J) * P_THREADS;
     if (maxm && !cached) return DVS_OK;  // (the growth phase wants the candidate in registers and S in LDS)
@@ -2833,8 +3015,9 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
                        s->params.n_seed >= 2 && s->params.n_seed <= P_SMALL_ROWS && !ctx->knobs.persist_no_small;
     auto lds_for = [&](uint32_t maxn_) {
         return ((B + 1) & ~1ull) * 8 + (cached && s->mat_kind != 1 ? ((B + 3) & ~3ull) * 4 : 0) +
-               (maxm ? ((B + 1) & ~1ull) * 8 : 0) + 128 * 8 + size_t(maxn_) * 52 + 8 + P_SOFT * 8 + 64 +
+               (maxm ? ((B + 1) & ~1ull) * 8 : 0) + 128 * 8 + size_t(maxn_) * 52 + 8 + P_WINWORDS * 8 + 64 +
                128 * 16 + 128 +  // (+ log2_tab's table, + the stamps of a -DDVS_PERSIST_STAMPS build)
+               size_t(maxn_ + 1) * 16 +  // (the accumulators' previous totals)
                (maxm ? p_batch_lds() : 0);
     };
     size_t lds = lds_for(p_maxn(cached, maxm));
@@ -2843,6 +3026,10 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
         if (lds_small <= ctx->lds_per_block) lds = lds_small;
         else s->persist_small = false;
     }
+    // OWN (see the kernel): nmost over count rows in the register cache beyond SMALL -- the slot map and this
+    // workgroup's own member's counts
+    if (cached && !maxm && s->mat_kind != 1 && !s->persist_small)
+        lds += size_t(p_maxn(cached, maxm)) * 4 + size_t(P_J) * P_THREADS * (s->mat_kind == 2 ? 2 : 4);
     s->persist_maxn = s->persist_small ? P_SMALLN : p_maxn(cached, maxm);
     s->persist_maxjobs = s->persist_small ? P_SMALLN + 1 : p_maxjobs(cached, maxm);
     // (MODE_MAX: max_size may be the whole stream; the kernel hands over when its LDS replica is full)

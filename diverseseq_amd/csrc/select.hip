@@ -305,7 +305,10 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, double *scrat
     const uint32_t WIDE = blockDim.x;
     const double *ext_row = nullptr, *ext_H = nullptr;
     unsigned long long gathered_p = SEL_NONE;
-    if (d.gather_all) {
+    // (stepwise re-entry behind the arbiter: the candidate is the one resolve stopped at, still in d.cand --
+    // the gathered slots are not looked at: the caller's buffer may have been reused since the step's apply)
+    const bool reentry = d.gather_all && (ctl->forced == FORCE_ACCEPT || ctl->forced == FORCE_REJECT);
+    if (d.gather_all && !reentry) {
         // stepwise mode: the earliest event among the gathered slots ([pos, H, row]) is this step's
         // event on every rank
         __shared__ int s_best;
@@ -329,9 +332,6 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, double *scrat
         ext_H = src + 1;
         gathered_p = s_best < 0 ? SEL_NONE : (unsigned long long)src[0];
     }
-    // (stepwise re-entry behind the arbiter: the slots have been gathered anew since the decision was left
-    // open -- the candidate is the one resolve stopped at, still in d.cand)
-    const bool reentry = d.gather_all && (ctl->forced == FORCE_ACCEPT || ctl->forced == FORCE_REJECT);
     const uint64_t p = reentry ? ctl->arb_pos : d.gather_all ? gathered_p : ctl->event_pos;
     if (reentry && tid == 0) ctl->event_pos = p;
     if (ctl->ev_kind != 0) return;  // a finalize is pending (arbiter re-entry)
@@ -1165,6 +1165,9 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
                             dbg[2 + 16 * w] / 100.0, dbg[3 + 16 * w] / 100.0, dbg[4 + 16 * w] / 100.0,
                             dbg[6 + 16 * w] / 100.0, dbg[7 + 16 * w] / 100.0, dbg[8 + 16 * w] / 100.0,
                             dbg[5 + 16 * w] / 100.0);
+                if (dbg[9] + dbg[10] + dbg[11] + dbg[12])
+                    fprintf(stderr, "[dvs persist block 0] us inside the phases: window top %.1f own rows scanned %.1f hint look + record %.1f (then: scan = the rest) | behind the rebuild %.1f\n",
+                            dbg[9] / 100.0, dbg[10] / 100.0, dbg[11] / 100.0, dbg[12] / 100.0);
                 if (dbg[16 + 10] + dbg[16 + 12])
                     fprintf(stderr, "[dvs persist] scan + rendezvous: row-per-workgroup windows %llu (%.1f us, %llu rows), "
                             "row-per-wave windows %llu (%.1f us, %llu rows)\n", dbg[16 + 10], dbg[16 + 9] / 100.0,
@@ -1549,9 +1552,18 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     SEL_ALLOC(d.evlog_pos, size_t(npos - n_seed + 2) * 8);
     SEL_ALLOC(d.evlog_kind, size_t(npos - n_seed + 2) * 4);
     if (s->params.flags & DVS_SELECT_STEPWISE) {
-        // the arbiter's row log (rows of accepted candidates may live on other ranks): every event a
-        // selection of this size can be expected to accept, at most 256 MB
-        const uint64_t want = std::min<uint64_t>(npos - n_seed + 2, std::max<uint64_t>(64, (uint64_t(256) << 20) / (B * 8)));
+        // the arbiter's row log (rows of accepted candidates may live on other ranks), sized from what a
+        // selection of this shape accepts: a greedy stream over N positions with a set of n takes about
+        // n (1 + ln(N / n)) events (position i is accepted with probability ~ n / i); four times that plus
+        // slack, never more than the stream has positions, at most 2 GiB (a log that still fills up ends
+        // the arbitration with DVS_ERR_UNSUPPORTED, exact_set.cpp)
+        const uint64_t n_eff = std::max<uint64_t>(1, params->mode == DVS_MODE_MAX
+                                                         ? std::min<uint64_t>(std::max<uint64_t>(params->max_size, n_seed), npos)
+                                                         : n_seed);
+        const double expect = double(n_eff) * (1.0 + std::log(std::max(1.0, double(npos) / double(n_eff))));
+        uint64_t want = uint64_t(4.0 * expect) + 64;
+        want = std::min<uint64_t>(want, std::max<uint64_t>(64, (uint64_t(2) << 30) / (B * 8)));
+        want = std::min<uint64_t>(want, npos - n_seed + 2);
         d.rowlog_cap = uint32_t(want);
         SEL_ALLOC(d.rowlog, size_t(want) * B * 8);
     }
