@@ -287,7 +287,7 @@ class Bench:
         m.close()
         # ... and the persistent kernel itself as a pure stream: the same launch with a threshold no
         # row reaches (no events, a handful of long windows), timed by the same HIP events
-        knobs = {"DVS_PERSIST_NO_EVENTS": "1", "DVS_PERSIST_WG_ROUNDS": "0", "DVS_WINDOW_SCALE": "100000",
+        knobs = {"DVS_PERSIST_NO_EVENTS": "1", "DVS_PERSIST_WG_ROUNDS": "0",  # (no events: also long windows)
                  "DVS_NO_HEAD_PHASE": "1", "DVS_PERSIST_NO_SEEDED": "1"}  # (ONE launch over the whole stream, set up by the set-up kernels)
         saved = {k_: os.environ.get(k_) for k_ in knobs}
         os.environ.update(knobs)

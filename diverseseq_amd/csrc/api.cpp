@@ -110,47 +110,25 @@ void dvs_dev_trim(dvs_ctx *ctx) {
 // the environment's switches, parsed once per context (dvs_internal.h dvs_knobs)
 void dvs_knobs_from_env(dvs_knobs *k) {
     auto on = [](const char *name) { return getenv(name) != nullptr; };
-    auto num = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
-    auto real = [](const char *name) { const char *e = getenv(name); return e ? atof(e) : 0.0; };
     *k = dvs_knobs();
     k->no_uniform_offsets = on("DVS_NO_UNIFORM_OFFSETS");
     k->no_offsets_cache = on("DVS_NO_OFFSETS_CACHE");
     k->counts_u32 = on("DVS_COUNTS_U32");
-    k->hist_no_pk16 = on("DVS_HIST_NO_PK16");
-    k->hist_threads = num("DVS_HIST_THREADS", 0);
-    k->hist_tile_threads = num("DVS_HIST_TILE_THREADS", 0);
-    k->hist_hot_rows = num("DVS_HIST_HOT_ROWS", -1);
-    k->hist_no_split = on("DVS_HIST_NO_SPLIT");
-    k->head_rows = num("DVS_HEAD_ROWS", 0);
     k->build_wait = on("DVS_BUILD_WAIT");
     k->no_packed_upload = on("DVS_NO_PACKED_UPLOAD");
-    k->no_cu_split = on("DVS_NO_CU_SPLIT");
-    k->head_cus = num("DVS_HEAD_CUS", 0);
     k->cu_mask_set = on("HSA_CU_MASK") || on("ROC_GLOBAL_CU_MASK");
     k->no_persist = on("DVS_NO_PERSIST");
-    k->no_persist_max = on("DVS_NO_PERSIST_MAX");
-    k->no_max_batch = on("DVS_NO_MAX_BATCH");
     k->no_head_phase = on("DVS_NO_HEAD_PHASE");
-    k->no_side_stream = on("DVS_NO_SIDE_STREAM");
-    k->keep_labels = on("DVS_KEEP_LABELS");
     k->persist_no_seeded = on("DVS_PERSIST_NO_SEEDED");
-    k->persist_seeded_any = on("DVS_PERSIST_SEEDED");
     k->persist_no_small = on("DVS_PERSIST_NO_SMALL");
-    k->persist_coop = on("DVS_PERSIST_COOP");
-    k->persist_debug = on("DVS_PERSIST_DEBUG");
     k->persist_no_coarse = on("DVS_PERSIST_NO_COARSE");
     k->persist_no_events = on("DVS_PERSIST_NO_EVENTS");
-    k->persist_no_burst_drop = on("DVS_PERSIST_NO_BURST_DROP");
-    k->persist_no_speculation = on("DVS_PERSIST_NO_SPECULATION");
-    k->persist_grid = num("DVS_PERSIST_GRID", 0);
-    k->persist_wg_rounds = num("DVS_PERSIST_WG_ROUNDS", -1);
-    k->persist_wg_scale = real("DVS_PERSIST_WG_SCALE");
-    k->scan_wg_per_cu = num("DVS_SCAN_WG_PER_CU", 0);
-    k->window_scale = real("DVS_WINDOW_SCALE");
-    k->mash_bytewise = on("DVS_MASH_BYTEWISE");
-    k->mash_big_table = on("DVS_MASH_BIG_TABLE");
+    k->persist_debug = on("DVS_PERSIST_DEBUG");
+    const char *rounds = getenv("DVS_PERSIST_WG_ROUNDS");
+    k->persist_wg_rounds = rounds ? atoi(rounds) : -1;
     k->ingest_no_stream = on("DVS_INGEST_NO_STREAM");
-    k->test_persist_fake_error = on("DVS_TEST_KNOBS") && on("DVS_PERSIST_FAKE_ERROR");
+    const char *tk = getenv("DVS_TEST_KNOBS");
+    k->test_persist_fake_error = tk && strstr(tk, "fake_persist_error") != nullptr;
 }
 
 extern "C" {
@@ -235,10 +213,9 @@ hipStream_t dvs_ctx_stream2(dvs_ctx *ctx) {
 bool dvs_ctx_cu_split(dvs_ctx *ctx) {
     if (ctx->cu_split_tried) return ctx->stream_head != nullptr;
     ctx->cu_split_tried = true;
-    if (ctx->knobs.no_cu_split || ctx->n_cu < 128 || ctx->n_cu % 8) return false;
+    if (ctx->n_cu < 128 || ctx->n_cu % 8) return false;
     if (ctx->knobs.cu_mask_set) return false;  // (the bit layout below assumes every CU)
     int head = 64;
-    if (ctx->knobs.head_cus) head = ctx->knobs.head_cus;
     head = std::max(16, std::min(ctx->n_cu / 2, head)) & ~7;
     const uint32_t words = uint32_t(ctx->n_cu + 31) / 32;
     std::vector<uint32_t> lo(words, 0u), hi(words, 0u);

@@ -19,36 +19,28 @@
 // only on dvs_ctx_refresh_knobs, a measurement / test aid): nothing on a per-call path calls getenv.
 // All of them are measurement aids or escape hatches; the defaults are the product.
 struct dvs_knobs {
-    // histogram (kmer_hist.hip)
-    bool no_uniform_offsets = false;  // DVS_NO_UNIFORM_OFFSETS: offsets uploaded even for one length laid end to end
-    bool no_offsets_cache = false;    // DVS_NO_OFFSETS_CACHE: every build validates + uploads its offsets
+    // The library's environment switches, read once per context (and again by dvs_ctx_refresh_knobs).  Every one
+    // is listed in INTEGRATION.md with the test or measurement that uses it; there are no others.
+    // k-mer matrices (kmer_hist.hip, api.cpp)
+    bool no_uniform_offsets = false;  // DVS_NO_UNIFORM_OFFSETS: sequences of one length still get an offsets array on the device
+    bool no_offsets_cache = false;    // DVS_NO_OFFSETS_CACHE: every build validates and uploads its offsets
     bool counts_u32 = false;          // DVS_COUNTS_U32: never 16-bit rows
-    bool hist_no_pk16 = false;        // DVS_HIST_NO_PK16
-    int hist_threads = 0;             // DVS_HIST_THREADS (0: default)
-    int hist_tile_threads = 0;        // DVS_HIST_TILE_THREADS
-    int hist_hot_rows = -1;           // DVS_HIST_HOT_ROWS (-1: default)
-    bool hist_no_split = false;       // DVS_HIST_NO_SPLIT
-    int head_rows = 0;                // DVS_HEAD_ROWS (0: default)
-    bool build_wait = false;          // DVS_BUILD_WAIT: device-resident builds wait for their kernels
+    bool build_wait = false;          // DVS_BUILD_WAIT: device-resident builds wait for their kernels (no split build)
     bool no_packed_upload = false;    // DVS_NO_PACKED_UPLOAD: host sequences cross PCIe one byte per base
-    // context (api.cpp)
-    bool no_cu_split = false;         // DVS_NO_CU_SPLIT
-    int head_cus = 0;                 // DVS_HEAD_CUS
     bool cu_mask_set = false;         // HSA_CU_MASK / ROC_GLOBAL_CU_MASK present: the device reports CUs it will not give
     // selection engines (select.hip, persist.hip)
-    bool no_persist = false, no_persist_max = false, no_max_batch = false, no_head_phase = false, no_side_stream = false;
-    bool keep_labels = false, persist_no_seeded = false, persist_seeded_any = false, persist_no_small = false;
-    bool persist_coop = false, persist_debug = false;
-    bool persist_no_coarse = false, persist_no_events = false, persist_no_burst_drop = false, persist_no_speculation = false;
-    int persist_grid = 0;             // DVS_PERSIST_GRID
-    int persist_wg_rounds = -1;       // DVS_PERSIST_WG_ROUNDS (-1: default)
-    double persist_wg_scale = 0.0;    // DVS_PERSIST_WG_SCALE (0: default)
-    int scan_wg_per_cu = 0;           // DVS_SCAN_WG_PER_CU
-    double window_scale = 0.0;        // DVS_WINDOW_SCALE (0: default)
-    // mash / ingest
-    bool mash_bytewise = false, mash_big_table = false, ingest_no_stream = false;
-    // test-only: honoured only when DVS_TEST_KNOBS=1 is ALSO set (a release run cannot trip over them)
-    bool test_persist_fake_error = false;  // DVS_PERSIST_FAKE_ERROR
+    bool no_persist = false;          // DVS_NO_PERSIST: the multi-launch engine serves every selection
+    bool no_head_phase = false;       // DVS_NO_HEAD_PHASE: no head phase on the CU-masked stream beside the histogram
+    bool persist_no_seeded = false;   // DVS_PERSIST_NO_SEEDED: the set-up kernels build the initial set
+    bool persist_no_small = false;    // DVS_PERSIST_NO_SMALL: small sets use the general instantiation
+    bool persist_no_coarse = false;   // DVS_PERSIST_NO_COARSE: no all-f32 tier in front of the f32-log tier
+    bool persist_no_events = false;   // DVS_PERSIST_NO_EVENTS: a threshold no row reaches, long windows (the pure-stream measurement)
+    bool persist_debug = false;       // DVS_PERSIST_DEBUG: per-launch report on stderr (phase stamps of a -DDVS_PERSIST_STAMPS build)
+    int persist_wg_rounds = -1;       // DVS_PERSIST_WG_ROUNDS: rounds of the grid up to which a window is scanned a row per workgroup (-1: default)
+    // ingest
+    bool ingest_no_stream = false;    // DVS_INGEST_NO_STREAM: host files are uploaded whole before they are parsed
+    // test-only (DVS_TEST_KNOBS=fake_persist_error): the first persistent launch's outcome is read as SEL_ERROR
+    bool test_persist_fake_error = false;
 };
 void dvs_knobs_from_env(dvs_knobs *k);
 

@@ -628,10 +628,10 @@ int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint3
 // a whole-sequence build may leave 16-bit rows (see dvs_matrix): the packed-histogram kernel serves it.
 // Up to 4096 bins only: beyond that the selection engines score rows with the f32-log tier alone,
 // which is bound by its arithmetic, not by the bytes of a row, and their per-event paths read counts
-// one per lane -- measured at 4^7 bins: 22.8 ms per selection with 16-bit rows, 18.3 with 32-bit.
+// one per lane -- measured at 4^7 bins: 22.8 ms per selection with 16-bit rows, 18.3 with 32-bit (round 4,
+// after the engine's hand-overs were rewritten: 24.0 against 20.2 ms for C4's whole input).
 bool dvs_hist_rows_fit_u16(const dvs_ctx *ctx, uint64_t B, size_t n_long) {
-    return n_long == 0 && B <= 4096 && (B & 3) == 0 && !ctx->knobs.counts_u32 &&
-           !ctx->knobs.hist_no_pk16 && !ctx->knobs.hist_threads;
+    return n_long == 0 && B <= 4096 && (B & 3) == 0 && !ctx->knobs.counts_u32;
 }
 
 // Launches the histogram build for sequences already in HBM (d_seqs, nbytes
@@ -677,8 +677,6 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const dvs_seq_view &sv, 
     // 256 threads for whole sequences: with 16-18 KB of LDS each, 8 workgroups (32 waves) fill a CU;
     // measured on 100k x 5 kb: 0.67 ms at 256 threads, 0.78 at 320, 0.86 at 384 and 512
     int nthreads = HIST_THREADS, tile_threads = HIST_THREADS;  // (genome tiles: 256 and 512 measure the same)
-    if (ctx->knobs.hist_threads) nthreads = ctx->knobs.hist_threads;
-    if (ctx->knobs.hist_tile_threads) tile_threads = ctx->knobs.hist_tile_threads;
     const size_t lds = (lds_hist ? ((B * 4 + 15) & ~15ull) : 0) + (CLOG_TBL + 32) * sizeof(double);
 #define DVS_LAUNCH_HIST(NS4, LH, PKD, GRID, TILES, NTHR, HOT)                                             \
     do {                                                                                         \
@@ -702,17 +700,15 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const dvs_seq_view &sv, 
     // when the selection starts; every other row is a streaming store.  Measured on 100k x 4^6:
     // streaming stores -0.04 ms per build + selection, the hot head another -0.01 ms.
     uint32_t hot_rows = uint32_t(std::min<uint64_t>(nseq, (192ull << 20) / (B * (m->kind == 2 ? 2 : 4))));
-    if (ctx->knobs.hist_hot_rows >= 0) hot_rows = uint32_t(ctx->knobs.hist_hot_rows);
     // whole sequences: the packed histogram at 128 threads when the row layout allows it
-    const bool pk16 = lds_hist && (B & 3) == 0 && !ctx->knobs.hist_no_pk16 && !ctx->knobs.hist_threads;
+    const bool pk16 = lds_hist && (B & 3) == 0;
     // A build that does not wait for its kernels is cut in two launches: the head of the matrix first
     // (what a selection reads first: its seeds), the totals of those rows on their way to the host right
     // behind it, then everything else.  The selection's set-up kernels run on the context's second
     // stream beside the second launch (select.hip sel_start).
     uint32_t head_rows = 0;
-    if (m->kind == 2 && no_wait && !ctx->knobs.hist_no_split) {
+    if (m->kind == 2 && no_wait) {
         uint32_t want = DVS_HEAD_ROWS;
-        if (ctx->knobs.head_rows) want = uint32_t(std::max(64, ctx->knobs.head_rows));  // (measurement knob)
         head_rows = std::min<uint32_t>(nseq, want);
     }
     if (head_rows == nseq) head_rows = 0;  // (nothing left to run beside)

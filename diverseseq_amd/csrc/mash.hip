@@ -776,9 +776,9 @@ static int mash_sketch_view(dvs_ctx *ctx, const dvs_seq_view &sv, const uint64_t
         DVS_HIP(ctx, hipMemcpyAsync(d_active.p, active.data(), nseq, hipMemcpyHostToDevice, ctx->stream));
         DVS_HIP(ctx, hipMemcpyAsync(d_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         DVS_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, nseq * 4, ctx->stream));
-        if (num_states == 4 && k <= 32 && (packed || !ctx->knobs.mash_bytewise)) {  // 2-bit packed windows
+        if (num_states == 4 && k <= 32 && true) {  // 2-bit packed windows
             // the small hash set when no active sequence lets more than ~512 windows of a tile through
-            bool small = !ctx->knobs.mash_big_table;
+            bool small = true;
             for (uint32_t q : list) {
                 const long double frac = ((long double)hi[q] - (long double)lo[q]) / 4294967296.0L;
                 if (frac * MASH_TILE > 512.0L) small = false;
@@ -857,7 +857,7 @@ static int mash_sketch_core(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_devic
         return mash_sketch_view(ctx, sv, offsets, nseq, k, sketch_size, num_states, mash_canonical, d_sk_out, d_lens_out);
     }
     DVS_HIP(ctx, hipSetDevice(ctx->device));
-    if (k <= 32 && !ctx->knobs.mash_bytewise && dvs_packed_upload_wanted(ctx, num_states, nbytes)) {
+    if (k <= 32 && dvs_packed_upload_wanted(ctx, num_states, nbytes)) {
         dvs_packed *p = nullptr;
         int rc = dvs_packed_alloc(ctx, nbytes, &p);
         if (!rc) rc = dvs_packed_fill_from_host(ctx, p, seqs);

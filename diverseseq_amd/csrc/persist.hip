@@ -1285,7 +1285,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             else
                 p_scan_rows<T, COARSE>(mat, d.totals, d.rowH, sl, slf, B, st, st.sumH - s_mH[st.li], win,
                                        uint64_t(blockIdx.x) * wpb + wave, nwaves, nrows, lane, nread, nprecise, nmid, coarse_on,
-                                       (sync->no_coarse & 8u) == 0);
+                                       true);
         }
         // SPEC: the candidate this window will most likely end with -- the event word as it stands when
         // this workgroup leaves the scan -- is taken up BEFORE the rendezvous has completed: its counts,
@@ -1586,7 +1586,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     if (released || !bar_ok) break;
                     bool worked = false;
                     if constexpr (SPEC) {
-                        if (seen != SEL_NONE && seen != fr_pos && (sync->no_coarse & 16u) == 0) {
+                        if (seen != SEL_NONE && seen != fr_pos) {
                             fetch_raw(seen);
                             const double t_ = double(craw_tot), rt_ = 1.0 / t_;
 #pragma unroll
@@ -1607,8 +1607,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                         }
                     }
                     if constexpr (SPEC_BIG) {
-                        if (seen != SEL_NONE && seen != spec_job_pos && one_job && has_job && st.n < 128 &&
-                            (sync->no_coarse & 16u) == 0) {
+                        if (seen != SEL_NONE && seen != spec_job_pos && one_job && has_job && st.n < 128) {
                             const uint32_t r = blockIdx.x / K;
                             const double tq = double(d.totals[seen]);
                             big_job(r, blockIdx.x % K, r < st.li ? r : r + 1, st.n, mat + seen * B, tq, 1.0 / tq, spec_th, spec_ts);
@@ -2930,10 +2929,7 @@ static int persist_prepare(dvs_ctx *ctx, dvs_select *s, uint32_t head_stop, hipS
     init.wg_thresh = s->params.window ? 0u : 4u;
     init.wg_scale = 1.5f;
     if (ctx->knobs.persist_wg_rounds >= 0) init.wg_thresh = uint32_t(ctx->knobs.persist_wg_rounds);
-    if (ctx->knobs.persist_wg_scale > 0.0) init.wg_scale = float(ctx->knobs.persist_wg_scale);
     init.no_coarse = (ctx->knobs.persist_no_coarse ? 1u : 0u) | (ctx->knobs.persist_no_events ? 2u : 0u) |
-                     (ctx->knobs.persist_no_burst_drop ? 8u : 0u) |
-                     (ctx->knobs.persist_no_speculation ? 16u : 0u) |  // (nothing is worked out ahead of the release)
                      0u;
     init.small_rows = s->persist_small ? s->persist_small_rows : 0u;
     init.lds_bytes = uint32_t(s->persist_lds);
@@ -2981,12 +2977,8 @@ static int persist_launch(dvs_ctx *ctx, dvs_select *s, const T *mat, uint32_t gr
     // time-outs in a row every later selection of the context too (ctx->persist_timeouts).  hipLaunchCooperativeKernel adds a runtime
     // check of the same arithmetic and no reservation, and costs ~0.2 ms per selection on this stack
     // (a step of 2.13 -> 1.91 ms without it: the launch itself starts 40 us later, the memset in front
-    // of it and the copy behind it take 35 us longer each, and the kernel runs 3 % slower);
-    // DVS_PERSIST_COOP=1 turns it back on.
-    hipError_t le = s->persist_coop
-                        ? hipLaunchCooperativeKernel(fn, dim3(grid), dim3(P_THREADS), args,
-                                                     uint32_t(s->persist_lds), on)
-                        : hipLaunchKernel(fn, dim3(grid), dim3(P_THREADS), args, s->persist_lds, on);
+    // of it and the copy behind it take 35 us longer each, and the kernel runs 3 % slower): it is not used.
+    hipError_t le = hipLaunchKernel(fn, dim3(grid), dim3(P_THREADS), args, s->persist_lds, on);
     if (s->time_scan) (void)hipEventRecord(e1, on);
     if (le != hipSuccess) {
         (void)hipGetLastError();
@@ -3002,11 +2994,10 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
     if (ctx->knobs.no_persist || ctx->persist_timeouts >= 3) return DVS_OK;
     // a process-wide CU mask hides CUs the device still reports: the grid below could never be resident
     if (ctx->knobs.cu_mask_set) return DVS_OK;
-    const bool maxm = s->params.mode == DVS_MODE_MAX && !ctx->knobs.no_persist_max;
+    const bool maxm = s->params.mode == DVS_MODE_MAX;
     if ((s->params.mode != DVS_MODE_NMOST && !maxm) || !s->h_order.empty() || !s->h_labels.empty()) return DVS_OK;
     if (s->npos >= P_POS_NONE) return DVS_OK;  // (window words hold 37-bit positions)
     s->persist_grid = uint32_t(std::min(ctx->n_cu, int(P_MAXG)));  // one 512-thread workgroup per CU: all resident
-    if (ctx->knobs.persist_grid) s->persist_grid = uint32_t(std::max(2, std::min(ctx->n_cu, ctx->knobs.persist_grid)));  // (measurement knob)
     const bool cached = B <= uint64_t(P_J) * P_THREADS;
     if (maxm && !cached) return DVS_OK;  // (the growth phase wants the candidate in registers and S in LDS)
     // SMALL sets (see the kernel): nmost, 16-bit rows of 4096 bins, every member's row in LDS
@@ -3053,12 +3044,6 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
             hit = ctx->persist_fits.emplace(key, fits).first;
         }
         if (!hit->second) return DVS_OK;
-    }
-    s->persist_coop = false;
-    if (ctx->knobs.persist_coop) {
-        int coop = 0;
-        (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, ctx->device);
-        s->persist_coop = coop != 0;
     }
     rc = dvs_dev_alloc(ctx, &s->psync, sizeof(PSync), "persistent sync block");
     if (!rc) rc = dvs_dev_alloc(ctx, &s->ppart, p_acc_bytes(s->persist_maxn) + (maxm ? p_batch_bytes() : 0),

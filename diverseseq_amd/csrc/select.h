@@ -104,7 +104,6 @@ struct dvs_select {
     bool scan_hot = false;
     // persistent single-launch engine (persist.hip)
     bool persist = false;
-    bool persist_coop = false;       // launched with hipLaunchCooperativeKernel
     bool persist_fell_back = false;  // the persistent kernel gave up (not co-resident): multi-launch engine from the seeds
     uint32_t persist_grid = 0, persist_maxn = 0, persist_maxjobs = 0;
     bool persist_small = false;       // the SMALL instantiation: member count rows in every workgroup's LDS

@@ -1284,7 +1284,7 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
         mb_rows_seen = c.mb_rows;
         mb_round_pairs = 0;
         const bool mb_can = mb_dense && iters > 1 && c.mode == DVS_MODE_MAX && c.size < c.max_size && c.s_is_resum != 0 &&
-                            !(s->params.flags & DVS_SELECT_STEPWISE) && !ctx->knobs.no_max_batch;
+                            !(s->params.flags & DVS_SELECT_STEPWISE);
         const bool mb_probe = mb_can && !mb_useful && ++mb_idle_rounds >= 4;
         if (mb_probe || mb_useful) mb_idle_rounds = 0;
         const int mb_iters = !mb_can ? 0 : mb_useful ? iters : mb_probe ? 2 : 0;  // (a selection starts with them on)
@@ -1313,7 +1313,7 @@ static void sel_plan_setup_stream(dvs_ctx *ctx, dvs_select *s) {
     s->setup_side = nullptr;
     s->head_phase = false;
     if (s->mat->head_rows_built && s->params.n_seed <= s->mat->head_rows_built && s->h_order.empty() &&
-        !(s->params.flags & DVS_SELECT_STEPWISE) && !ctx->knobs.no_side_stream) {
+        !(s->params.flags & DVS_SELECT_STEPWISE)) {
         s->head_phase = s->mat->rest_beside_head && ctx->stream_head && s->persist &&
                         s->params.mode == DVS_MODE_NMOST && s->params.window == 0 &&
                         s->cap + 2 <= uint32_t(ctx->head_cus) && s->npos > 4ull * s->mat->head_rows_built &&
@@ -1423,7 +1423,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     // label-free (label = position: the persistent engine qualifies) and the caller's values are
     // put back on the way out (dvs_select_get_members, dvs_select_delta_jsd).
     const uint32_t *caller_labels = nullptr;
-    if (labels && !order && params->mode != DVS_MODE_SET && !ctx->knobs.keep_labels) {
+    if (labels && !order && params->mode != DVS_MODE_SET) {
         bool distinct = true;
         std::vector<uint32_t> sorted(labels, labels + npos);
         std::sort(sorted.begin(), sorted.end());
@@ -1504,7 +1504,6 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     s->scan_lds = 16 + (s->base_in_lds ? B * 8 : 0);
     const uint32_t wg_fit = s->base_in_lds ? std::max<uint32_t>(1, uint32_t((160 * 1024) / (B * 8 + 512))) : 4;
     uint32_t wg_per_cu = std::min<uint32_t>(wg_fit, 2);  // 16 waves per CU, 16 KB of loads in flight each
-    if (ctx->knobs.scan_wg_per_cu) wg_per_cu = uint32_t(std::max(1, ctx->knobs.scan_wg_per_cu));
     s->scan_grid = std::max<uint32_t>(1, uint32_t(ctx->n_cu) * wg_per_cu);
     s->loo_grid = cap;
     // measured slower than three launches (one CU does the whole leave-one-out pass): opt-in only
@@ -1607,10 +1606,10 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     // cache is begun by that kernel itself -- S, the entropy sum, the leave-one-out pass and the first
     // lowest member from nothing but the seed positions -- instead of four launches in front of it
     // (sets of up to 32: beyond that the S of the seeds -- a memory round trip per four members -- costs
-    // what the launches cost; DVS_PERSIST_SEEDED=1 forces it for any size, DVS_PERSIST_NO_SEEDED=1 turns it off)
+    // what the launches cost; DVS_PERSIST_NO_SEEDED=1 turns it off)
     // (a STEPWISE selection never launches the persistent kernel: its set-up kernels must run)
     s->seeded_start = s->persist && params->mode == DVS_MODE_NMOST && B <= 4096 && !order && !labels &&
-                      !(s->params.flags & DVS_SELECT_STEPWISE) && n_seed >= 2 && (n_seed <= 32 || ctx->knobs.persist_seeded_any) && !ctx->knobs.persist_no_seeded;
+                      !(s->params.flags & DVS_SELECT_STEPWISE) && n_seed >= 2 && n_seed <= 32 && !ctx->knobs.persist_no_seeded;
     s->persist_seeded = s->seeded_start;
     if (size_t(n_seed) * sizeof(uint64_t) <= 4096 - SEL_SEEDS_AT) {
         s->d_seed_list = reinterpret_cast<unsigned char *>(d.ctl) + SEL_SEEDS_AT;
@@ -1683,7 +1682,7 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     // measured on the north-star shape: {2, 3, 4} x window_min {256..2048}, and power laws
     // wc * gap^0.5..0.75 for the early stream, are all within 3 % of each other
     c.wscale = 4.0;
-    if (ctx->knobs.window_scale > 0.0) c.wscale = ctx->knobs.window_scale;
+    if (ctx->knobs.persist_no_events) c.wscale = 1e5;  // (the pure-stream measurement: a few long windows)
     s->ctl0 = c;  // (sel_seed adds the window policy of the engine in charge and uploads it)
     s->seed_positions = seeds;
 

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-os.environ.update({"DVS_PERSIST_NO_EVENTS": "1", "DVS_PERSIST_WG_ROUNDS": "0", "DVS_WINDOW_SCALE": "100000",
+os.environ.update({"DVS_PERSIST_NO_EVENTS": "1", "DVS_PERSIST_WG_ROUNDS": "0", 
                    "DVS_NO_HEAD_PHASE": "1", "DVS_PERSIST_NO_SEEDED": "1"})
 from diverseseq_amd import engine  # noqa: E402
 

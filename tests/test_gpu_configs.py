@@ -123,8 +123,7 @@ def test_persistent_engine_falls_back_to_the_multi_launch_engine(ctx, monkeypatc
     sel = m.nmost(11)
     assert sel.summary().engine == 1
     _assert_selection(sel, exp)
-    monkeypatch.setenv("DVS_TEST_KNOBS", "1")  # (test-only switches are honoured only with this one set as well)
-    monkeypatch.setenv("DVS_PERSIST_FAKE_ERROR", "1")  # the first launch's outcome is read as SEL_ERROR
+    monkeypatch.setenv("DVS_TEST_KNOBS", "fake_persist_error")  # (test-only: the first launch's outcome is read as SEL_ERROR)
     sel = m.nmost(11)
     assert sel.summary().engine == 0
     _assert_selection(sel, exp)
@@ -530,7 +529,7 @@ def test_head_phase_of_a_split_build_vs_oracle(ctx, k, n, bad_seeds):
     del keep
 
 
-@pytest.mark.parametrize("env", [{"DVS_NO_HEAD_PHASE": "1"}, {"DVS_NO_CU_SPLIT": "1"}, {"DVS_PERSIST_COOP": "1"}, {"DVS_HEAD_CUS": "32"}])
+@pytest.mark.parametrize("env", [{"DVS_NO_HEAD_PHASE": "1"}, {"DVS_PERSIST_NO_SEEDED": "1"}, {"DVS_BUILD_WAIT": "1"}])
 def test_head_phase_knobs_do_not_change_the_answer(env, monkeypatch):
     from diverseseq_amd import engine
 
