@@ -146,7 +146,8 @@ struct PSync {
     const unsigned long long *seed_list;  // ... those positions (ctl->size of them)
     uint32_t small_rows;  // SMALL instantiation: member rows the LDS replica has room for
     uint32_t lds_bytes;   // the launch's dynamic LDS (a -DDVS_PERSIST_STAMPS build keeps its ticks in the last 128 bytes)
-    uint32_t pad2[54];
+    uint32_t wmax;        // longest window of this engine (the control block's cap is the multi-launch scan's)
+    uint32_t pad2[53];
     PRel rel[8];                            // one copy per group g = blockIdx % 8
     unsigned long long wrec[P_MAXG];        // arrival record of every workgroup (a window word)
     unsigned long long soft[P_MAXG][P_LIST];  // the candidates a workgroup listed in the current window (window words)
@@ -399,14 +400,16 @@ __device__ __forceinline__ void p_scan_rows(const T *__restrict__ mat,
         }
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, xmin = 0.0;
         if (vec) {
-            const uint64_t full = B - B % (256 * P_CH);
+            // (behind the COARSE tier this pass sees a few dozen rows per selection: half the burst, half the registers)
+            constexpr int F_CH = COARSE ? P_CH / 2 : P_CH;
+            const uint64_t full = B - B % (256 * F_CH);
             uint64_t i0 = 0;
-            for (; i0 < full; i0 += 256 * P_CH) {  // P_CH chunks of 1 KiB per wave instruction per burst
-                Raw4<T> raw[P_CH];
+            for (; i0 < full; i0 += 256 * F_CH) {  // F_CH chunks of 1 KiB per wave instruction per burst
+                Raw4<T> raw[F_CH];
 #pragma unroll
-                for (int j = 0; j < P_CH; j++) raw[j].load(rp + i0 + uint64_t(j) * 256 + lane * 4);
+                for (int j = 0; j < F_CH; j++) raw[j].load(rp + i0 + uint64_t(j) * 256 + lane * 4);
 #pragma unroll
-                for (int j = 0; j < P_CH; j++) {
+                for (int j = 0; j < F_CH; j++) {
                     const uint64_t i = i0 + uint64_t(j) * 256 + lane * 4;
                     const double2 b01 = *reinterpret_cast<const double2 *>(sl + i);
                     const double2 b23 = *reinterpret_cast<const double2 *>(sl + i + 2);
@@ -879,7 +882,10 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     if (head_phase) st.npos = sync->stop_at;  // (the next launch carries on from the mirrored state)
     st.window = ctl->window;
     st.wmin = ctl->window_min;
-    st.wmax = ctl->window_max;
+    // (a window costs this engine nothing for being long: every wave looks at the hint word before every row and
+    // stops behind the first event -- the cap only decides how often an event-free stretch of the late stream is
+    // interrupted by a rendezvous and its drain)
+    st.wmax = sync->wmax > ctl->window_max ? sync->wmax : ctl->window_max;
     st.n = ctl->size;
     st.li = ctl->lowest;
     st.sumH = ctl->sum_entropy;
@@ -2883,7 +2889,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     }
     if (lead && tid == 0) {
         ctl->cursor = st.cursor;
-        ctl->window = st.window;
+        ctl->window = st.window < ctl->window_max ? st.window : ctl->window_max;  // (the multi-launch scan's cap)
         ctl->n_windows += st.n_windows;
         ctl->n_events += st.n_events;
         ctl->n_accepts += st.n_accepts;
@@ -2933,6 +2939,7 @@ static int persist_prepare(dvs_ctx *ctx, dvs_select *s, uint32_t head_stop, hipS
                      0u;
     init.small_rows = s->persist_small ? s->persist_small_rows : 0u;
     init.lds_bytes = uint32_t(s->persist_lds);
+    init.wmax = uint32_t(std::min<uint64_t>(s->npos, 0xFFFFFFFFull));
     DVS_HIP(ctx, hipMemcpyAsync(head_stop ? s->psync_head : s->psync, &init, sizeof init, hipMemcpyHostToDevice, on));
     DVS_HIP(ctx, hipMemsetAsync(head_stop ? s->ppart_head : s->ppart, 0, p_acc_bytes(s->persist_maxn), on));
     return DVS_OK;

@@ -12,7 +12,7 @@ import sys
 txt = open(sys.argv[1]).read().splitlines()
 out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "", "unit": "us per selection (sum over the launch), s_memrealtime at 100 MHz",
        "source": "scripts/stamps.sh: library built with -DDVS_PERSIST_STAMPS, bench.py --steps 4 --no-side-runs, DVS_PERSIST_DEBUG=1",
-       "phases": {"scan": "this workgroup's share of the window's rows", "bar1": "arrival -> release of the window's rendezvous "
+       "phases": {"scan": "this workgroup's share of the window's rows", "bar1": "arrival record stored -> release seen "
                   "(the accept's frequencies and this workgroup's leave-one-out job are worked out in here)",
                   "resolve": "release -> accept decided", "loo": "publish the job, shift the member arrays, mirror (mirror block)",
                   "bar2": "wait for the leave-one-out totals", "partials": "totals -> delta_jsd", "combine": "argmin, hand-over through LDS",
@@ -29,6 +29,13 @@ for line in txt:
     if m and kind:
         vals = dict(re.findall(r"([a-z0-9\- ]+?) ([0-9.]+)(?: \||$| )", m.group(2).replace("|", "")))
         out["launches"][kind][m.group(1)] = {k.strip(): float(v) for k, v in vals.items()}
+        continue
+    m = re.match(r"\[dvs persist block 0\] us inside the phases: window top ([0-9.]+) own rows scanned ([0-9.]+) hint look \+ record ([0-9.]+) .*behind the rebuild ([0-9.]+)", line)
+    if m and kind:
+        out["launches"][kind]["block 0, inside the phases"] = {
+            "window top (barrier, window words reset)": float(m.group(1)), "own rows scanned": float(m.group(2)),
+            "workgroup barrier + arrival record stored": float(m.group(3)), "behind the rebuild": float(m.group(4)),
+            "note": "these four are taken out of `scan` (which keeps only what lies between the last row and the arrival) and of `rebuild`"}
         continue
     m = re.match(r"\[dvs persist\] scan \+ rendezvous: row-per-workgroup windows (\d+) \(([0-9.]+) us, (\d+) rows\), row-per-wave windows (\d+) \(([0-9.]+) us, (\d+) rows\)", line)
     if m and kind:
