@@ -151,6 +151,11 @@ struct PSync {
     PRel rel[8];                            // one copy per group g = blockIdx % 8
     unsigned long long wrec[P_MAXG];        // arrival record of every workgroup (a window word)
     unsigned long long soft[P_MAXG][P_LIST];  // the candidates a workgroup listed in the current window (window words)
+#ifdef DVS_PERSIST_STAMPS
+    // four traced windows (epochs 12, 24, 36, 48): 100 MHz ticks per workgroup at the window's top, at its arrival record,
+    // when it saw the release; [3] = the gathering block's own: gather begun, last record seen, release stored
+    unsigned long long trace[4][4][P_MAXG];
+#endif
     unsigned long long dbg2[16];   // block 0 (owns a job): phase ticks
     unsigned long long dbg[16];    // mirror block: 100 MHz ticks per phase (scan, bar1, resolve, loo, bar2, finalize)
 };
@@ -1240,9 +1245,22 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             t_prev = t_now;                                                \
         }                                                                  \
     } while (0)
+// one window's timeline across the grid (DVS_PERSIST_DEBUG prints it): slot `which` of the traced window
+#define P_TRACE(which)                                                                             \
+    do {                                                                                           \
+        if (tid == 0 && (epoch == 12 || epoch == 24 || epoch == 36 || epoch == 48))               \
+            sync->trace[epoch / 12 - 1][which][blockIdx.x] = __builtin_amdgcn_s_memrealtime();     \
+    } while (0)
+#define P_TRACE_G(slot)                                                                            \
+    do {                                                                                           \
+        if (tid == 0 && (epoch == 12 || epoch == 24 || epoch == 36 || epoch == 48))               \
+            sync->trace[epoch / 12 - 1][3][slot] = __builtin_amdgcn_s_memrealtime();               \
+    } while (0)
 #else
 #define P_STAMP(k) do { } while (0)
 #define P_STAMP_B0(k) do { } while (0)
+#define P_TRACE(which) do { } while (0)
+#define P_TRACE_G(slot) do { } while (0)
 #endif
     for (;;) {
         // The loop body's view of the bin count and the thread index goes through an empty asm:
@@ -1272,6 +1290,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         }
         __syncthreads();
         P_STAMP_B0(9);  // (the top of the window: its barrier)
+        P_TRACE(0);
 #ifdef DVS_PERSIST_STAMPS
         const unsigned long long t_window = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1504,11 +1523,13 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             const uint32_t nl = *win.nlist;
             const unsigned long long own = s_win[0] | ((unsigned long long)(nl < P_LIST ? nl : P_LIST) << 1);
             if (tid == 0 && early_rec != epoch) __hip_atomic_store(&sync->wrec[blockIdx.x], own, RLX_AGENT);
-            P_STAMP_B0(11);  // (the look at the hint, the candidate's row requested, the workgroup's barrier, the record stored)
+            P_STAMP_B0(11);  // (the workgroup's barrier, the record stored)
+            P_TRACE(1);
             if (gath) {
                 // ONE wave gathers: lane l waits for the records of workgroups l, l + 64, l + 128, l + 192 (four loads in
                 // flight per look), the minimum is taken by DPP, lanes 0..7 store the release word -- no LDS, no
                 // barrier between the last record's arrival and the release
+                P_TRACE_G(0);
                 if (wave == 0) {
                     constexpr uint32_t Q = P_MAXG / 64;
                     unsigned long long w[Q];
@@ -1542,6 +1563,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                         }
                         __builtin_amdgcn_s_sleep(1);
                     }
+                    P_TRACE_G(1);
                     unsigned long long m = own & ~6ull, fl = own & 6ull;
 #pragma unroll
                     for (uint32_t q = 0; q < Q; q++)
@@ -1554,6 +1576,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     const unsigned long long relw = m | (anyl ? 2ull : 0ull);
                     if (ok && lane < 8) __hip_atomic_store(&sync->rel[lane].rel, relw, RLX_AGENT);
                     if (!ok && lane == 0) __hip_atomic_store(&sync->timeout, 1u, RLX_AGENT);
+                    P_TRACE_G(2);
                     if (lane == 0) {
                         s_win[4] = relw;
                         s_flag[0] = ok ? 1 : 0;
@@ -1621,11 +1644,15 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                             worked = true;
                         }
                     }
-                    if (!worked) __builtin_amdgcn_s_sleep(1);
+                    if (!worked) {
+                        __builtin_amdgcn_s_sleep(1);
+                        for (uint32_t z = (sync->no_coarse >> 8) & 31u; z > 0; z--) __builtin_amdgcn_s_sleep(4);  // EXPERIMENT
+                    }
                 }
             }
         }
         if (!bar_ok) { exit_status = SEL_ERROR; break; }
+        P_TRACE(2);
         P_STAMP(1);
 #ifdef DVS_PERSIST_STAMPS
         if (lead && tid == 0) {  // scan + rendezvous time and window count by scan mode, rows per mode
@@ -2937,6 +2964,7 @@ static int persist_prepare(dvs_ctx *ctx, dvs_select *s, uint32_t head_stop, hipS
     if (ctx->knobs.persist_wg_rounds >= 0) init.wg_thresh = uint32_t(ctx->knobs.persist_wg_rounds);
     init.no_coarse = (ctx->knobs.persist_no_coarse ? 1u : 0u) | (ctx->knobs.persist_no_events ? 2u : 0u) |
                      0u;
+    if (getenv("DVS_X_POLLSLEEP")) init.no_coarse |= (uint32_t(atoi(getenv("DVS_X_POLLSLEEP"))) & 31u) << 8;  // EXPERIMENT
     init.small_rows = s->persist_small ? s->persist_small_rows : 0u;
     init.lds_bytes = uint32_t(s->persist_lds);
     init.wmax = uint32_t(std::min<uint64_t>(s->npos, 0xFFFFFFFFull));
@@ -3061,6 +3089,11 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
 }
 
 size_t dvs_persist_dbg_offset(void) { return offsetof(PSync, dbg2); }  // dbg2[16] then dbg[16]
+#ifdef DVS_PERSIST_STAMPS
+size_t dvs_persist_trace_offset(void) { return offsetof(PSync, trace); }
+#else
+size_t dvs_persist_trace_offset(void) { return 0; }
+#endif
 
 int dvs_persist_launch(dvs_ctx *ctx, dvs_select *s) {
     return dvs_mat_dispatch(s->mat, [&](auto *mp) { return persist_launch(ctx, s, mp, s->persist_grid, 0u, ctx->stream); });

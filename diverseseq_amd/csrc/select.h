@@ -151,3 +151,4 @@ int dvs_persist_launch_head(dvs_ctx *ctx, dvs_select *s, uint32_t grid, uint32_t
 int dvs_persist_prepare_main(dvs_ctx *ctx, dvs_select *s);
 int dvs_persist_prepare_head(dvs_ctx *ctx, dvs_select *s, uint32_t stop_at, hipStream_t on);
 size_t dvs_persist_dbg_offset(void);
+size_t dvs_persist_trace_offset(void);  // 0 unless built with -DDVS_PERSIST_STAMPS

@@ -1165,6 +1165,34 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
                             dbg[2 + 16 * w] / 100.0, dbg[3 + 16 * w] / 100.0, dbg[4 + 16 * w] / 100.0,
                             dbg[6 + 16 * w] / 100.0, dbg[7 + 16 * w] / 100.0, dbg[8 + 16 * w] / 100.0,
                             dbg[5 + 16 * w] / 100.0);
+                if (dvs_persist_trace_offset()) {  // four windows' timelines across the grid
+                    std::vector<unsigned long long> tr(4 * 4 * 256);
+                    if (hipMemcpy(tr.data(), static_cast<char *>(blk) + dvs_persist_trace_offset(), tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                        const uint32_t G = which ? s->persist_grid : uint32_t(ctx->head_cus);
+                        for (int w_ = 0; w_ < 4; w_++) {
+                            const unsigned long long *t0 = &tr[(w_ * 4 + 0) * 256], *t1 = &tr[(w_ * 4 + 1) * 256], *t2 = &tr[(w_ * 4 + 2) * 256], *tg = &tr[(w_ * 4 + 3) * 256];
+                            if (!tg[2] || G < 4) continue;
+                            std::vector<double> top, arr, seen;
+                            unsigned long long first_top = ~0ull;
+                            for (uint32_t b = 0; b + 2 < G; b++) if (t0[b]) first_top = std::min(first_top, t0[b]);
+                            for (uint32_t b = 0; b + 2 < G; b++) {
+                                if (!t0[b] || !t1[b] || !t2[b]) continue;
+                                top.push_back((t0[b] - first_top) / 100.0);
+                                arr.push_back((t1[b] - first_top) / 100.0);
+                                seen.push_back((double(t2[b]) - double(tg[2])) / 100.0);
+                            }
+                            if (arr.empty()) continue;
+                            auto srt = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); };
+                            srt(top); srt(arr); srt(seen);
+                            auto q_ = [](const std::vector<double> &v, double f) { return v[size_t(f * (v.size() - 1))]; };
+                            fprintf(stderr, "[dvs persist trace] window %d: tops 0 / %.2f / %.2f (min/median/max us), records stored %.2f / %.2f / %.2f / %.2f (min/median/90%%/max), "
+                                    "gather begun %.2f, last record seen %.2f, release stored %.2f, release seen +%.2f / +%.2f / +%.2f (min/median/max after it was stored)\n",
+                                    w_ * 12 + 12, q_(top, 0.5), top.back(), arr.front(), q_(arr, 0.5), q_(arr, 0.9), arr.back(),
+                                    (double(tg[0]) - double(first_top)) / 100.0, (double(tg[1]) - double(first_top)) / 100.0, (double(tg[2]) - double(first_top)) / 100.0,
+                                    seen.front(), q_(seen, 0.5), seen.back());
+                        }
+                    }
+                }
                 if (dbg[9] + dbg[10] + dbg[11] + dbg[12])
                     fprintf(stderr, "[dvs persist block 0] us inside the phases: window top %.1f own rows scanned %.1f hint look + record %.1f (then: scan = the rest) | behind the rebuild %.1f\n",
                             dbg[9] / 100.0, dbg[10] / 100.0, dbg[11] / 100.0, dbg[12] / 100.0);
