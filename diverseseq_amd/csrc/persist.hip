@@ -1644,10 +1644,10 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                             worked = true;
                         }
                     }
-                    if (!worked) {
-                        __builtin_amdgcn_s_sleep(1);
-                        for (uint32_t z = (sync->no_coarse >> 8) & 31u; z > 0; z--) __builtin_amdgcn_s_sleep(4);  // EXPERIMENT
-                    }
+                    // (one poller, one look in flight: a second poller half a round trip behind the first -- and a second
+                    // gathering wave -- made every round trip slower, 1.53 -> 1.71 ms per step; waiting 0.1-0.4 us
+                    // longer between looks changed nothing, 0.85 us cost 4 %: profiles/r04_polling_ab.txt)
+                    if (!worked) __builtin_amdgcn_s_sleep(1);
                 }
             }
         }
@@ -2964,7 +2964,6 @@ static int persist_prepare(dvs_ctx *ctx, dvs_select *s, uint32_t head_stop, hipS
     if (ctx->knobs.persist_wg_rounds >= 0) init.wg_thresh = uint32_t(ctx->knobs.persist_wg_rounds);
     init.no_coarse = (ctx->knobs.persist_no_coarse ? 1u : 0u) | (ctx->knobs.persist_no_events ? 2u : 0u) |
                      0u;
-    if (getenv("DVS_X_POLLSLEEP")) init.no_coarse |= (uint32_t(atoi(getenv("DVS_X_POLLSLEEP"))) & 31u) << 8;  // EXPERIMENT
     init.small_rows = s->persist_small ? s->persist_small_rows : 0u;
     init.lds_bytes = uint32_t(s->persist_lds);
     init.wmax = uint32_t(std::min<uint64_t>(s->npos, 0xFFFFFFFFull));
