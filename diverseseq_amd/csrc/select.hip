@@ -1605,7 +1605,6 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
                                     hipMemcpyHostToDevice, ctx->stream));
     }
 #undef SEL_ALLOC
-    SEL_HIP(hipMemsetAsync(d.wg_rows, 0, size_t(s->scan_grid) * 8, ctx->stream));
 
     static_assert(sizeof(SelCtl) <= 4096, "control block must fit a cached pinned block");
     {
@@ -1630,6 +1629,10 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     if (s->setup_side) s->used_side_streams = true;
     SEL_HIP(hipMemsetAsync(d.inset, 0, std::max<size_t>(nlabels, 1), s->setup_side ? s->setup_side : ctx->stream));
     s->inset_clean = true;
+    // ... and so are the scan workgroups' row counters, which the set-up's own leave-one-out launch adds up (on the
+    // context's stream this fill raced with a set-up on a side stream: `rows_scored` of a selection with a set of
+    // more than 32 came out 4.4 M too high whenever the pool's block still held another selection's counters)
+    SEL_HIP(hipMemsetAsync(d.wg_rows, 0, size_t(s->scan_grid) * 8, s->setup_side ? s->setup_side : ctx->stream));
     // SEEDED start (persist.hip): an nmost selection whose state fits the persistent kernel's register
     // cache is begun by that kernel itself -- S, the entropy sum, the leave-one-out pass and the first
     // lowest member from nothing but the seed positions -- instead of four launches in front of it
