@@ -154,7 +154,9 @@ struct PSync {
 #ifdef DVS_PERSIST_STAMPS
     // four traced windows (epochs 12, 24, 36, 48): 100 MHz ticks per workgroup at the window's top, at its arrival record,
     // when it saw the release; [3] = the gathering block's own: gather begun, last record seen, release stored
-    unsigned long long trace[4][4][P_MAXG];
+    // [4..6]: the accept behind the window: this workgroup's job published (or nothing to publish), its totals read, its
+    // rebuild of sl done
+    unsigned long long trace[4][7][P_MAXG];
 #endif
     unsigned long long dbg2[16];   // block 0 (owns a job): phase ticks
     unsigned long long dbg[16];    // mirror block: 100 MHz ticks per phase (scan, bar1, resolve, loo, bar2, finalize)
@@ -2623,6 +2625,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             }
         }
         st.cursor = p + 1;
+        P_TRACE(4);
         P_STAMP(3);
         // ================= finalize (every workgroup): totals -> delta_jsd -> argmin (strict '<'
         // from 1e6, first index), all from the accumulators
@@ -2780,6 +2783,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // for the next one now, ahead of its stores.  Then S_new_i = clamp(S_i - low_i) + f_i and the new
         // member's row go to global memory (sl is still the old vector: the rebuild below rewrites it) -- what
         // resolve_kernel would have left behind, also for the kernels that take over an argmin too close to call.
+        P_TRACE(5);
         announce_early(epoch + 1);
         if (lead)
             for (uint32_t i = tid; i < n; i += P_THREADS) d.ord[i] = s_slot[i];
@@ -2891,6 +2895,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         }
         __syncthreads();
         P_STAMP(5);
+        P_TRACE(6);
         P_STAMP_B0(12);  // (behind the rebuild: the cache's decision)
         if (st.cursor >= st.npos) { exit_status = SEL_DONE; break; }
         st.window = p_next_window(st, nwg, wg_thresh, wg_scale, wgmode);

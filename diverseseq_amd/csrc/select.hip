@@ -1166,13 +1166,14 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
                             dbg[6 + 16 * w] / 100.0, dbg[7 + 16 * w] / 100.0, dbg[8 + 16 * w] / 100.0,
                             dbg[5 + 16 * w] / 100.0);
                 if (dvs_persist_trace_offset()) {  // four windows' timelines across the grid
-                    std::vector<unsigned long long> tr(4 * 4 * 256);
+                    std::vector<unsigned long long> tr(4 * 7 * 256);
                     if (hipMemcpy(tr.data(), static_cast<char *>(blk) + dvs_persist_trace_offset(), tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
                         const uint32_t G = which ? s->persist_grid : uint32_t(ctx->head_cus);
                         for (int w_ = 0; w_ < 4; w_++) {
-                            const unsigned long long *t0 = &tr[(w_ * 4 + 0) * 256], *t1 = &tr[(w_ * 4 + 1) * 256], *t2 = &tr[(w_ * 4 + 2) * 256], *tg = &tr[(w_ * 4 + 3) * 256];
+                            const unsigned long long *t0 = &tr[(w_ * 7 + 0) * 256], *t1 = &tr[(w_ * 7 + 1) * 256], *t2 = &tr[(w_ * 7 + 2) * 256], *tg = &tr[(w_ * 7 + 3) * 256];
+                            const unsigned long long *t4 = &tr[(w_ * 7 + 4) * 256], *t5 = &tr[(w_ * 7 + 5) * 256], *t6 = &tr[(w_ * 7 + 6) * 256];
                             if (!tg[2] || G < 4) continue;
-                            std::vector<double> top, arr, seen;
+                            std::vector<double> top, arr, seen, pub, tot, end_;
                             unsigned long long first_top = ~0ull;
                             for (uint32_t b = 0; b + 2 < G; b++) if (t0[b]) first_top = std::min(first_top, t0[b]);
                             for (uint32_t b = 0; b + 2 < G; b++) {
@@ -1180,6 +1181,11 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
                                 top.push_back((t0[b] - first_top) / 100.0);
                                 arr.push_back((t1[b] - first_top) / 100.0);
                                 seen.push_back((double(t2[b]) - double(tg[2])) / 100.0);
+                                if (t4[b] > tg[2] && t5[b] > tg[2] && t6[b] > tg[2]) {  // (the window ended in an accept)
+                                    pub.push_back((double(t4[b]) - double(tg[2])) / 100.0);
+                                    tot.push_back((double(t5[b]) - double(tg[2])) / 100.0);
+                                    end_.push_back((double(t6[b]) - double(tg[2])) / 100.0);
+                                }
                             }
                             if (arr.empty()) continue;
                             auto srt = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); };
@@ -1190,6 +1196,12 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
                                     w_ * 12 + 12, q_(top, 0.5), top.back(), arr.front(), q_(arr, 0.5), q_(arr, 0.9), arr.back(),
                                     (double(tg[0]) - double(first_top)) / 100.0, (double(tg[1]) - double(first_top)) / 100.0, (double(tg[2]) - double(first_top)) / 100.0,
                                     seen.front(), q_(seen, 0.5), seen.back());
+                            if (!pub.empty()) {
+                                srt(pub); srt(tot); srt(end_);
+                                fprintf(stderr, "[dvs persist trace] window %d, its accept (us after the release was stored; min/median/max): job published %.2f / %.2f / %.2f, "
+                                        "totals read %.2f / %.2f / %.2f, rebuild done %.2f / %.2f / %.2f\n", w_ * 12 + 12, pub.front(), q_(pub, 0.5), pub.back(),
+                                        tot.front(), q_(tot, 0.5), tot.back(), end_.front(), q_(end_, 0.5), end_.back());
+                            }
                         }
                     }
                 }
