@@ -1,4 +1,4 @@
-// Persistent form of the greedy selection (MODE_NMOST, identity order, unique ids).
+// Persistent form of the greedy selection (MODE_NMOST and MODE_MAX, identity order, unique ids).
 //
 // The multi-launch engine in select.hip pays, for every greedy event, a scan launch
 // plus resolve / leave-one-out / finalize launches and their serial latencies.  Here
@@ -9,20 +9,22 @@
 //     and the vector sl_i = S_i - lowest_i in LDS (32 KB at k=6) -- what a
 //     candidate's frequencies are added to (src/records.rs:78-81);
 //   * SCAN: waves score the rows of the current window exactly as scan_kernel does
-//     (x = (sl + c/T)/n, fast tier + f64 recheck), atomicMin'ing the first event into
-//     an epoch-tagged word;
-//   * grid barrier; then EVERY workgroup resolves the first event redundantly and
+//     (x = (sl + c/T)/n: all-f32 tier, f32-log tier, f64 recheck); a workgroup's first
+//     event goes into its arrival record, and as a hint into a word the others poll;
+//   * the window's rendezvous (the gathering block takes the minimum of the records and
+//     releases the window); then EVERY workgroup resolves the first event redundantly and
 //     deterministically (same code, same reduction tree -> same bits, so no
 //     broadcast is needed): exact delta_jsd of the candidate, decision,
 //     replace_lowest, new total_jsd;
 //   * leave-one-out as (n + 1) * K jobs over the workgroups (get_lowest_record_index,
-//     src/records.rs:220-252); grid barrier; every workgroup reads the job partials,
-//     takes the argmin, rebuilds sl in its LDS and scans on from the event + 1.
-//   * the LAST workgroup additionally mirrors the state into the global SelDev / SelCtl
-//     arrays (what the host reads back, and what the multi-launch kernels resume
-//     from) and takes no share of the scan.
+//     src/records.rs:220-252), their sums added to accumulators that every workgroup polls
+//     for completeness; every workgroup takes the argmin, rebuilds sl in its LDS and scans on
+//     from the event + 1.
+//   * the last two workgroups scan nothing: one GATHERS the arrival records, the other
+//     MIRRORS the state into the global SelDev / SelCtl arrays (what the host reads back,
+//     and what the multi-launch kernels resume from).
 //
-// Two grid barriers per accepted event and none of the launch latencies.  Any decision
+// Two grid-wide exchanges per accepted event and none of the launch latencies.  Any decision
 // inside the rounding band stops the kernel with SEL_ARBITER; the host arbitrates and
 // runs that one event through the multi-launch kernels, then relaunches this one.
 //
@@ -845,7 +847,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     uint64_t *s_pos = reinterpret_cast<uint64_t *>(s_ds + maxn);  // matrix row of each member
     uint32_t *s_slot = reinterpret_cast<uint32_t *>(s_pos + maxn);
     // the window's words: [0] this workgroup's first event (its arrival record), [1] candidates it listed,
-    // [2] scratch minimum of the listed candidates' walk, [8..15] / [16..23] the gathering waves' minima and flags
+    // [2] scratch minimum of the listed candidates' walk, [4..6] what the polling thread saw (release word, hint
+    // word, released?)
     unsigned long long *s_win = reinterpret_cast<unsigned long long *>(s_slot + maxn + (maxn & 1));
     int *s_flag = reinterpret_cast<int *>(s_win + P_WINWORDS);
     static_assert(maxn % 4 == 0 && P_WINWORDS % 2 == 0, "s_ltab below must sit on a 16-byte boundary");
@@ -868,8 +871,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     const int tid0 = threadIdx.x;
     const int tid = tid0;
     [[maybe_unused]] const uint32_t lane = tid & 63, wave = tid >> 6;
-    // the LAST block mirrors the state into global memory: with n < G it owns no member in
-    // the leave-one-out pass, so its extra stores overlap the other blocks' arithmetic
+    // (one block mirrors the state into global memory: it owns no member in the leave-one-out pass and scans
+    // nothing, so its stores overlap the other blocks' work)
     // Two workgroups scan nothing (grids of three and more): the last one GATHERS the arrival records of every
     // window and stores its release word -- it stores nothing else, so no store of its own ever sits in front of
     // its polling loads --, the one before it MIRRORS the state into global memory (`lead`).  The mirror
