@@ -35,7 +35,7 @@ EXPORTS = (
     "dvs_select_destroy", "dvs_select_get_summary", "dvs_select_get_members",
     "dvs_select_gather_members",
     "dvs_select_delta_jsd", "dvs_select_step_pack",
-    "dvs_select_step_apply", "dvs_select_step_poll", "dvs_select_bench_scan", "dvs_selftest_fast_log2", "dvs_selftest_log2_acc", "dvs_selftest_log2_f32", "dvs_selftest_exact_div", "dvs_mash_sketch", "dvs_mash_distances", "dvs_euclidean_distances", "dvs_sketches_build", "dvs_sketches_destroy", "dvs_sketches_get", "dvs_sketches_dev", "dvs_sketches_dev_lens", "dvs_sketches_distances",
+    "dvs_select_step_apply", "dvs_select_step_poll", "dvs_select_bench_scan", "dvs_selftest_fast_log2", "dvs_selftest_log2_acc", "dvs_selftest_log2_f32", "dvs_selftest_exact_div", "dvs_selftest_handover", "dvs_mash_sketch", "dvs_mash_distances", "dvs_euclidean_distances", "dvs_sketches_build", "dvs_sketches_destroy", "dvs_sketches_get", "dvs_sketches_dev", "dvs_sketches_dev_lens", "dvs_sketches_distances",
     "dvs_default_alphabet_lut", "dvs_seqbatch_from_fasta", "dvs_seqbatch_destroy", "dvs_seqbatch_info",
     "dvs_seqbatch_offsets", "dvs_seqbatch_header_positions", "dvs_seqbatch_dev_codes", "dvs_seqbatch_get_codes",
     "dvs_matrix_build_from_seqbatch",
@@ -160,6 +160,7 @@ def load() -> C.CDLL:
         L.dvs_selftest_log2_acc.argtypes = [vp, f64p]
         L.dvs_selftest_log2_f32.argtypes = [vp, f64p]
         L.dvs_selftest_exact_div.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.dvs_selftest_handover.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)]
         L.dvs_mash_sketch.argtypes = [vp, vp, C.c_int, u64p, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.c_uint32, C.c_int, u32p, u32p]
         L.dvs_mash_distances.argtypes = [vp, u32p, C.c_uint32, u32p, C.c_uint32, C.c_uint32,

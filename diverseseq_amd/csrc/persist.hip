@@ -151,8 +151,12 @@ struct PSync {
     uint32_t wmax;        // longest window of this engine (the control block's cap is the multi-launch scan's)
     uint32_t pad2[53];
     PRel rel[8];                            // one copy per group g = blockIdx % 8
-    unsigned long long wrec[P_MAXG];        // arrival record of every workgroup (a window word)
-    unsigned long long soft[P_MAXG][P_LIST];  // the candidates a workgroup listed in the current window (window words)
+    // Two sets of arrival records and listed candidates, taking turns by the window's parity: a workgroup that is
+    // still walking window e's listed candidates reads the others' records and entries of window e, while a quick
+    // one may already have scanned window e + 1 and stored its record for it.  Window e + 2's words (the same set as
+    // e's) cannot be written before every workgroup has stored its record for e + 1, i.e. has left window e.
+    unsigned long long wrec[2][P_MAXG];          // arrival record of every workgroup (a window word)
+    unsigned long long soft[2][P_MAXG][P_LIST];  // the candidates a workgroup listed in the window (window words)
 #ifdef DVS_PERSIST_STAMPS
     // four traced windows (epochs 12, 24, 36, 48): 100 MHz ticks per workgroup at the window's top, at its arrival record,
     // when it saw the release; [3] = the gathering block's own: gather begun, last record seen, release stored
@@ -257,7 +261,7 @@ struct PWin {
     PRel *rel;                    // the eight group copies (hints are posted to all of them)
     unsigned long long *wgev;     // LDS: this workgroup's first event so far (becomes its arrival record)
     uint32_t *nlist;              // LDS: candidates this workgroup has listed in this window
-    unsigned long long *mysoft;   // this workgroup's list entries (sync->soft[blockIdx.x])
+    unsigned long long *mysoft;   // this workgroup's list entries (sync->soft[epoch & 1][blockIdx.x])
 };
 // the first event posted so far in this window, as far as this group's hint word knows
 __device__ __forceinline__ uint64_t p_hint_pos(const PWin &w) {
@@ -303,6 +307,62 @@ __device__ __forceinline__ unsigned long long p_wave_min_u64(unsigned long long 
         return ((unsigned long long)uint32_t(__builtin_amdgcn_readlane(hi, l)) << 32) | uint32_t(__builtin_amdgcn_readlane(lo, l));
     };
     return mn(mn(row(0), row(16)), mn(row(32), row(48)));
+}
+
+// The gathering block's part of a window's rendezvous, by ONE wave: lane l waits for the arrival records of
+// workgroups l, l + 64, l + 128, l + 192 (four loads in flight per look; records of other windows are not looked
+// at twice), the minimum is taken by DPP, lanes 0..7 store the release word -- no LDS, no barrier between the last
+// record's arrival and the release.  `own`: the gathering block's own record.  Returns the release word; ok = false
+// on a time-out (the launch is then given up: sync->timeout).  seen_all / stored: 100 MHz ticks (stamps builds).
+__device__ __forceinline__ unsigned long long p_gather(PSync *sync, uint32_t G, uint32_t epoch, unsigned long long own,
+                                                       uint32_t lane, bool &ok, unsigned long long *seen_all = nullptr,
+                                                       unsigned long long *stored = nullptr) {
+    constexpr uint32_t Q = P_MAXG / 64;
+    unsigned long long w[Q];
+    bool have[Q];
+#pragma unroll
+    for (uint32_t q = 0; q < Q; q++) {
+        w[q] = ~0ull;
+        have[q] = lane + 64 * q >= G - 1;  // (this workgroup's own record is `own`)
+    }
+    uint32_t spins = 0;
+    ok = true;
+    for (;;) {
+        unsigned long long got[Q];
+#pragma unroll
+        for (uint32_t q = 0; q < Q; q++)
+            got[q] = have[q] ? 0ull : __hip_atomic_load(&sync->wrec[epoch & 1u][lane + 64 * q], RLX_AGENT);
+        bool all = true;
+#pragma unroll
+        for (uint32_t q = 0; q < Q; q++) {
+            if (!have[q] && p_word_is(got[q], epoch)) {
+                w[q] = got[q];
+                have[q] = true;
+            }
+            all = all && have[q];
+        }
+        if (__ballot(!all) == 0ull) break;
+        if ((++spins & 255u) == 0 && (spins > P_SPIN_LIMIT || __hip_atomic_load(&sync->timeout, RLX_AGENT))) {
+            ok = false;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (seen_all) *seen_all = __builtin_amdgcn_s_memrealtime();
+    unsigned long long m = own & ~6ull, fl = own & 6ull;
+#pragma unroll
+    for (uint32_t q = 0; q < Q; q++)
+        if (lane + 64 * q < G - 1 && have[q]) {
+            m = (w[q] & ~6ull) < m ? (w[q] & ~6ull) : m;
+            fl |= w[q] & 6ull;
+        }
+    m = p_wave_min_u64(m);
+    const bool anyl = __ballot(fl != 0ull) != 0ull;
+    const unsigned long long relw = m | (anyl ? 2ull : 0ull);
+    if (ok && lane < 8) __hip_atomic_store(&sync->rel[lane].rel, relw, RLX_AGENT);
+    if (!ok && lane == 0) __hip_atomic_store(&sync->timeout, 1u, RLX_AGENT);
+    if (stored) *stored = __builtin_amdgcn_s_memrealtime();
+    return relw;
 }
 
 // One wave's share of the window, as scan_rows_hot but against the unscaled vector sl:
@@ -959,7 +1019,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     auto announce_early = [&](uint32_t next_epoch) {
         if (lead && two_roles && !MAXM) {
             if (threadIdx.x == 0)
-                __hip_atomic_store(&sync->wrec[blockIdx.x], p_word(next_epoch, SEL_NONE, false), RLX_AGENT);
+                __hip_atomic_store(&sync->wrec[next_epoch & 1u][blockIdx.x], p_word(next_epoch, SEL_NONE, false), RLX_AGENT);
             early_rec = next_epoch;
         }
     };
@@ -1288,7 +1348,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         win.rel = sync->rel;
         win.wgev = s_win;
         win.nlist = reinterpret_cast<uint32_t *>(s_win + 1);
-        win.mysoft = &sync->soft[blockIdx.x][0];
+        win.mysoft = &sync->soft[epoch & 1u][blockIdx.x][0];
         if (tid == 0) {  // (the previous window's words were last read before the barrier that ended its walk)
             s_win[0] = p_word(epoch, SEL_NONE, false);
             *win.nlist = 0u;
@@ -1527,61 +1587,23 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         {
             const uint32_t nl = *win.nlist;
             const unsigned long long own = s_win[0] | ((unsigned long long)(nl < P_LIST ? nl : P_LIST) << 1);
-            if (tid == 0 && early_rec != epoch) __hip_atomic_store(&sync->wrec[blockIdx.x], own, RLX_AGENT);
+            if (tid == 0 && early_rec != epoch) __hip_atomic_store(&sync->wrec[epoch & 1u][blockIdx.x], own, RLX_AGENT);
             P_STAMP_B0(11);  // (the workgroup's barrier, the record stored)
             P_TRACE(1);
             if (gath) {
-                // ONE wave gathers: lane l waits for the records of workgroups l, l + 64, l + 128, l + 192 (four loads in
-                // flight per look), the minimum is taken by DPP, lanes 0..7 store the release word -- no LDS, no
-                // barrier between the last record's arrival and the release
                 P_TRACE_G(0);
-                if (wave == 0) {
-                    constexpr uint32_t Q = P_MAXG / 64;
-                    unsigned long long w[Q];
-                    bool have[Q];
-#pragma unroll
-                    for (uint32_t q = 0; q < Q; q++) {
-                        w[q] = ~0ull;
-                        have[q] = lane + 64 * q >= G - 1;  // (this workgroup's own record is `own`)
+                if (wave == 0) {  // (p_gather: one wave, no LDS, no barrier between the last record and the release)
+                    bool ok;
+#ifdef DVS_PERSIST_STAMPS
+                    unsigned long long t_seen = 0, t_stored = 0;
+                    const unsigned long long relw = p_gather(sync, G, epoch, own, lane, ok, &t_seen, &t_stored);
+                    if (tid == 0 && (epoch == 12 || epoch == 24 || epoch == 36 || epoch == 48)) {
+                        sync->trace[epoch / 12 - 1][3][1] = t_seen;
+                        sync->trace[epoch / 12 - 1][3][2] = t_stored;
                     }
-                    uint32_t spins = 0;
-                    bool ok = true;
-                    for (;;) {
-                        unsigned long long got[Q];
-#pragma unroll
-                        for (uint32_t q = 0; q < Q; q++)
-                            got[q] = have[q] ? 0ull : __hip_atomic_load(&sync->wrec[lane + 64 * q], RLX_AGENT);
-                        bool all = true;
-#pragma unroll
-                        for (uint32_t q = 0; q < Q; q++) {
-                            if (!have[q] && p_word_is(got[q], epoch)) {
-                                w[q] = got[q];
-                                have[q] = true;
-                            }
-                            all = all && have[q];
-                        }
-                        if (__ballot(!all) == 0ull) break;
-                        if ((++spins & 255u) == 0 &&
-                            (spins > P_SPIN_LIMIT || __hip_atomic_load(&sync->timeout, RLX_AGENT))) {
-                            ok = false;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    P_TRACE_G(1);
-                    unsigned long long m = own & ~6ull, fl = own & 6ull;
-#pragma unroll
-                    for (uint32_t q = 0; q < Q; q++)
-                        if (lane + 64 * q < G - 1 && have[q]) {
-                            m = (w[q] & ~6ull) < m ? (w[q] & ~6ull) : m;
-                            fl |= w[q] & 6ull;
-                        }
-                    m = p_wave_min_u64(m);
-                    const bool anyl = __ballot(fl != 0ull) != 0ull;
-                    const unsigned long long relw = m | (anyl ? 2ull : 0ull);
-                    if (ok && lane < 8) __hip_atomic_store(&sync->rel[lane].rel, relw, RLX_AGENT);
-                    if (!ok && lane == 0) __hip_atomic_store(&sync->timeout, 1u, RLX_AGENT);
-                    P_TRACE_G(2);
+#else
+                    const unsigned long long relw = p_gather(sync, G, epoch, own, lane, ok);
+#endif
                     if (lane == 0) {
                         s_win[4] = relw;
                         s_flag[0] = ok ? 1 : 0;
@@ -1758,11 +1780,11 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     }
                     return w;
                 };
-                const unsigned long long rec = tagged(&sync->wrec[tid]);
+                const unsigned long long rec = tagged(&sync->wrec[epoch & 1u][tid]);
                 const uint32_t c = list_ok ? p_word_listed(rec) : 0u;
 #pragma unroll
                 for (uint32_t i = 0; i < P_LIST; i++)
-                    if (i < c) le[i] = p_word_pos(tagged(&sync->soft[tid][i]), epoch);
+                    if (i < c) le[i] = p_word_pos(tagged(&sync->soft[epoch & 1u][tid][i]), epoch);
             }
             list_ok = __syncthreads_or(list_ok ? 0 : 1) == 0;
             uint64_t floor = st.cursor;
@@ -2939,6 +2961,165 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     }
 }
 
+// ---- Self-test of the hand-over words on their own (dvs_selftest_handover): `rounds` synthetic
+// windows through the very functions the engine uses -- arrival records, hints, listed candidates, p_gather, the
+// release word, and a use of the never-cleared accumulators per round -- with every workgroup's contribution a hash
+// of (round, workgroup) that every workgroup can recompute, and a pseudo-random pause in front of every step.  A
+// workgroup counts a failure whenever what it reads differs from what the hashes say it must read.
+__device__ __forceinline__ uint32_t ho_hash(uint32_t round, uint32_t b) {
+    uint32_t h = round * 0x9E3779B1u ^ (b + 1u) * 0x85EBCA77u;
+    h ^= h >> 15;
+    h *= 0xC2B2AE3Du;
+    h ^= h >> 13;
+    return h;
+}
+// the event workgroup b finds in round `round` (SEL_NONE: none), whether it is a sure one, and a candidate it lists
+__device__ __forceinline__ uint64_t ho_event(uint32_t round, uint32_t b, bool &sure, bool &lists) {
+    const uint32_t h = ho_hash(round, b);
+    sure = (h >> 2) & 1u;
+    lists = ((h >> 3) & 15u) == 0u;
+    return (h & 3u) == 0u ? uint64_t(round) * 4096u + ((h >> 8) % 4000u) : SEL_NONE;
+}
+constexpr uint32_t HO_MEMBERS = 24, HO_K = 8;  // accumulator words in use: 24 "members" x 8 contributions each
+
+__global__ __launch_bounds__(P_THREADS) void handover_selftest_kernel(PSync *sync, unsigned long long *acc_all, uint32_t G,
+                                                                      uint32_t rounds, unsigned long long *bad) {
+    __shared__ unsigned long long s_win[8];
+    __shared__ unsigned long long s_prev[(HO_MEMBERS + 1) * 2];
+    __shared__ int s_flag[2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = blockIdx.x;
+    const bool gath = b == G - 1;
+    const uint32_t n_work = G - 1;
+    for (uint32_t i = tid; i < (HO_MEMBERS + 1) * 2; i += P_THREADS) s_prev[i] = 0ull;
+    unsigned long long fails = 0;
+    PRel *myrel = &sync->rel[b & 7u];
+    const unsigned long long *acc = acc_all + uint64_t(b & 7u) * (HO_MEMBERS + 1) * 2;
+    for (uint32_t epoch = 0; epoch < rounds; epoch++) {
+        PWin win;
+        win.epoch = epoch;
+        win.hintp = &myrel->hint;
+        win.rel = sync->rel;
+        win.wgev = s_win;
+        win.nlist = reinterpret_cast<uint32_t *>(s_win + 1);
+        win.mysoft = &sync->soft[epoch & 1u][b][0];
+        if (tid == 0) {
+            s_win[0] = p_word(epoch, SEL_NONE, false);
+            *win.nlist = 0u;
+        }
+        __syncthreads();
+        const uint32_t h = ho_hash(epoch, b);
+        for (uint32_t z = (h >> 24) & 15u; z > 0; z--) __builtin_amdgcn_s_sleep(3);  // (workgroups arrive out of step)
+        bool sure, lists;
+        const uint64_t mine = gath ? SEL_NONE : ho_event(epoch, b, sure, lists);
+        if (!gath && tid == 0) {
+            if (mine != SEL_NONE) p_post_event_thread(win, mine, sure);
+            if (lists) p_list_candidate(win, uint64_t(epoch) * 4096u + 4001u + b);
+        }
+        __syncthreads();
+        const uint32_t nl = *win.nlist;
+        const unsigned long long own = s_win[0] | ((unsigned long long)(nl < P_LIST ? nl : P_LIST) << 1);
+        if (tid == 0) __hip_atomic_store(&sync->wrec[epoch & 1u][b], own, RLX_AGENT);
+        unsigned long long rel_w = 0ull;
+        bool ok = true;
+        if (gath) {
+            if (wave == 0) {
+                const unsigned long long relw = p_gather(sync, G, epoch, own, lane, ok);
+                if (lane == 0) {
+                    s_win[4] = relw;
+                    s_flag[0] = ok ? 1 : 0;
+                }
+            }
+        } else if (tid == 0) {
+            uint32_t spins = 0;
+            unsigned long long r_ = 0ull;
+            int okk = 1;
+            for (;;) {
+                const uint4 v = p_load16_agent(myrel);
+                r_ = ((unsigned long long)v.y << 32) | v.x;
+                if (p_word_is(r_, epoch)) break;
+                // a hint of this window never names a position in front of the window's first event
+                if ((++spins & 255u) == 0 && (spins > P_SPIN_LIMIT || __hip_atomic_load(&sync->timeout, RLX_AGENT))) {
+                    __hip_atomic_store(&sync->timeout, 1u, RLX_AGENT);
+                    okk = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            s_win[4] = r_;
+            s_flag[0] = okk;
+        }
+        __syncthreads();
+        rel_w = s_win[4];
+        ok = s_flag[0] != 0;
+        if (!ok) break;  // (every workgroup sees the time-out flag sooner or later)
+        // (now and then a workgroup is late to look -- as one that was inside its speculative job when the release
+        // came: by then quick workgroups have stored their records of the NEXT window)
+        if (((h >> 12) & 31u) == 0u)
+            for (uint32_t z = 0; z < 24; z++) __builtin_amdgcn_s_sleep(8);
+        // what the release must say: the minimum of the workgroups' events, and whether anybody listed
+        if (wave == 0) {
+            unsigned long long best = p_word(epoch, SEL_NONE, false);
+            bool anyl = false;
+            for (uint32_t q = lane; q < n_work; q += 64) {
+                bool s2, l2;
+                const uint64_t e2 = ho_event(epoch, q, s2, l2);
+                if (e2 != SEL_NONE) {
+                    const unsigned long long w2 = p_word(epoch, e2, s2);
+                    best = w2 < best ? w2 : best;
+                }
+                anyl = anyl || l2;
+            }
+            best = p_wave_min_u64(best);
+            const bool any = __ballot(anyl) != 0ull;
+            const unsigned long long want = best | (any ? 2ull : 0ull);
+            const unsigned long long hint = __hip_atomic_load(&myrel->hint, RLX_AGENT);
+            bool wrong = rel_w != want;
+            // a hint that carries this window's tag names an event some workgroup did find: never one in front of the first
+            if (p_word_is(hint, epoch) && p_word_pos(hint, epoch) != SEL_NONE && p_word_pos(hint, epoch) < p_word_pos(want, epoch)) wrong = true;
+            // the listed candidates of every workgroup that says it listed one
+            if (any) {
+                for (uint32_t q = lane; q < n_work; q += 64) {
+                    bool s2, l2;
+                    (void)ho_event(epoch, q, s2, l2);
+                    unsigned long long rec = __hip_atomic_load(&sync->wrec[epoch & 1u][q], RLX_AGENT);
+                    for (uint32_t spins = 0; !p_word_is(rec, epoch) && spins < (1u << 20); spins++)
+                        rec = __hip_atomic_load(&sync->wrec[epoch & 1u][q], RLX_AGENT);
+                    if (p_word_listed(rec) != (l2 ? 1u : 0u)) wrong = true;
+                    if (l2) {
+                        unsigned long long ent = __hip_atomic_load(&sync->soft[epoch & 1u][q][0], RLX_AGENT);
+                        for (uint32_t spins = 0; !p_word_is(ent, epoch) && spins < (1u << 20); spins++)
+                            ent = __hip_atomic_load(&sync->soft[epoch & 1u][q][0], RLX_AGENT);
+                        if (p_word_pos(ent, epoch) != uint64_t(epoch) * 4096u + 4001u + q) wrong = true;
+                    }
+                }
+            }
+            if (__ballot(wrong) != 0ull && lane == 0) fails++;
+        }
+        // a use of the accumulators: workgroup j < HO_MEMBERS * HO_K adds its value to member j / HO_K (eight replicas,
+        // lane g adds to group g's), everybody reads every member's total as the difference to the previous use
+        for (uint32_t z = (h >> 20) & 7u; z > 0; z--) __builtin_amdgcn_s_sleep(2);
+        if (b < HO_MEMBERS * HO_K && tid < 8) {
+            const double v = double((h >> 4) & 0xFFFFu) * (1.0 / 65536.0), v2 = double(h & 0xFFu) * (1.0 / 4096.0);
+            p_acc_add(acc_all + (uint64_t(tid) * (HO_MEMBERS + 1) + b / HO_K) * 2, v, v2);
+        }
+        bool acc_ok = true, acc_wrong = false;
+        if (tid < HO_MEMBERS) {
+            const unsigned long long d0 = p_acc_complete(acc + uint64_t(tid) * 2, s_prev + tid * 2, HO_K, acc_ok);
+            const unsigned long long d1 = p_acc_complete(acc + uint64_t(tid) * 2 + 1, s_prev + tid * 2 + 1, HO_K, acc_ok);
+            unsigned long long e0 = 0ull, e1 = 0ull;
+            for (uint32_t q = 0; q < HO_K; q++) {
+                const uint32_t h2 = ho_hash(epoch, tid * HO_K + q);
+                e0 += p_acc_word(double((h2 >> 4) & 0xFFFFu) * (1.0 / 65536.0));
+                e1 += p_acc_word(double(h2 & 0xFFu) * (1.0 / 4096.0));
+            }
+            acc_wrong = !acc_ok || d0 != e0 || d1 != e1;
+        }
+        if (__syncthreads_or(acc_wrong ? 1 : 0) && tid == 0) fails++;
+    }
+    if (tid == 0 && fails) atomicAdd(bad, fails);
+    if (tid == 0 && __hip_atomic_load(&sync->timeout, RLX_AGENT)) atomicAdd(bad, 1ull << 32);  // (a time-out: reported apart)
+}
+
 }  // namespace
 
 // the instantiation that serves a selection (dvs_persist_setup decided maxm / cached / small)
@@ -3131,5 +3312,43 @@ int dvs_persist_prepare_head(dvs_ctx *ctx, dvs_select *s, uint32_t stop_at, hipS
 int dvs_persist_prepare_main(dvs_ctx *ctx, dvs_select *s) {
     int rc = persist_prepare(ctx, s, 0u, ctx->stream);
     if (!rc) s->persist_prepared = true;
+    return rc;
+}
+
+// Self-test of the hand-over words (see handover_selftest_kernel): *failures = workgroup-rounds in which a word read
+// was not the word the hashes demand (+ 2^32 if a spin ran into its bound).  One workgroup per CU, all resident.
+extern "C" int dvs_selftest_handover(dvs_ctx *ctx, uint32_t rounds, uint64_t *failures) {
+    if (!ctx || !failures || !rounds) return dvs_set_error(ctx, DVS_ERR_VALUE, "bad argument");
+    if (rounds >= P_EPOCH_MAX) return dvs_set_error(ctx, DVS_ERR_VALUE, "at most %u rounds", P_EPOCH_MAX - 1);
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t G = uint32_t(std::min(ctx->n_cu, int(P_MAXG)));
+    if (G < HO_MEMBERS * HO_K + 1 || ctx->knobs.cu_mask_set)
+        return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "the self-test wants %u co-resident workgroups", HO_MEMBERS * HO_K + 1);
+    void *d_sync = nullptr, *d_acc = nullptr, *d_bad = nullptr;
+    int rc = dvs_dev_alloc(ctx, &d_sync, sizeof(PSync), "self-test sync block");
+    if (!rc) rc = dvs_dev_alloc(ctx, &d_acc, p_acc_bytes(HO_MEMBERS), "self-test accumulators");
+    if (!rc) rc = dvs_dev_alloc(ctx, &d_bad, 8, "self-test counter");
+    if (!rc) {
+        std::vector<unsigned char> image(sizeof(PSync), 0);
+        PSync &init = *reinterpret_cast<PSync *>(image.data());
+        for (int g = 0; g < 8; g++) init.rel[g].hint = ~0ull;
+        hipError_t e = hipMemcpyAsync(d_sync, image.data(), sizeof(PSync), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_acc, 0, p_acc_bytes(HO_MEMBERS), ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 8, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // (the image is a local)
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(handover_selftest_kernel, dim3(G), dim3(P_THREADS), 0, ctx->stream, static_cast<PSync *>(d_sync),
+                               static_cast<unsigned long long *>(d_acc), G, rounds, static_cast<unsigned long long *>(d_bad));
+            e = hipGetLastError();
+        }
+        unsigned long long bad = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = dvs_hip_fail(ctx, e, "hand-over self-test");
+        *failures = bad;
+    }
+    dvs_dev_free(ctx, d_sync);
+    dvs_dev_free(ctx, d_acc);
+    dvs_dev_free(ctx, d_bad);
     return rc;
 }

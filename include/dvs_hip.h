@@ -288,6 +288,12 @@ int dvs_selftest_log2_f32(dvs_ctx *ctx, double *max_ulps);
  * division (select_dev.h exact_div_u32) against the division itself: every count <= total <=
  * 8192 and 2^32 random pairs; reports the number of mismatches (must be 0) */
 int dvs_selftest_exact_div(dvs_ctx *ctx, uint64_t *mismatches);
+/* The persistent engine's hand-over words on their own (csrc/persist.hip): `rounds` synthetic windows
+ * -- arrival records, hints, listed candidates, the gathering block's release, a use of the never-cleared
+ * leave-one-out accumulators -- with contributions every workgroup can recompute and pseudo-random pauses in front of
+ * every step; one workgroup per CU.  *failures = workgroup-rounds in which a word read was not the word it must be
+ * (+ 2^32 when a bounded spin ran out). */
+int dvs_selftest_handover(dvs_ctx *ctx, uint32_t rounds, uint64_t *failures);
 
 /* ---- mash ----------------------------------------------------------------- *
  * dvs_mash_sketch replaces _dvs.mash_sketch (src/distance.rs:136-182) for a

@@ -799,6 +799,18 @@ def test_exact_quotient_by_fma(ctx):
     assert bad.value == 0
 
 
+def test_handover_words_of_the_persistent_engine(ctx):
+    """The persistent engine's cross-workgroup words on their own: 200 000 synthetic windows -- arrival
+    records, hints, listed candidates, the gathering block's release and a use of the never-cleared leave-one-out
+    accumulators each -- with pseudo-random pauses in front of every step and contributions every workgroup can
+    recompute: no workgroup ever reads a word that is not the one it must be, and no spin runs out."""
+    import ctypes as C
+
+    bad = C.c_uint64(1)
+    ctx.check(ctx._L.dvs_selftest_handover(ctx._h, 200_000, C.byref(bad)))
+    assert bad.value == 0, (bad.value >> 32, bad.value & 0xFFFFFFFF)
+
+
 # ------------------------------------------------ genome-scale rows (configs C3 / C5, scaled down)
 def test_genome_length_sequences_max_and_sketch(ctx):
     """C3 / C5 shapes at reduced N: ~3 Mb sequences (92 tiles each), `max` min_size 5 and
