@@ -2989,7 +2989,11 @@ __global__ __launch_bounds__(P_THREADS) void handover_selftest_kernel(PSync *syn
     __shared__ int s_flag[2];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = blockIdx.x;
     const bool gath = b == G - 1;
-    const uint32_t n_work = G - 1;
+    // (the workgroup in front of the gathering block plays the MIRROR block: it finds nothing, announces itself for the
+    // next round as soon as it has read this round's last word, and then stays away for a while -- its stores)
+    const bool mirror = b == G - 2;
+    const uint32_t n_work = G - 2;
+    uint32_t early_rec = 0xFFFFFFFFu;
     for (uint32_t i = tid; i < (HO_MEMBERS + 1) * 2; i += P_THREADS) s_prev[i] = 0ull;
     unsigned long long fails = 0;
     PRel *myrel = &sync->rel[b & 7u];
@@ -3010,15 +3014,16 @@ __global__ __launch_bounds__(P_THREADS) void handover_selftest_kernel(PSync *syn
         const uint32_t h = ho_hash(epoch, b);
         for (uint32_t z = (h >> 24) & 15u; z > 0; z--) __builtin_amdgcn_s_sleep(3);  // (workgroups arrive out of step)
         bool sure, lists;
-        const uint64_t mine = gath ? SEL_NONE : ho_event(epoch, b, sure, lists);
-        if (!gath && tid == 0) {
+        const uint64_t mine = (gath || mirror) ? SEL_NONE : ho_event(epoch, b, sure, lists);
+        if (mirror) lists = false;
+        if (!gath && !mirror && tid == 0) {
             if (mine != SEL_NONE) p_post_event_thread(win, mine, sure);
             if (lists) p_list_candidate(win, uint64_t(epoch) * 4096u + 4001u + b);
         }
         __syncthreads();
         const uint32_t nl = *win.nlist;
         const unsigned long long own = s_win[0] | ((unsigned long long)(nl < P_LIST ? nl : P_LIST) << 1);
-        if (tid == 0) __hip_atomic_store(&sync->wrec[epoch & 1u][b], own, RLX_AGENT);
+        if (tid == 0 && early_rec != epoch) __hip_atomic_store(&sync->wrec[epoch & 1u][b], own, RLX_AGENT);
         unsigned long long rel_w = 0ull;
         bool ok = true;
         if (gath) {
@@ -3115,6 +3120,11 @@ __global__ __launch_bounds__(P_THREADS) void handover_selftest_kernel(PSync *syn
             acc_wrong = !acc_ok || d0 != e0 || d1 != e1;
         }
         if (__syncthreads_or(acc_wrong ? 1 : 0) && tid == 0) fails++;
+        if (mirror && epoch + 1 < rounds) {  // announce_early: the next round's record now, then the "stores"
+            if (tid == 0) __hip_atomic_store(&sync->wrec[(epoch + 1) & 1u][b], p_word(epoch + 1, SEL_NONE, false), RLX_AGENT);
+            early_rec = epoch + 1;
+            for (uint32_t z = (h >> 16) & 15u; z > 0; z--) __builtin_amdgcn_s_sleep(16);
+        }
     }
     if (tid == 0 && fails) atomicAdd(bad, fails);
     if (tid == 0 && __hip_atomic_load(&sync->timeout, RLX_AGENT)) atomicAdd(bad, 1ull << 32);  // (a time-out: reported apart)
@@ -3322,8 +3332,8 @@ extern "C" int dvs_selftest_handover(dvs_ctx *ctx, uint32_t rounds, uint64_t *fa
     if (rounds >= P_EPOCH_MAX) return dvs_set_error(ctx, DVS_ERR_VALUE, "at most %u rounds", P_EPOCH_MAX - 1);
     DVS_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t G = uint32_t(std::min(ctx->n_cu, int(P_MAXG)));
-    if (G < HO_MEMBERS * HO_K + 1 || ctx->knobs.cu_mask_set)
-        return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "the self-test wants %u co-resident workgroups", HO_MEMBERS * HO_K + 1);
+    if (G < HO_MEMBERS * HO_K + 2 || ctx->knobs.cu_mask_set)
+        return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "the self-test wants %u co-resident workgroups", HO_MEMBERS * HO_K + 2);
     void *d_sync = nullptr, *d_acc = nullptr, *d_bad = nullptr;
     int rc = dvs_dev_alloc(ctx, &d_sync, sizeof(PSync), "self-test sync block");
     if (!rc) rc = dvs_dev_alloc(ctx, &d_acc, p_acc_bytes(HO_MEMBERS), "self-test accumulators");
