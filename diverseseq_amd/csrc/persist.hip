@@ -1327,6 +1327,22 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
 #define P_TRACE(which) do { } while (0)
 #define P_TRACE_G(slot) do { } while (0)
 #endif
+// A -DDVS_PERSIST_CHAOS build holds pseudo-randomly chosen workgroups back (up to ~10 us) at the points where they
+// are about to write or read a word another workgroup reads or writes: the answers must not change
+// (scripts/chaos.sh runs the parity suite and the repeat script against such a build).
+#ifdef DVS_PERSIST_CHAOS
+#define P_CHAOS(k)                                                                                         \
+    do {                                                                                                   \
+        uint32_t h_ = (epoch * 0x9E3779B1u) ^ ((blockIdx.x + 1u) * 0x85EBCA77u) ^ (uint32_t(k) * 0xC2B2AE3Du); \
+        h_ ^= h_ >> 15;                                                                                    \
+        h_ *= 0x27D4EB2Fu;                                                                                 \
+        h_ ^= h_ >> 13;                                                                                    \
+        if ((h_ & 15u) == 0u)                                                                              \
+            for (uint32_t z_ = (h_ >> 8) & 31u; z_ > 0; z_--) __builtin_amdgcn_s_sleep(12);               \
+    } while (0)
+#else
+#define P_CHAOS(k) do { } while (0)
+#endif
     for (;;) {
         // The loop body's view of the bin count and the thread index goes through an empty asm:
         // otherwise every loop-invariant mask and address derived from them (dozens) is hoisted in
@@ -1354,6 +1370,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             *win.nlist = 0u;
         }
         __syncthreads();
+        P_CHAOS(1);  // (late into the window)
         P_STAMP_B0(9);  // (the top of the window: its barrier)
         P_TRACE(0);
 #ifdef DVS_PERSIST_STAMPS
@@ -1581,6 +1598,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // nothing, waits for all of them (thread t polls workgroup t's) and stores the release word: the
         // window's first event.  The others poll their group's copy of it together with the hint word beside
         // it (one 16-byte load; each word says itself which window it belongs to).
+        P_CHAOS(2);  // (late with its arrival record)
         __syncthreads();  // (every wave's events and listings are in s_win)
         unsigned long long rel_w = 0ull;
         bool bar_ok = true;
@@ -1679,6 +1697,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             }
         }
         if (!bar_ok) { exit_status = SEL_ERROR; break; }
+        P_CHAOS(3);  // (late to act on the release: the lists are walked, the job published, later than the others')
         P_TRACE(2);
         P_STAMP(1);
 #ifdef DVS_PERSIST_STAMPS
@@ -2652,6 +2671,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         st.cursor = p + 1;
         P_TRACE(4);
         P_STAMP(3);
+        P_CHAOS(4);  // (late to read the totals)
         // ================= finalize (every workgroup): totals -> delta_jsd -> argmin (strict '<'
         // from 1e6, first index), all from the accumulators
         uint32_t lowest;
@@ -2808,6 +2828,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // for the next one now, ahead of its stores.  Then S_new_i = clamp(S_i - low_i) + f_i and the new
         // member's row go to global memory (sl is still the old vector: the rebuild below rewrites it) -- what
         // resolve_kernel would have left behind, also for the kernels that take over an argmin too close to call.
+        P_CHAOS(5);  // (the mirror block: late with its early announcement; everybody: late into the rebuild)
         P_TRACE(5);
         announce_early(epoch + 1);
         if (lead)
