@@ -1012,6 +1012,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     uint32_t pend_kind = 0;  // ev_kind left pending for the multi-launch kernels (finalize tie)
     bool bail = false;       // leave with the state as it stands and status RUN (MAXM: an undecidable push)
     [[maybe_unused]] uint32_t mx_batch = 1;  // MAXM: rows the next tentative push takes along (identical in every workgroup)
+    [[maybe_unused]] uint32_t n_batches = 0;  // MAXM: batches of this launch so far (their results alternate between two areas)
     // the mirror block (two_roles): the window whose arrival record it has already stored -- at the end of the
     // window before, the moment it had read the last word another workgroup wrote for that window (the release,
     // the listed candidates, the leave-one-out totals), ahead of its own stores
@@ -1953,7 +1954,11 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 if (E >= 2) {
                 for (;;) {  // batch after batch while the rows keep being events
                     constexpr uint32_t JW = P_BATCH_MEMBERS + 2;  // result rows per batch entry
-                    double *bres = reinterpret_cast<double *>(part + p_acc_bytes(maxn) / 8);
+                    // (the results of a batch are read behind its rendezvous -- and a workgroup that is slow to read them must
+                    // not meet the NEXT batch's: two result areas taking turns; the one two batches on is written behind the
+                    // next batch's rendezvous, which every workgroup reaches only after it has read this batch's)
+                    double *bres = reinterpret_cast<double *>(part + p_acc_bytes(maxn) / 8) + uint64_t(n_batches & 1u) * (p_batch_bytes() / 8);
+                    n_batches++;
                     const uint32_t jpe = n + 3;  // leave-one-out of n + 1 members, the whole bigger set, the score
                     __syncthreads();  // every thread has read the member arrays of the resolve phase
                     if (tid < E) {
@@ -3300,7 +3305,7 @@ int dvs_persist_setup(dvs_ctx *ctx, dvs_select *s) {
         if (!hit->second) return DVS_OK;
     }
     rc = dvs_dev_alloc(ctx, &s->psync, sizeof(PSync), "persistent sync block");
-    if (!rc) rc = dvs_dev_alloc(ctx, &s->ppart, p_acc_bytes(s->persist_maxn) + (maxm ? p_batch_bytes() : 0),
+    if (!rc) rc = dvs_dev_alloc(ctx, &s->ppart, p_acc_bytes(s->persist_maxn) + (maxm ? 2 * p_batch_bytes() : 0),
                                 "leave-one-out accumulators");  // (MODE_MAX: + the results of a batch's jobs)
     if (rc) return rc;
     s->persist = true;
