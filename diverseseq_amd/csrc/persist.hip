@@ -1328,8 +1328,9 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
 #define P_TRACE(which) do { } while (0)
 #define P_TRACE_G(slot) do { } while (0)
 #endif
-// A -DDVS_PERSIST_CHAOS build holds pseudo-randomly chosen workgroups back (up to ~10 us) at the points where they
-// are about to write or read a word another workgroup reads or writes: the answers must not change
+// A -DDVS_PERSIST_CHAOS build holds pseudo-randomly chosen workgroups back (one in sixteen up to ~10 us, one in four
+// thousand for ~60 us) at the points where they are about to write or read a word another workgroup reads or
+// writes: the answers must not change
 // (scripts/chaos.sh runs the parity suite and the repeat script against such a build).
 #ifdef DVS_PERSIST_CHAOS
 #define P_CHAOS(k)                                                                                         \
@@ -1340,6 +1341,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         h_ ^= h_ >> 13;                                                                                    \
         if ((h_ & 15u) == 0u)                                                                              \
             for (uint32_t z_ = (h_ >> 8) & 31u; z_ > 0; z_--) __builtin_amdgcn_s_sleep(12);               \
+        if ((h_ & 0xFFF0u) == 0x1230u) /* now and then for the length of several windows (~60 us) */      \
+            for (uint32_t z_ = 0; z_ < 160; z_++) __builtin_amdgcn_s_sleep(14);                            \
     } while (0)
 #else
 #define P_CHAOS(k) do { } while (0)
