@@ -162,7 +162,7 @@ struct PSync {
     // when it saw the release; [3] = the gathering block's own: gather begun, last record seen, release stored
     // [4..6]: the accept behind the window: this workgroup's job published (or nothing to publish), its totals read, its
     // rebuild of sl done
-    unsigned long long trace[4][7][P_MAXG];
+    unsigned long long trace[4][8][P_MAXG];  // ([7]: the speculative job's sums handed to the accumulators, or that point passed)
 #endif
     unsigned long long dbg2[16];   // block 0 (owns a job): phase ticks
     unsigned long long dbg[16];    // mirror block: 100 MHz ticks per phase (scan, bar1, resolve, loo, bar2, finalize)
@@ -2483,6 +2483,15 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 job_published = true;
             }
         }
+        P_TRACE(7);
+#ifdef DVS_PERSIST_STAMPS
+        if constexpr (SPEC || SPEC_BIG) {  // (block 0: how often its job was ready when the release came)
+            if (blockIdx.x == 0 && tid == 0) {
+                s_dbg[15] += job_published ? 1u : 0u;
+                s_dbg[14] += (fr_pos == p) ? 1u : 0u;
+            }
+        }
+#endif
         const uint32_t n = st.n, li = st.li;
         const uint32_t slot_low = s_slot[li];
         const uint32_t old_lab = lead ? d.mLabel[slot_low] : 0;

@@ -1166,12 +1166,12 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
                             dbg[6 + 16 * w] / 100.0, dbg[7 + 16 * w] / 100.0, dbg[8 + 16 * w] / 100.0,
                             dbg[5 + 16 * w] / 100.0);
                 if (dvs_persist_trace_offset()) {  // four windows' timelines across the grid
-                    std::vector<unsigned long long> tr(4 * 7 * 256);
+                    std::vector<unsigned long long> tr(4 * 8 * 256);
                     if (hipMemcpy(tr.data(), static_cast<char *>(blk) + dvs_persist_trace_offset(), tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
                         const uint32_t G = which ? s->persist_grid : uint32_t(ctx->head_cus);
                         for (int w_ = 0; w_ < 4; w_++) {
-                            const unsigned long long *t0 = &tr[(w_ * 7 + 0) * 256], *t1 = &tr[(w_ * 7 + 1) * 256], *t2 = &tr[(w_ * 7 + 2) * 256], *tg = &tr[(w_ * 7 + 3) * 256];
-                            const unsigned long long *t4 = &tr[(w_ * 7 + 4) * 256], *t5 = &tr[(w_ * 7 + 5) * 256], *t6 = &tr[(w_ * 7 + 6) * 256];
+                            const unsigned long long *t0 = &tr[(w_ * 8 + 0) * 256], *t1 = &tr[(w_ * 8 + 1) * 256], *t2 = &tr[(w_ * 8 + 2) * 256], *tg = &tr[(w_ * 8 + 3) * 256];
+                            const unsigned long long *t4 = &tr[(w_ * 8 + 4) * 256], *t5 = &tr[(w_ * 8 + 5) * 256], *t6 = &tr[(w_ * 8 + 6) * 256], *t7 = &tr[(w_ * 8 + 7) * 256];
                             if (!tg[2] || G < 4) continue;
                             std::vector<double> top, arr, seen, pub, tot, end_;
                             unsigned long long first_top = ~0ull;
@@ -1197,6 +1197,18 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
                                     (double(tg[0]) - double(first_top)) / 100.0, (double(tg[1]) - double(first_top)) / 100.0, (double(tg[2]) - double(first_top)) / 100.0,
                                     seen.front(), q_(seen, 0.5), seen.back());
                             if (!pub.empty()) {
+                                {   // the five workgroups that published last: when each arrived, saw the release, published
+                                    std::vector<std::pair<double, uint32_t>> late;
+                                    for (uint32_t b = 0; b + 2 < G; b++)
+                                        if (t4[b] > tg[2]) late.emplace_back((double(t4[b]) - double(tg[2])) / 100.0, b);
+                                    std::sort(late.rbegin(), late.rend());
+                                    for (size_t i = 0; i < late.size() && i < 5; i++) {
+                                        const uint32_t b = late[i].second;
+                                        fprintf(stderr, "[dvs persist trace] window %d: workgroup %u arrived %.2f before the release was stored, saw it +%.2f, handed its speculative job over +%.2f, was through the job loop +%.2f\n",
+                                                w_ * 12 + 12, b, (double(tg[2]) - double(t1[b])) / 100.0, (double(t2[b]) - double(tg[2])) / 100.0,
+                                                (double(t7[b]) - double(tg[2])) / 100.0, late[i].first);
+                                    }
+                                }
                                 srt(pub); srt(tot); srt(end_);
                                 fprintf(stderr, "[dvs persist trace] window %d, its accept (us after the release was stored; min/median/max): job published %.2f / %.2f / %.2f, "
                                         "totals read %.2f / %.2f / %.2f, rebuild done %.2f / %.2f / %.2f\n", w_ * 12 + 12, pub.front(), q_(pub, 0.5), pub.back(),
@@ -1205,6 +1217,8 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
                         }
                     }
                 }
+                if (dbg[15] + dbg[14])
+                    fprintf(stderr, "[dvs persist block 0] accepts for which its leave-one-out job was ready when the release came: %llu (the candidate's frequencies: %llu)\n", dbg[15], dbg[14]);
                 if (dbg[9] + dbg[10] + dbg[11] + dbg[12])
                     fprintf(stderr, "[dvs persist block 0] us inside the phases: window top %.1f own rows scanned %.1f hint look + record %.1f (then: scan = the rest) | behind the rebuild %.1f\n",
                             dbg[9] / 100.0, dbg[10] / 100.0, dbg[11] / 100.0, dbg[12] / 100.0);
