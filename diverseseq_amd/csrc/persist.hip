@@ -1294,6 +1294,29 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     if (tid < 16) s_dbg[tid] = 0ull;
     __syncthreads();
     unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
+#ifdef DVS_PROBE
+// ONE interval per build (-DDVS_PERSIST_STAMPS -DDVS_PROBE=k, scripts/probe.sh): thread 0 of block 0 (it owns a leave-one-out
+// job) and of the last scanning block (it owns none) take two clock reads per pass -- everything else is switched off, so
+// what is measured is not the stamps.  [0] the ticks, [1] the passes.
+#define P_PROBE_BEGIN(id)                                                                          \
+    do {                                                                                           \
+        if ((id) == DVS_PROBE && (blockIdx.x == 0 || blockIdx.x == n_work - 1) && tid == 0)        \
+            t_prev = __builtin_amdgcn_s_memrealtime();                                             \
+    } while (0)
+#define P_PROBE_END(id)                                                                            \
+    do {                                                                                           \
+        if ((id) == DVS_PROBE && (blockIdx.x == 0 || blockIdx.x == n_work - 1) && tid == 0) {      \
+            s_dbg[0] += __builtin_amdgcn_s_memrealtime() - t_prev;                                 \
+            s_dbg[1] += 1;                                                                         \
+        }                                                                                          \
+    } while (0)
+#define P_STAMP(k) do { } while (0)
+#define P_STAMP_B0(k) do { } while (0)
+#define P_TRACE(which) do { } while (0)
+#define P_TRACE_G(slot) do { } while (0)
+#else
+#define P_PROBE_BEGIN(id) do { } while (0)
+#define P_PROBE_END(id) do { } while (0)
 #define P_STAMP(k)                                                         \
     do {                                                                   \
         if ((lead || blockIdx.x == 0) && tid == 0) {                       \
@@ -1322,11 +1345,14 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         if (tid == 0 && (epoch == 12 || epoch == 24 || epoch == 36 || epoch == 48))               \
             sync->trace[epoch / 12 - 1][3][slot] = __builtin_amdgcn_s_memrealtime();               \
     } while (0)
+#endif  // DVS_PROBE
 #else
 #define P_STAMP(k) do { } while (0)
 #define P_STAMP_B0(k) do { } while (0)
 #define P_TRACE(which) do { } while (0)
 #define P_TRACE_G(slot) do { } while (0)
+#define P_PROBE_BEGIN(id) do { } while (0)
+#define P_PROBE_END(id) do { } while (0)
 #endif
 // A -DDVS_PERSIST_CHAOS build holds pseudo-randomly chosen workgroups back (one in sixteen up to ~10 us, one in four
 // thousand for ~60 us) at the points where they are about to write or read a word another workgroup reads or
@@ -1374,6 +1400,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             *win.nlist = 0u;
         }
         __syncthreads();
+        P_PROBE_END(6);
+        P_PROBE_BEGIN(1);  // 1: the window's top -> this workgroup's arrival record stored
         P_CHAOS(1);  // (late into the window)
         P_STAMP_B0(9);  // (the top of the window: its barrier)
         P_TRACE(0);
@@ -1610,6 +1638,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             const uint32_t nl = *win.nlist;
             const unsigned long long own = s_win[0] | ((unsigned long long)(nl < P_LIST ? nl : P_LIST) << 1);
             if (tid == 0 && early_rec != epoch) __hip_atomic_store(&sync->wrec[epoch & 1u][blockIdx.x], own, RLX_AGENT);
+            P_PROBE_END(1);
+            P_PROBE_BEGIN(2);  // 2: record stored -> release seen
             P_STAMP_B0(11);  // (the workgroup's barrier, the record stored)
             P_TRACE(1);
             if (gath) {
@@ -1701,6 +1731,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             }
         }
         if (!bar_ok) { exit_status = SEL_ERROR; break; }
+        P_PROBE_END(2);
+        P_PROBE_BEGIN(3);  // 3: release seen -> this workgroup's job handed to the accumulators (an accept)
         P_CHAOS(3);  // (late to act on the release: the lists are walked, the job published, later than the others')
         P_TRACE(2);
         P_STAMP(1);
@@ -2483,6 +2515,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 job_published = true;
             }
         }
+        P_PROBE_END(3);
+        P_PROBE_BEGIN(4);  // 4: job handed over -> the totals read and the argmin taken
         P_TRACE(7);
 #ifdef DVS_PERSIST_STAMPS
         if constexpr (SPEC || SPEC_BIG) {  // (block 0: how often its job was ready when the release came)
@@ -2845,6 +2879,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // for the next one now, ahead of its stores.  Then S_new_i = clamp(S_i - low_i) + f_i and the new
         // member's row go to global memory (sl is still the old vector: the rebuild below rewrites it) -- what
         // resolve_kernel would have left behind, also for the kernels that take over an argmin too close to call.
+        P_PROBE_END(4);
+        P_PROBE_BEGIN(5);  // 5: argmin known -> sl rebuilt
         P_CHAOS(5);  // (the mirror block: late with its early announcement; everybody: late into the rebuild)
         P_TRACE(5);
         announce_early(epoch + 1);
@@ -2958,6 +2994,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         }
         __syncthreads();
         P_STAMP(5);
+        P_PROBE_END(5);
+        P_PROBE_BEGIN(6);  // 6: sl rebuilt -> the next window's top
         P_TRACE(6);
         P_STAMP_B0(12);  // (behind the rebuild: the cache's decision)
         if (st.cursor >= st.npos) { exit_status = SEL_DONE; break; }
@@ -2966,8 +3004,13 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     }
 
 #ifdef DVS_PERSIST_STAMPS
+#ifdef DVS_PROBE
+    if ((blockIdx.x == n_work - 1 || blockIdx.x == 0) && tid == 0)
+        for (int k_ = 0; k_ < 16; k_++) (blockIdx.x == 0 ? sync->dbg2 : sync->dbg)[k_] += s_dbg[k_];
+#else
     if ((lead || blockIdx.x == 0) && tid == 0)
         for (int k_ = 0; k_ < 16; k_++) (lead ? sync->dbg : sync->dbg2)[k_] += s_dbg[k_];
+#endif
 #endif
     // ---- exit: the scan vector of the multi-launch kernels, base = (S - lowest) / size -- sl / n, bin by bin
     // the value their finalize kernel forms -- once per launch instead of once per accept.  (Not behind an
@@ -3329,6 +3372,11 @@ size_t dvs_persist_dbg_offset(void) { return offsetof(PSync, dbg2); }  // dbg2[1
 size_t dvs_persist_trace_offset(void) { return offsetof(PSync, trace); }
 #else
 size_t dvs_persist_trace_offset(void) { return 0; }
+#endif
+#if defined(DVS_PERSIST_STAMPS) && defined(DVS_PROBE)
+int dvs_persist_probe_id(void) { return DVS_PROBE; }
+#else
+int dvs_persist_probe_id(void) { return 0; }
 #endif
 
 int dvs_persist_launch(dvs_ctx *ctx, dvs_select *s) {

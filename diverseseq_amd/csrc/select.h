@@ -152,3 +152,4 @@ int dvs_persist_prepare_main(dvs_ctx *ctx, dvs_select *s);
 int dvs_persist_prepare_head(dvs_ctx *ctx, dvs_select *s, uint32_t stop_at, hipStream_t on);
 size_t dvs_persist_dbg_offset(void);
 size_t dvs_persist_trace_offset(void);  // 0 unless built with -DDVS_PERSIST_STAMPS
+int dvs_persist_probe_id(void);         // the one interval a -DDVS_PROBE=k build measures (0: none)

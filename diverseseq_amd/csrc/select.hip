@@ -1159,6 +1159,12 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
             if (!blk) continue;
             if (hipMemcpy(dbg, static_cast<char *>(blk) + dvs_persist_dbg_offset(), sizeof dbg, hipMemcpyDeviceToHost) == hipSuccess) {
                 fprintf(stderr, "[dvs persist] %s launch\n", which ? "full-grid" : "head-phase");
+                if (dvs_persist_probe_id()) {  // (a one-interval build: [0] ticks, [1] passes; block 0 then the last scanning block)
+                    fprintf(stderr, "[dvs persist probe %d] block 0 (owns a job): %.3f us x %llu; the last scanning block (no job): %.3f us x %llu\n",
+                            dvs_persist_probe_id(), dbg[1] ? dbg[0] / 100.0 / double(dbg[1]) : 0.0, dbg[1],
+                            dbg[17] ? dbg[16] / 100.0 / double(dbg[17]) : 0.0, dbg[17]);
+                    continue;
+                }
                 for (int w = 0; w < 2; w++)
                     fprintf(stderr, "[dvs persist %s] us: scan %.1f bar1 %.1f resolve %.1f loo %.1f bar2 %.1f | partials %.1f combine %.1f lowest-row fetch %.1f rebuild %.1f\n",
                             w ? "mirror block" : "block 0", dbg[0 + 16 * w] / 100.0, dbg[1 + 16 * w] / 100.0,
