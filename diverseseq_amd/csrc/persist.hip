@@ -2516,6 +2516,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             }
         }
         P_PROBE_END(3);
+        P_PROBE_BEGIN(12);  // 12: job handed over -> member arrays shifted (in front of the job loop)
         P_PROBE_BEGIN(4);  // 4: job handed over -> the totals read and the argmin taken
         P_TRACE(7);
 #ifdef DVS_PERSIST_STAMPS
@@ -2626,6 +2627,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // order the K workgroups of a member arrive in, and partial sums of this magnitude
         // (>= 2^-3) convert without rounding.  (Every term is >= 0: the clamps of the reference
         // leave no negative bin here, so there is no NaN to carry.)
+        P_PROBE_END(12);
+        P_PROBE_BEGIN(13);  // 13: the job loop and wave 0's wait for the totals
         const double rdiv = 1.0 / (dn - 1.0);
         unsigned long long *acc_all = part;                                                    // the eight replicas
         const unsigned long long *acc = acc_all + uint64_t(blockIdx.x & 7u) * (maxn + 1) * 2;  // this group's
@@ -2771,6 +2774,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                     s_prev[a1 * 2] = ph1 + wh1;
                     s_prev[a1 * 2 + 1] = ps1 + ws1;
                 }
+                P_PROBE_END(13);
+                P_PROBE_BEGIN(14);  // 14: totals complete -> argmin handed to the other waves
                 P_STAMP(4);
                 const double h0 = p_acc_value(wh0), sv0 = p_acc_value(ws0);
                 const double h1 = p_acc_value(wh1), sv1 = p_acc_value(ws1);
@@ -2880,6 +2885,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         // member's row go to global memory (sl is still the old vector: the rebuild below rewrites it) -- what
         // resolve_kernel would have left behind, also for the kernels that take over an argmin too close to call.
         P_PROBE_END(4);
+        P_PROBE_END(14);
+        P_PROBE_BEGIN(7);  // 7: argmin handed over -> the rebuild's first load (the mirror's stores, the band checks)
         P_PROBE_BEGIN(5);  // 5: argmin known -> sl rebuilt
         P_CHAOS(5);  // (the mirror block: late with its early announcement; everybody: late into the rebuild)
         P_TRACE(5);
@@ -2938,6 +2945,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         st.li = lowest;
         st.band = band;
         st.thr = st.total_jsd + DVS_EPS;
+        P_PROBE_END(7);
+        P_PROBE_BEGIN(8);  // 8: the rebuild's loads and arithmetic
         {   // sl <- S_new - new lowest, in place (each thread owns its bins)
             const bool low_is_new = lowest == n - 1;
             const T *lrow = mat + s_pos[lowest] * B;
@@ -2985,6 +2994,8 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
                 }
             }
         }
+        P_PROBE_END(8);
+        P_PROBE_BEGIN(9);  // 9: the barrier behind the rebuild
         if (lead && tid == 0) {
             ctl->lowest = lowest;
             ctl->band = band;
@@ -2994,6 +3005,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         }
         __syncthreads();
         P_STAMP(5);
+        P_PROBE_END(9);
         P_PROBE_END(5);
         P_PROBE_BEGIN(6);  // 6: sl rebuilt -> the next window's top
         P_TRACE(6);
