@@ -1731,6 +1731,19 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
             }
         }
         if (!bar_ok) { exit_status = SEL_ERROR; break; }
+        // The release names a SURE event and nobody listed a candidate in front of it: the window ends in the accept
+        // of exactly that row (a sure event is accepted outright, below) -- so a job worked out for it while the
+        // workgroup waited goes to the accumulators HERE, before anything else is looked at: the other workgroups'
+        // wait for the totals ends when the last job's additions land.
+        [[maybe_unused]] bool early_published = false;
+        if constexpr (SPEC || SPEC_BIG) {
+            const uint64_t h0 = p_word_pos(rel_w, epoch);
+            if (h0 != SEL_NONE && p_word_sure(rel_w) && p_word_listed(rel_w) == 0u && one_job && has_job && !lead &&
+                spec_job_pos == h0) {
+                if (tid < 8) p_acc_add(part + (uint64_t(tid) * (maxn + 1) + blockIdx.x / K) * 2, spec_th, spec_ts);
+                early_published = true;
+            }
+        }
         P_PROBE_END(2);
         P_PROBE_BEGIN(3);  // 3: release seen -> this workgroup's job handed to the accumulators (an accept)
         P_CHAOS(3);  // (late to act on the release: the lists are walked, the job published, later than the others')
@@ -2508,7 +2521,7 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
         [[maybe_unused]] bool job_published = false;
         if constexpr (SPEC || SPEC_BIG) {
             if (one_job && has_job && !lead && spec_job_pos == p) {
-                if (tid < 8) {  // lane g adds the job's words to group g's replica
+                if (tid < 8 && !early_published) {  // lane g adds the job's words to group g's replica
                     unsigned long long *dst = part + (uint64_t(tid) * (maxn + 1) + blockIdx.x / K) * 2;
                     p_acc_add(dst, spec_th, spec_ts);
                 }
