@@ -284,7 +284,8 @@ def _labels(ids) -> np.ndarray:
 
 def _gather(store: ZarrStoreWrapper, seqids):
     """the sequences of `seqids` as one stream (uint8 data, uint64 offsets[n+1]) + identity labels"""
-    ids = list(store.unique_seqids) if seqids is None else list(seqids)
+    # (a list is used as it is -- nothing here changes it)
+    ids = list(store.unique_seqids) if seqids is None else seqids if isinstance(seqids, list) else list(seqids)
     if store._disk is None:
         # (the store's own id list -- one C-level list comparison -- needs no look-ups, and its ids are
         # distinct by construction: the labels are the positions)

@@ -1485,10 +1485,14 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     const uint32_t *caller_labels = nullptr;
     if (labels && !order && params->mode != DVS_MODE_SET) {
         bool distinct = true;
-        std::vector<uint32_t> sorted(labels, labels + npos);
-        std::sort(sorted.begin(), sorted.end());
-        for (uint64_t p = 1; p < npos && distinct; p++)
-            distinct = sorted[p] != sorted[p - 1] || sorted[p] == 0xFFFFFFFFu;
+        bool rising = true;  // (the usual call: the positions themselves -- one pass, no copy)
+        for (uint64_t p = 1; p < npos && rising; p++) rising = labels[p] > labels[p - 1];
+        if (!rising) {
+            std::vector<uint32_t> sorted(labels, labels + npos);
+            std::sort(sorted.begin(), sorted.end());
+            for (uint64_t p = 1; p < npos && distinct; p++)
+                distinct = sorted[p] != sorted[p - 1] || sorted[p] == 0xFFFFFFFFu;
+        }
         if (distinct) {
             caller_labels = labels;
             labels = nullptr;

@@ -160,23 +160,29 @@ def test_concat():
 
 
 def test_host_packer_of_the_packed_upload():
-    """csrc/pack_host.cpp (AVX2 + BMI2 when the CPU has them, scalar otherwise): 2 bits per base + 1
-    invalid bit per base in the kernels' own word layout (uint32 of codes per 16 bases with the FIRST base in
-    the top bit pair, uint16 of mask with the first base in bit 15), positions behind the end of a ragged tail
-    marked invalid -- against a numpy restatement, at every length around the 16- and 32-base groups"""
+    """csrc/pack_host.cpp (AVX-512, AVX2 or scalar, whichever the CPU runs -- every form it runs is checked): 2
+    bits per base + 1 invalid bit per base in the kernels' own word layout (uint32 of codes per 16 bases with the
+    FIRST base in the top bit pair, uint16 of mask with the first base in bit 15), positions behind the end of a
+    ragged tail marked invalid -- against a numpy restatement, at every length around the 16-, 32- and 64-base
+    groups"""
     lib = ctypes.CDLL(str(_lib.LIB_PATH))
-    f = lib.dvs_pack_bases
-    f.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    f = lib.dvs_pack_bases_level
+    f.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     f.restype = None
+    lib.dvs_pack_level.restype = ctypes.c_int
+    top = lib.dvs_pack_level()
+    assert 0 <= top <= 2
     rng = np.random.default_rng(3)
-    for n in (0, 1, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 1000, 4099, 1 << 16):
+    for n in (0, 1, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 127, 128, 129, 1000, 4099, 1 << 16):
         src = rng.integers(0, 4, size=n, dtype=np.uint8)
         if n:
             src[rng.integers(0, n, size=n // 10 + 1)] = rng.integers(4, 256, size=n // 10 + 1, dtype=np.uint8)
         nw = (n + 15) // 16
-        codes = np.full(nw + 4, 0xDEADBEEF, np.uint32)
-        mask = np.full(nw + 4, 0xBEEF, np.uint16)
-        f(src.ctypes.data, n, codes.ctypes.data, mask.ctypes.data)
         ec, em = pack_reference(src)
-        assert (codes[:nw] == ec).all() and (mask[:nw] == em).all(), n
-        assert (codes[nw:] == 0xDEADBEEF).all() and (mask[nw:] == 0xBEEF).all(), n  # nothing written behind the last word
+        for level in range(top + 1):
+            codes = np.full(nw + 4, 0xDEADBEEF, np.uint32)
+            mask = np.full(nw + 4, 0xBEEF, np.uint16)
+            f(src.ctypes.data, n, codes.ctypes.data, mask.ctypes.data, level)
+            assert (codes[:nw] == ec).all() and (mask[:nw] == em).all(), (n, level)
+            # nothing written behind the last word
+            assert (codes[nw:] == 0xDEADBEEF).all() and (mask[nw:] == 0xBEEF).all(), (n, level)
