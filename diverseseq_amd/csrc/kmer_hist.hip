@@ -557,19 +557,33 @@ int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint3
             longest = len > longest ? len : longest;
         }
         if (bad || longest >= uint64_t(TILE_LEN) + k) {
+            uint64_t long_windows = 0;
             for (uint32_t r = 0; r < nseq; r++) {
                 const uint64_t s0 = offsets[r], s1 = offsets[r + 1];
                 if (s1 < s0 || s1 > nbytes)
                     return dvs_set_error(ctx, DVS_ERR_VALUE, "offsets[%u..%u] = %llu..%llu out of range", r,
                                          r + 1, (unsigned long long)s0, (unsigned long long)s1);
+                if (s1 - s0 >= k && s1 - (s0 + k - 1) > TILE_LEN) long_windows += s1 - (s0 + k - 1);
+            }
+            // A tile of a long row ends in one global atomic per non-empty bin, so it should hold many more windows
+            // than there are bins (at 4^7 bins a 32768-window tile spent as long merging as counting: 4.35 ms for
+            // 1050 genomes of 3 Mb) -- 16 windows a bin, while that still leaves thousands of tiles for the grid.
+            // (The tiles of a long row count in 32-bit LDS words: no limit from the packed 16-bit counters.)
+            uint64_t tile_long = TILE_LEN;
+            {
+                const uint64_t B_ = k < 16 ? uint64_t(1) << (2 * k) : ~0ull;  // (the usual alphabet's; any length is correct)
+                while (tile_long < 262144 && tile_long < 16 * B_ && long_windows / (2 * tile_long) >= 4096) tile_long *= 2;
+            }
+            for (uint32_t r = 0; r < nseq; r++) {
+                const uint64_t s0 = offsets[r], s1 = offsets[r + 1];
                 if (s1 - s0 < k) continue;
                 const uint64_t first = s0 + k - 1;
                 if (s1 - first <= TILE_LEN) continue;
                 long_rows.push_back(r);
-                for (uint64_t b = first; b < s1; b += TILE_LEN) {
+                for (uint64_t b = first; b < s1; b += tile_long) {
                     KTile t;
                     t.begin = b;
-                    t.end = std::min<uint64_t>(b + TILE_LEN, s1);
+                    t.end = std::min<uint64_t>(b + tile_long, s1);
                     t.seq_begin = s0;
                     t.row = r;
                     t.single = 0;

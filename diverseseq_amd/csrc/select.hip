@@ -502,12 +502,39 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, double *scrat
 
 // Initial set: S = sum of the member rows in member order, sumH likewise,
 // total_jsd (SummedRecords::new, records.rs:36-47).  Members were written by
-// seed_kernel.  One block.
+// seed_kernel.  Two launches: the sum bin by bin over the whole grid (every bin's adds in member order; as
+// part of the one-block kernel below it was 0.5 ms at 4^7 bins and 100 members -- one CU pulling 12.8 MB),
+// then one block for the entropy of the sum, whose order of additions is the block's.
+constexpr int RSUM_THREADS = 256;
+__global__ __launch_bounds__(RSUM_THREADS) void rebuild_sum_kernel(SelDev d) {
+    __shared__ uint32_t s_ord[RSUM_THREADS];
+    const uint32_t n = d.ctl->size;
+    const uint64_t i = uint64_t(blockIdx.x) * RSUM_THREADS + threadIdx.x;
+    double acc = 0.0;
+    for (uint32_t base = 0; base < n; base += RSUM_THREADS) {
+        const uint32_t cnt = n - base < RSUM_THREADS ? n - base : RSUM_THREADS;
+        __syncthreads();
+        if (threadIdx.x < cnt) s_ord[threadIdx.x] = d.ord[base + threadIdx.x];
+        __syncthreads();
+        if (i < d.B) {
+            uint32_t r = 0;
+            for (; r + 8 <= cnt; r += 8) {  // eight rows requested together, added in member order
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = d.M[uint64_t(s_ord[r + q]) * d.B + i];
+#pragma unroll
+                for (int q = 0; q < 8; q++) acc += v[q];
+            }
+            for (; r < cnt; r++) acc += d.M[uint64_t(s_ord[r]) * d.B + i];
+        }
+    }
+    if (i < d.B) d.S[i] = acc;
+}
+
 __global__ __launch_bounds__(WIDE_THREADS) void rebuild_kernel(SelDev d) {
     __shared__ double scratch[48];
-    // the member order and entropies go through LDS first: read straight from global memory every
-    // row's address (and thread 0's whole entropy sum) is a chain of dependent round trips
-    __shared__ uint32_t s_ord[WIDE_THREADS];
+    // the members' entropies go through LDS first: read straight from global memory thread 0's whole
+    // entropy sum is a chain of dependent round trips
     __shared__ double s_mh[WIDE_THREADS];
     SelCtl *ctl = d.ctl;
     const uint32_t n = ctl->size;
@@ -515,17 +542,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void rebuild_kernel(SelDev d) {
     for (uint32_t base = 0; base < n; base += WIDE_THREADS) {
         const uint32_t cnt = n - base < WIDE_THREADS ? n - base : WIDE_THREADS;
         __syncthreads();
-        if (threadIdx.x < cnt) {
-            const uint32_t o = d.ord[base + threadIdx.x];
-            s_ord[threadIdx.x] = o;
-            s_mh[threadIdx.x] = d.mH[o];
-        }
+        if (threadIdx.x < cnt) s_mh[threadIdx.x] = d.mH[d.ord[base + threadIdx.x]];
         __syncthreads();
-        for (uint64_t i = threadIdx.x; i < d.B; i += WIDE_THREADS) {
-            double acc = base ? d.S[i] : 0.0;
-            for (uint32_t r = 0; r < cnt; r++) acc += d.M[uint64_t(s_ord[r]) * d.B + i];
-            d.S[i] = acc;
-        }
         if (threadIdx.x == 0)
             for (uint32_t r = 0; r < cnt; r++) sh += s_mh[r];
     }
@@ -751,6 +769,14 @@ __device__ __forceinline__ bool max_batch_applies(const SelCtl *ctl, const SelDe
            ctl->mb_stuck == 0;
 }
 
+// One workgroup: ONE member r (or the whole bigger set, or the score) and MB_RG consecutive rows of the batch --
+// S and the member's row are read once for the group, and what differs per row is the candidate's counts.  The
+// jobs only steer the cursor over rows that change nothing (anything inside a band stops the batch), so their
+// quotients are the exact ones by fma (exact_div_u32) and the means multiply by reciprocals, like the persistent
+// engine's batches (persist.hip): two f64 divisions per bin fewer -- the kernel was bound by them (4^7 bins, 117
+// members, 32 rows: 150 us, ~100 vector instructions per bin).
+constexpr uint32_t MB_RG = 4;
+static_assert(MB_ROWS % MB_RG == 0, "whole groups");
 template <typename T>
 __global__ __launch_bounds__(MB_THREADS) void max_batch_jobs_kernel(SelDev d, const T *__restrict__ mat,
                                                                     double *__restrict__ res, uint32_t JW) {
@@ -758,46 +784,76 @@ __global__ __launch_bounds__(MB_THREADS) void max_batch_jobs_kernel(SelDev d, co
     __shared__ double2 ltab[128];  // log2_tab's table (select_dev.h): ~18 instead of ~33 instructions per logarithm
     const SelCtl *ctl = d.ctl;
     if (!max_batch_applies(ctl, d, JW)) return;
-    const uint32_t n = ctl->size, r = blockIdx.x, e = blockIdx.y;
+    const uint32_t n = ctl->size, r = blockIdx.x, e0 = blockIdx.y * MB_RG;
     if (r >= n + 3) return;
     if (threadIdx.x < 128) log2_tab_fill(ltab, threadIdx.x);
     __syncthreads();
-    const uint64_t p = ctl->cursor + e;
-    if (p >= ctl->npos) return;
-    const uint32_t row = d.order ? d.order[p] : uint32_t(p);
-    const uint32_t lab = d.labels ? d.labels[p] : row;
-    if (lab < d.nlabels && d.inset[lab]) return;  // a member already: no event (records.rs:71-74,87-89)
-    const uint32_t toti = d.totals[row];
-    if (toti == 0) return;  // no valid k-mer: the stream skips the row (records.rs:419-423)
-    const double tot = double(toti);
-    const T *rp = mat + uint64_t(row) * d.B;
-    Ent en;
+    // the group's rows (the same answers in every thread: the branches below are uniform)
+    const T *rp[MB_RG];
+    double tot[MB_RG], rt[MB_RG];
+    bool live[MB_RG], any = false;
+#pragma unroll
+    for (uint32_t q = 0; q < MB_RG; q++) {
+        const uint64_t p = ctl->cursor + e0 + q;
+        live[q] = false;
+        rp[q] = mat;
+        tot[q] = rt[q] = 1.0;
+        if (p >= ctl->npos) continue;
+        const uint32_t row = d.order ? d.order[p] : uint32_t(p);
+        const uint32_t lab = d.labels ? d.labels[p] : row;
+        if (lab < d.nlabels && d.inset[lab]) continue;  // a member already: no event (records.rs:71-74,87-89)
+        const uint32_t toti = d.totals[row];
+        if (toti == 0) continue;  // no valid k-mer: the stream skips the row (records.rs:419-423)
+        live[q] = any = true;
+        rp[q] = mat + uint64_t(row) * d.B;
+        tot[q] = double(toti);
+        rt[q] = 1.0 / tot[q];
+    }
+    if (!any) return;
+    Ent en[MB_RG];
     if (r == n + 2) {  // increases_jsd: block_delta_jsd's arithmetic
         const double *low = d.M + uint64_t(d.ord[ctl->lowest]) * d.B;
-        const double dsize = double(n);
+        const double rn = 1.0 / double(n);
         for (uint64_t i = threadIdx.x; i < d.B; i += MB_THREADS) {
             const double v = d.S[i] - low[i];
-            en.add((v + cand_freq(rp, i, tot)) / dsize, ltab);
+#pragma unroll
+            for (uint32_t q = 0; q < MB_RG; q++)
+                if (live[q]) en[q].add((v + cand_freq_x(rp[q], i, tot[q], rt[q])) * rn, ltab);
         }
     } else if (r == n + 1) {  // the bigger set as a whole (resolve_body: Stmp = S + candidate, H(Stmp / (n + 1)))
-        const double dn1 = double(n + 1);
-        for (uint64_t i = threadIdx.x; i < d.B; i += MB_THREADS) en.add((d.S[i] + cand_freq(rp, i, tot)) / dn1, ltab);
+        const double rn1 = 1.0 / double(n + 1);
+        for (uint64_t i = threadIdx.x; i < d.B; i += MB_THREADS) {
+            const double sv = d.S[i];
+#pragma unroll
+            for (uint32_t q = 0; q < MB_RG; q++)
+                if (live[q]) en[q].add((sv + cand_freq_x(rp[q], i, tot[q], rt[q])) * rn1, ltab);
+        }
     } else {  // without member r, r == n: without the candidate (loo_body)
-        const double div = double(n);
+        const double rdiv = 1.0 / double(n);
         const double *mrow = r < n ? d.M + uint64_t(d.ord[r]) * d.B : nullptr;
         for (uint64_t i = threadIdx.x; i < d.B; i += MB_THREADS) {
-            const double f = cand_freq(rp, i, tot);
-            double v = ((d.S[i] + f) - (mrow ? mrow[i] : f)) / div;  // updated_mean_freqs, records.rs:276-286
-            if (v <= DVS_EPS) v = 0.0;
-            en.add(v, ltab);
+            const double sv = d.S[i], mv = mrow ? mrow[i] : 0.0;
+#pragma unroll
+            for (uint32_t q = 0; q < MB_RG; q++)
+                if (live[q]) {
+                    const double f = cand_freq_x(rp[q], i, tot[q], rt[q]);
+                    double v = ((sv + f) - (mrow ? mv : f)) * rdiv;  // updated_mean_freqs, records.rs:276-286
+                    if (v <= DVS_EPS) v = 0.0;
+                    en[q].add(v, ltab);
+                }
         }
     }
-    double h = en.h, mn = en.mn, sm = en.sum;
-    block_red3(h, mn, sm, scratch);
-    if (threadIdx.x == 0) {
-        res[(uint64_t(e) * 3 + 0) * JW + r] = h;
-        res[(uint64_t(e) * 3 + 1) * JW + r] = sm;
-        res[(uint64_t(e) * 3 + 2) * JW + r] = mn;
+#pragma unroll
+    for (uint32_t q = 0; q < MB_RG; q++) {
+        if (!live[q]) continue;
+        double h = en[q].h, mn = en[q].mn, sm = en[q].sum;
+        block_red3(h, mn, sm, scratch);
+        if (threadIdx.x == 0) {
+            const uint32_t e = e0 + q;
+            res[(uint64_t(e) * 3 + 0) * JW + r] = h;
+            res[(uint64_t(e) * 3 + 1) * JW + r] = sm;
+            res[(uint64_t(e) * 3 + 2) * JW + r] = mn;
+        }
     }
 }
 
@@ -1091,7 +1147,7 @@ static int launch_max_batch(dvs_ctx *ctx, dvs_select *s, const T *mat, uint32_t 
         if (rc) return rc;
     }
     if (size_bound + 3 > s->mb_jw) return DVS_OK;  // (a set beyond the result block: the ordinary iterations alone)
-    hipLaunchKernelGGL((max_batch_jobs_kernel<T>), dim3(size_bound + 3, MB_ROWS), dim3(MB_THREADS), 0, ctx->stream, s->dev, mat,
+    hipLaunchKernelGGL((max_batch_jobs_kernel<T>), dim3(size_bound + 3, MB_ROWS / MB_RG), dim3(MB_THREADS), 0, ctx->stream, s->dev, mat,
                        s->d_mbres, s->mb_jw);
     hipLaunchKernelGGL(max_batch_decide_kernel, dim3(1), dim3(WIDE_THREADS), 0, ctx->stream, s->dev, s->d_mbres, s->mb_jw);
     s->mb_launched++;
@@ -1457,6 +1513,7 @@ static int sel_seed(dvs_ctx *ctx, dvs_select *s, const T *mat, hipStream_t st, b
     }
     hipLaunchKernelGGL((seed_kernel<T>), dim3(uint32_t(seeds.size())), dim3(LOO_THREADS), 0,
                        st, s->dev, mat, d_seed);
+    hipLaunchKernelGGL(rebuild_sum_kernel, dim3(uint32_t((s->dev.B + RSUM_THREADS - 1) / RSUM_THREADS)), dim3(RSUM_THREADS), 0, st, s->dev);
     hipLaunchKernelGGL(rebuild_kernel, dim3(1), dim3(WIDE_THREADS), 0, st, s->dev);
     launch_iteration<T>(ctx, s, mat, 2, st);  // loo + finalize of the initial set
     // (one fused launch of one block for sets of <= 16 measured no faster: 2.29 vs 2.27 ms per step)
