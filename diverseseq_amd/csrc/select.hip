@@ -775,7 +775,7 @@ __device__ __forceinline__ bool max_batch_applies(const SelCtl *ctl, const SelDe
 // quotients are the exact ones by fma (exact_div_u32) and the means multiply by reciprocals, like the persistent
 // engine's batches (persist.hip): two f64 divisions per bin fewer -- the kernel was bound by them (4^7 bins, 117
 // members, 32 rows: 150 us, ~100 vector instructions per bin).
-constexpr uint32_t MB_RG = 4;
+constexpr uint32_t MB_RG = 2;
 static_assert(MB_ROWS % MB_RG == 0, "whole groups");
 template <typename T>
 __global__ __launch_bounds__(MB_THREADS) void max_batch_jobs_kernel(SelDev d, const T *__restrict__ mat,
@@ -811,37 +811,55 @@ __global__ __launch_bounds__(MB_THREADS) void max_batch_jobs_kernel(SelDev d, co
     }
     if (!any) return;
     Ent en[MB_RG];
-    if (r == n + 2) {  // increases_jsd: block_delta_jsd's arithmetic
-        const double *low = d.M + uint64_t(d.ord[ctl->lowest]) * d.B;
-        const double rn = 1.0 / double(n);
-        for (uint64_t i = threadIdx.x; i < d.B; i += MB_THREADS) {
-            const double v = d.S[i] - low[i];
+    // Four bins a thread per pass: S, the second row and the rows' counts are requested together, then the
+    // arithmetic -- every row's terms still in bin order (i, i + 256, ...), as the one-bin loop adds them.
+    auto run = [&](const double *second, auto term) {
+        constexpr int U = 4;
+        uint64_t i = threadIdx.x;
+        for (; i + uint64_t(U - 1) * MB_THREADS < d.B; i += uint64_t(U) * MB_THREADS) {
+            double sv[U], mv[U];
+            T c[MB_RG][U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                sv[u] = d.S[i + uint64_t(u) * MB_THREADS];
+                mv[u] = second ? second[i + uint64_t(u) * MB_THREADS] : 0.0;
+            }
 #pragma unroll
             for (uint32_t q = 0; q < MB_RG; q++)
-                if (live[q]) en[q].add((v + cand_freq_x(rp[q], i, tot[q], rt[q])) * rn, ltab);
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (live[q]) c[q][u] = rp[q][i + uint64_t(u) * MB_THREADS];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (uint32_t q = 0; q < MB_RG; q++)
+                    if (live[q]) en[q].add(term(sv[u], mv[u], count_freq_x(c[q][u], tot[q], rt[q])), ltab);
         }
+        for (; i < d.B; i += MB_THREADS) {
+            const double sv = d.S[i], mv = second ? second[i] : 0.0;
+#pragma unroll
+            for (uint32_t q = 0; q < MB_RG; q++)
+                if (live[q]) en[q].add(term(sv, mv, cand_freq_x(rp[q], i, tot[q], rt[q])), ltab);
+        }
+    };
+    if (r == n + 2) {  // increases_jsd: block_delta_jsd's arithmetic
+        const double rn = 1.0 / double(n);
+        run(d.M + uint64_t(d.ord[ctl->lowest]) * d.B, [&](double sv, double lowv, double f) { return ((sv - lowv) + f) * rn; });
     } else if (r == n + 1) {  // the bigger set as a whole (resolve_body: Stmp = S + candidate, H(Stmp / (n + 1)))
         const double rn1 = 1.0 / double(n + 1);
-        for (uint64_t i = threadIdx.x; i < d.B; i += MB_THREADS) {
-            const double sv = d.S[i];
-#pragma unroll
-            for (uint32_t q = 0; q < MB_RG; q++)
-                if (live[q]) en[q].add((sv + cand_freq_x(rp[q], i, tot[q], rt[q])) * rn1, ltab);
-        }
-    } else {  // without member r, r == n: without the candidate (loo_body)
+        run(nullptr, [&](double sv, double, double f) { return (sv + f) * rn1; });
+    } else if (r < n) {  // without member r (loo_body)
         const double rdiv = 1.0 / double(n);
-        const double *mrow = r < n ? d.M + uint64_t(d.ord[r]) * d.B : nullptr;
-        for (uint64_t i = threadIdx.x; i < d.B; i += MB_THREADS) {
-            const double sv = d.S[i], mv = mrow ? mrow[i] : 0.0;
-#pragma unroll
-            for (uint32_t q = 0; q < MB_RG; q++)
-                if (live[q]) {
-                    const double f = cand_freq_x(rp[q], i, tot[q], rt[q]);
-                    double v = ((sv + f) - (mrow ? mv : f)) * rdiv;  // updated_mean_freqs, records.rs:276-286
-                    if (v <= DVS_EPS) v = 0.0;
-                    en[q].add(v, ltab);
-                }
-        }
+        run(d.M + uint64_t(d.ord[r]) * d.B, [&](double sv, double mv, double f) {
+            double v = ((sv + f) - mv) * rdiv;  // updated_mean_freqs, records.rs:276-286
+            return v <= DVS_EPS ? 0.0 : v;
+        });
+    } else {  // r == n: without the candidate itself
+        const double rdiv = 1.0 / double(n);
+        run(nullptr, [&](double sv, double, double f) {
+            double v = ((sv + f) - f) * rdiv;
+            return v <= DVS_EPS ? 0.0 : v;
+        });
     }
 #pragma unroll
     for (uint32_t q = 0; q < MB_RG; q++) {
