@@ -129,6 +129,7 @@ void dvs_knobs_from_env(dvs_knobs *k) {
     k->ingest_no_stream = on("DVS_INGEST_NO_STREAM");
     const char *tk = getenv("DVS_TEST_KNOBS");
     k->test_persist_fake_error = tk && strstr(tk, "fake_persist_error") != nullptr;
+    if (const char *lt = tk ? strstr(tk, "long_tile_") : nullptr) k->test_long_tile = uint32_t(strtoul(lt + 10, nullptr, 10));
 }
 
 extern "C" {
@@ -138,6 +139,7 @@ int dvs_abi_version(void) { return DVS_ABI_VERSION; }
 int dvs_ctx_refresh_knobs(dvs_ctx *ctx) {
     if (!ctx) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
     dvs_knobs_from_env(&ctx->knobs);
+    ctx->off_cache.n_off = 0;  // (the tile lists of the last build were made under the old switches)
     return DVS_OK;
 }
 

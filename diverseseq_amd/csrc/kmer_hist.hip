@@ -573,6 +573,7 @@ int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint3
             {
                 const uint64_t B_ = k < 16 ? uint64_t(1) << (2 * k) : ~0ull;  // (the usual alphabet's; any length is correct)
                 while (tile_long < 262144 && tile_long < 16 * B_ && long_windows / (2 * tile_long) >= 4096) tile_long *= 2;
+                if (ctx->knobs.test_long_tile >= TILE_LEN) tile_long = ctx->knobs.test_long_tile;  // (tests: small inputs, long tiles)
             }
             for (uint32_t r = 0; r < nseq; r++) {
                 const uint64_t s0 = offsets[r], s1 = offsets[r + 1];

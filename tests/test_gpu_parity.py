@@ -83,6 +83,25 @@ def test_counts_long_sequences_multi_tile(ctx):
     _check_matrix(ctx, seqs, 3)
 
 
+@pytest.mark.parametrize("tile", [65536, 262144])
+def test_counts_long_rows_in_long_tiles(ctx, monkeypatch, tile):
+    """long rows are cut into tiles of up to 16 windows per bin once the input is large (2^28 bases and more:
+    dvs_hist_prepare); here the tile length is forced (DVS_TEST_KNOBS=long_tile_<n>) so that inputs the oracle counts in
+    a second take the same path: rows shorter than, equal to and a few windows beyond whole tiles, invalid symbols
+    across tile edges, a short row between them -- counts, totals and entropies against the oracle at 4^6 and 4^7"""
+    monkeypatch.setenv("DVS_TEST_KNOBS", f"long_tile_{tile}")
+    rng = np.random.default_rng(tile)
+    k_edge = 7
+    lens = (tile + k_edge - 1, tile + k_edge, 2 * tile + k_edge + 3, 3 * tile // 2, 40_000)
+    seqs = [rng.integers(0, 4, size=n, dtype=np.uint8) for n in lens]
+    for s in seqs:
+        s[rng.integers(0, s.size, size=s.size // 5000 + 1)] = 4
+    seqs[2][tile + 1:tile + 9] = 4  # invalid symbols across the first tile's end
+    seqs.insert(2, rng.integers(0, 4, size=700, dtype=np.uint8))
+    _check_matrix(ctx, seqs, 7)
+    _check_matrix(ctx, seqs, 6)
+
+
 def test_counts_fullest_single_tile(ctx):
     """the longest sequence that is still one tile (32 768 windows), as a homopolymer: one bin takes
     every count -- the packed 16-bit LDS counters of the whole-sequence kernel must not carry (low
