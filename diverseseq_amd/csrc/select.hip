@@ -910,10 +910,32 @@ __global__ __launch_bounds__(WIDE_THREADS) void max_batch_decide_kernel(SelDev d
                     const double mh = r < n ? d.mH[d.ord[r]] : H_e;
                     return tj - (re[r] - (sumH_t - mh) / div);
                 };
+                // (a lane's first four members' deltas stay in registers for the second and third pass -- every delta is
+                // two dependent global loads, and sets of up to 256 members need no more; the same values either way)
+                constexpr uint32_t KEEP = 4;
+                double kept[KEEP];
+                auto delta_again = [&](uint32_t r) {
+                    const uint32_t q = (r - lane) >> 6;
+                    double v = 0.0;
+                    bool have = false;
+#pragma unroll
+                    for (uint32_t x = 0; x < KEEP; x++)
+                        if (q == x) {
+                            v = kept[x];
+                            have = true;
+                        }
+                    return have ? v : delta(r);
+                };
                 double best = 1e6, acc = 0.0;
                 bool risky = sum_risky(svm, d.B) || !(hm == hm);
+#pragma unroll
+                for (uint32_t x = 0; x < KEEP; x++) kept[x] = 0.0;
                 for (uint32_t r = lane; r < n1; r += 64) {
                     const double v = delta(r);
+                    const uint32_t q = (r - lane) >> 6;
+#pragma unroll
+                    for (uint32_t x = 0; x < KEEP; x++)
+                        if (q == x) kept[x] = v;
                     risky |= sum_risky(re[JW + r], d.B);
                     acc += v;
                     if (v < best) best = v;
@@ -921,13 +943,13 @@ __global__ __launch_bounds__(WIDE_THREADS) void max_batch_decide_kernel(SelDev d
                 const double dmin = dvs_wave_min(best);
                 double fi = 4294967295.0;
                 for (uint32_t r = lane; r < n1; r += 64)
-                    if (dmin < 1e6 && delta(r) == dmin) fi = fmin(fi, double(r));
+                    if (dmin < 1e6 && delta_again(r) == dmin) fi = fmin(fi, double(r));
                 const double dfirst = dvs_wave_min(fi);
                 const uint32_t lowest = (dfirst < 4294967295.0) ? uint32_t(dfirst) : 0u;
                 const double mean = dvs_wave_sum(acc) / dn1;
                 double second = 1e6, tv = 0.0;
                 for (uint32_t r = lane; r < n1; r += 64) {
-                    const double v = delta(r);
+                    const double v = delta_again(r);
                     if (r != lowest && v < second) second = v;
                     const double t = v - mean;
                     tv += t * t;
