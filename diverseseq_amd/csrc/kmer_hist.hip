@@ -12,7 +12,8 @@
 //   * one 256-thread workgroup per TILE of k-mer end positions of ONE sequence;
 //     a sequence up to TILE_LEN bases is a single tile and its row is written
 //     once with coalesced 16-B stores; longer sequences (genomes) are split
-//     into tiles whose LDS histograms are merged with global u32 atomics;
+//     into tiles whose LDS histograms are merged with global u32 atomics (tiles of
+//     up to 16 windows per bin for large inputs: dvs_hist_prepare);
 //   * each lane owns 16-byte chunks (global_load_dwordx4, 1 KiB per wave
 //     instruction) plus the previous chunk as the k-1 halo; for num_states == 4
 //     the 32 bases are packed to a 64-bit 2-bit word and a 32-bit invalid mask
