@@ -692,7 +692,10 @@ int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const dvs_seq_view &sv, 
     }
     // 256 threads for whole sequences: with 16-18 KB of LDS each, 8 workgroups (32 waves) fill a CU;
     // measured on 100k x 5 kb: 0.67 ms at 256 threads, 0.78 at 320, 0.86 at 384 and 512
-    int nthreads = HIST_THREADS, tile_threads = HIST_THREADS;  // (genome tiles: 256 and 512 measure the same)
+    // (genome tiles: 256 and 512 measure the same at 4^6 bins; a 64 KB histogram -- 4^7 bins -- leaves room for two
+    // workgroups a CU, and 512 threads each put sixteen waves on it instead of eight)
+    int nthreads = HIST_THREADS;
+    const int tile_threads = (lds_hist && B * 4 > 32768) ? HIST_MAX_THREADS : HIST_THREADS;
     const size_t lds = (lds_hist ? ((B * 4 + 15) & ~15ull) : 0) + (CLOG_TBL + 32) * sizeof(double);
 #define DVS_LAUNCH_HIST(NS4, LH, PKD, GRID, TILES, NTHR, HOT)                                             \
     do {                                                                                         \
