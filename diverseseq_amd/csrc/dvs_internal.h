@@ -42,7 +42,7 @@ struct dvs_knobs {
     // test-only (DVS_TEST_KNOBS=fake_persist_error): the first persistent launch's outcome is read as SEL_ERROR
     bool test_persist_fake_error = false;
     // test-only (DVS_TEST_KNOBS=long_tile_<n>): long rows are cut into tiles of n windows whatever the input's size
-    // (the tiles only grow beyond 32768 windows for inputs of 2^28 bases and more: kmer_hist.hip dvs_hist_prepare)
+    // (the tiles only grow beyond 32768 windows for inputs of 2^27 bases and more: kmer_hist.hip dvs_hist_prepare)
     uint32_t test_long_tile = 0;
 };
 void dvs_knobs_from_env(dvs_knobs *k);

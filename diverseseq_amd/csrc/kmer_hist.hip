@@ -568,12 +568,12 @@ int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint3
             }
             // A tile of a long row ends in one global atomic per non-empty bin, so it should hold many more windows
             // than there are bins (at 4^7 bins a 32768-window tile spent as long merging as counting: 4.35 ms for
-            // 1050 genomes of 3 Mb) -- 16 windows a bin, while that still leaves thousands of tiles for the grid.
+            // 1050 genomes of 3 Mb) -- 16 windows a bin, while that still leaves >= 2048 tiles for the grid.
             // (The tiles of a long row count in 32-bit LDS words: no limit from the packed 16-bit counters.)
             uint64_t tile_long = TILE_LEN;
             {
                 const uint64_t B_ = k < 16 ? uint64_t(1) << (2 * k) : ~0ull;  // (the usual alphabet's; any length is correct)
-                while (tile_long < 262144 && tile_long < 16 * B_ && long_windows / (2 * tile_long) >= 4096) tile_long *= 2;
+                while (tile_long < 262144 && tile_long < 16 * B_ && long_windows / (2 * tile_long) >= 2048) tile_long *= 2;
                 if (ctx->knobs.test_long_tile >= TILE_LEN) tile_long = ctx->knobs.test_long_tile;  // (tests: small inputs, long tiles)
             }
             for (uint32_t r = 0; r < nseq; r++) {

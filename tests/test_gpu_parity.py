@@ -85,7 +85,7 @@ def test_counts_long_sequences_multi_tile(ctx):
 
 @pytest.mark.parametrize("tile", [65536, 262144])
 def test_counts_long_rows_in_long_tiles(ctx, monkeypatch, tile):
-    """long rows are cut into tiles of up to 16 windows per bin once the input is large (2^28 bases and more:
+    """long rows are cut into tiles of up to 16 windows per bin once the input is large (2^27 bases and more:
     dvs_hist_prepare); here the tile length is forced (DVS_TEST_KNOBS=long_tile_<n>) so that inputs the oracle counts in
     a second take the same path: rows shorter than, equal to and a few windows beyond whole tiles, invalid symbols
     across tile edges, a short row between them -- counts, totals and entropies against the oracle at 4^6 and 4^7"""
