@@ -57,11 +57,12 @@ def _check_counts(m, seqs, k):
 
 def test_planes_from_host_and_from_device(ctx):
     """dvs_pack_sequences: the host packer (threads + chunked copies) and the device kernel write the same words
-    as the numpy statement of the layout, at lengths around the 16-base words and across 4 Mi-base chunks"""
+    as the numpy statement of the layout, at lengths around the 16-base words and across the 1 Mi-base chunks of the
+    host packer (whose copies take 1, 2, 4, 8, then 16 chunks at a time)"""
     import torch
 
     rng = np.random.default_rng(11)
-    for n in (1, 15, 16, 17, 33, 4099, (4 << 20) - 1, (4 << 20) + 17, (9 << 20) + 5):
+    for n in (1, 15, 16, 17, 33, 4099, (1 << 20) - 1, (1 << 20) + 1, (3 << 20) + 17, (4 << 20) - 1, (9 << 20) + 5, (33 << 20) + 77):
         src = rng.integers(0, 4, size=n, dtype=np.uint8)
         src[rng.integers(0, n, size=n // 50 + 1)] = rng.integers(4, 256, size=n // 50 + 1, dtype=np.uint8)
         src[-1] = 7
@@ -123,7 +124,8 @@ def test_host_builds_cross_pcie_packed_and_are_read_packed(ctx, monkeypatch):
     n, L, k = 9000, 4000, 6
     data = rng.integers(0, 4, size=n * L, dtype=np.uint8)
     data[rng.integers(0, data.size, size=4000)] = 4
-    for a in ((4 << 20) - 2, (4 << 20) - 1, 4 << 20, (4 << 20) + 1, (8 << 20) - 1, 8 << 20):  # the host packer's chunk seams
+    for a in ((1 << 20) - 1, 1 << 20, (3 << 20) - 1, 3 << 20, (4 << 20) - 2, (4 << 20) - 1, 4 << 20, (4 << 20) + 1, (7 << 20) - 1,
+              7 << 20, (15 << 20) - 1, 15 << 20, (31 << 20) - 1, 31 << 20):  # the host packer's chunk seams and its copies' (1, 2, 4, 8, 16 chunks)
         data[a] = 9
     offsets = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
     m1 = ctx.build_matrix_concat(data, offsets, k, 4)
@@ -132,7 +134,8 @@ def test_host_builds_cross_pcie_packed_and_are_read_packed(ctx, monkeypatch):
     m2 = ctx.build_matrix_concat(data, offsets, k, 4)
     c2 = m2.counts()
     assert (c1 == c2).all() and (m1.totals() == m2.totals()).all() and (m1.entropy() == m2.entropy()).all()
-    for r in [0, 1, (4 << 20) // L - 1, (4 << 20) // L, (4 << 20) // L + 1, (8 << 20) // L, n - 1] + rng.integers(0, n, 20).tolist():
+    for r in [0, 1, (1 << 20) // L, (3 << 20) // L, (4 << 20) // L - 1, (4 << 20) // L, (4 << 20) // L + 1, (7 << 20) // L, (15 << 20) // L,
+              (31 << 20) // L, n - 1] + rng.integers(0, n, 20).tolist():
         assert (c1[r] == oracle.count_kmers(data[r * L:(r + 1) * L], 4, k)).all(), r
     m1.close()
     m2.close()
