@@ -366,7 +366,9 @@ def _build_beside_the_id_check(store: ZarrStoreWrapper, seqids, n_min: int, k: i
         t.join()
     if same and same[0]:
         if err is not None:
-            raise err
+            # (without the frames it came through: they hold views of the store's arena, and an exception somebody keeps
+            # would keep the arena from growing -- BufferError on the store's next write)
+            raise err.with_traceback(None)
         return seqids, m, np.arange(len(seqids), dtype=np.uint32)
     if m is not None:
         m.close()
