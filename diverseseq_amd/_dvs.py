@@ -360,15 +360,16 @@ def _build_beside_the_id_check(store: ZarrStoreWrapper, seqids, n_min: int, k: i
     try:
         m = engine.default_context().build_matrix_concat(data, offsets, k, num_states)
     except Exception as e:  # (re-raised below if the lists turn out equal: the ordinary way would meet it too)
-        err = e
+        # kept WITHOUT its traceback: the frames it came through hold views of the store's arena, and traceback ->
+        # this frame -> `err` is a cycle only the collector would break -- until then the arena could not grow
+        # (BufferError on the store's next write)
+        err = e.with_traceback(None)
     finally:
         data = None
         t.join()
     if same and same[0]:
         if err is not None:
-            # (without the frames it came through: they hold views of the store's arena, and an exception somebody keeps
-            # would keep the arena from growing -- BufferError on the store's next write)
-            raise err.with_traceback(None)
+            raise err
         return seqids, m, np.arange(len(seqids), dtype=np.uint32)
     if m is not None:
         m.close()

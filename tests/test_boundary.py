@@ -173,8 +173,12 @@ def test_id_lists_compared_beside_the_build_host_logic(monkeypatch):
                 raise RuntimeError("device says no")
             return Mat()
 
+    import gc
+
     monkeypatch.setattr(engine, "default_context", lambda: Ctx())
     monkeypatch.setattr(_dvs, "_SPEC_IDS", 50)
+    gc.collect()
+    gc.disable()  # (the views must go by reference counting: nobody can count on the collector before the next write)
     st = _dvs.make_zarr_store()
     for i in range(120):
         st.write(f"s{i:04d}", bytes([i % 4] * (20 + i % 3)))
@@ -195,7 +199,10 @@ def test_id_lists_compared_beside_the_build_host_logic(monkeypatch):
     assert _dvs._build_beside_the_id_check(st, swapped, 10, 3, 4) is None  # (the ordinary way will meet its own errors)
     with pytest.raises(RuntimeError, match="device says no"):
         _dvs._build_beside_the_id_check(st, list(own), 10, 3, 4)
-    st.write("one more", b"\x00\x01")  # (a live view of the arena would make this a BufferError)
+    try:
+        st.write("one more", b"\x00\x01")  # (a live view of the arena would make this a BufferError)
+    finally:
+        gc.enable()
 
 
 def test_concat():
