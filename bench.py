@@ -202,7 +202,8 @@ class Bench:
         self.sync()
 
         stats = {"rows_scored": 0, "scan_ms": 0.0, "scan_launches": 0, "n_accepts": 0,
-                 "n_windows": 0, "n_arbitrated": 0, "hist_ms": 0.0, "engine": 0, "count_bytes": 4}
+                 "n_windows": 0, "n_arbitrated": 0, "hist_ms": 0.0, "engine": 0, "count_bytes": 4,
+                 "scan_ms_last": 0.0, "rows_scored_last": 0, "arbiter_ms": 0.0}
         timing = {}   # exact: per-step all_gather; chunk: the merge's all_gathers (device events / host clock)
         last = {}     # members and statistics of the last timed step (checked against the oracle below)
         merge_buffers = {}
@@ -222,8 +223,9 @@ class Bench:
                 merged.close()
             if collect:
                 s = sel.summary()
-                for key in ("rows_scored", "scan_ms", "scan_launches", "n_accepts", "n_windows", "n_arbitrated"):
-                    stats[key] += getattr(s, key)
+                for key in ("rows_scored", "scan_ms", "scan_launches", "n_accepts", "n_windows", "n_arbitrated",
+                            "scan_ms_last", "rows_scored_last", "arbiter_ms"):
+                    stats[key] += getattr(s, key, 0)
                 stats["hist_ms"] += (t1 - t0) * 1e3
                 stats["engine"] = s.engine
                 stats["count_bytes"] = m.count_bytes
@@ -501,6 +503,7 @@ def main():
                 "hist_host_ms_per_step": stats["hist_ms"] / a.steps,  # host time of the build call (it does not wait for its kernel)
                 "scan_ms_per_step": stats["scan_ms"] / a.steps,
                 "tie_arbitrations": stats["n_arbitrated"],
+                "host_arbiter_ms": stats["arbiter_ms"],
                 "offsets_cache": "off in the timed steps (every step validates its offsets as a first build does; "
                                  "sequences of one length laid end to end -- this workload -- are recognised in that "
                                  "pass and built from (base, stride): nothing is uploaded)",
@@ -527,6 +530,20 @@ def main():
                 "avg_launch_us": stats["scan_ms"] * 1e3 / max(1, stats["scan_launches"]),
             },
         }
+        # The average over a selection's launches hides two very different ones when it starts with a head phase
+        # (the event-dense first rows on the head CUs beside the histogram, then the full grid): each on its own
+        if stats["engine"] == 1 and stats["scan_launches"] == 2 * a.steps and stats["scan_ms_last"] > 0:
+            def launch_line(what, ms, rows):
+                byts = rows * B * cb
+                return {"what": what, "avg_launch_us": ms * 1e3 / a.steps, "rows_per_launch": rows / a.steps,
+                        "bytes_per_launch": byts / a.steps, "achieved": byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                        "unit": "GB/s", "frac": (byts / (ms * 1e-3) / 1e9 / peak) if ms > 0 else 0.0}
+            out["roofline"]["per_launch"] = [
+                launch_line("head phase: the stream's first rows on the head CUs, beside the histogram of the rest",
+                            stats["scan_ms"] - stats["scan_ms_last"], stats["rows_scored"] - stats["rows_scored_last"]),
+                launch_line("full grid: the rest of the stream from the state the head phase leaves",
+                            stats["scan_ms_last"], stats["rows_scored_last"]),
+            ]
         if b.test_engine:
             out["engine_module"] = b.test_engine  # (CPU test hook: not a measurement)
         if world > 1 or b.force_dist:

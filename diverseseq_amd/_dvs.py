@@ -19,8 +19,6 @@ from __future__ import annotations
 
 import operator
 
-import threading
-import time
 
 import numpy as np
 
@@ -331,58 +329,10 @@ def _check_k(k: int):
         raise ValueError("k cannot be 0")  # src/record.rs:126
 
 
-_SPEC_IDS = 20_000  # id lists from this length on are compared beside the build
-
-
-def _build_beside_the_id_check(store: ZarrStoreWrapper, seqids, n_min: int, k: int, num_states: int):
-    """An in-memory store asked for what looks like its own id list (same length, same first and last id): whether it
-    IS that list takes one C-level comparison of 1.7 ms per 100 000 ids -- which runs on a thread here, beside the
-    upload and histogram of the store's arena (the library's call lets go of the GIL), instead of in front of them.
-    The answer decides what is returned: (ids, matrix, labels) when the lists are equal; None -- the matrix thrown
-    away, or the build's exception swallowed -- when they are not or the shortcut does not apply, and the caller
-    takes the ordinary way with its own checks and errors."""
-    own_ids = store._ids if store._disk is None else None
-    if (own_ids is None or not isinstance(seqids, list) or len(seqids) < _SPEC_IDS or len(seqids) != len(own_ids)
-            or len(seqids) < n_min or k == 0 or seqids[0] != own_ids[0] or seqids[-1] != own_ids[-1]):
-        return None
-    same = []
-
-    def compare():
-        # (first let the caller's thread reach the library's call, where it lets go of the GIL: a list comparison
-        # holds it from its first element to its last)
-        time.sleep(3e-4)
-        same.append(seqids == own_ids)
-
-    t = threading.Thread(target=compare)
-    t.start()
-    m, err = None, None
-    data, offsets = store._concat(own_ids, True)
-    try:
-        m = engine.default_context().build_matrix_concat(data, offsets, k, num_states)
-    except Exception as e:  # (re-raised below if the lists turn out equal: the ordinary way would meet it too)
-        # kept WITHOUT its traceback: the frames it came through hold views of the store's arena, and traceback ->
-        # this frame -> `err` is a cycle only the collector would break -- until then the arena could not grow
-        # (BufferError on the store's next write)
-        err = e.with_traceback(None)
-    finally:
-        data = None
-        t.join()
-    if same and same[0]:
-        if err is not None:
-            raise err
-        return seqids, m, np.arange(len(seqids), dtype=np.uint32)
-    if m is not None:
-        m.close()
-    return None
-
-
 def _gather_and_build(store: ZarrStoreWrapper, seqids, n_min: int, k: int, num_states: int):
     """ids, count matrix and labels of a selection's stream.  `data` may be a VIEW of the in-memory
     store's arena: it is let go on every way out of here -- also when the checks or the build raise, since
     a traceback would otherwise keep the frame's view alive and the store's next write fail (BufferError)."""
-    spec = _build_beside_the_id_check(store, seqids, n_min, k, num_states)
-    if spec is not None:
-        return spec
     ids, data, offsets, labels = _gather(store, seqids)
     try:
         if len(ids) < n_min:

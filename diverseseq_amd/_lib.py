@@ -59,7 +59,8 @@ class SelectSummary(C.Structure):
                 ("n_windows", C.c_uint32), ("n_events", C.c_uint32),
                 ("n_accepts", C.c_uint32), ("n_arbitrated", C.c_uint32),
                 ("scan_ms", C.c_double), ("scan_launches", C.c_uint64),
-                ("engine", C.c_uint32), ("rows_coarse_passed", C.c_uint32)]
+                ("engine", C.c_uint32), ("rows_coarse_passed", C.c_uint32),
+                ("scan_ms_last", C.c_double), ("rows_scored_last", C.c_uint64), ("arbiter_ms", C.c_double)]
 
 
 class DvsLibraryMissing(RuntimeError):

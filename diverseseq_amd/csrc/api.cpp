@@ -9,7 +9,7 @@ uint64_t dvs_pow_u64(uint32_t base, uint32_t exp, bool *overflow);
 void dvs_matrix_free_fields(dvs_matrix *m);
 int dvs_matrix_fill_counts(dvs_ctx *ctx, dvs_matrix *m, const dvs_seq_view &sv, const uint64_t *offsets, bool no_wait);
 int dvs_matrix_fill_freq_entropy(dvs_ctx *ctx, dvs_matrix *m);
-int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint32_t k, uint64_t nbytes, size_t *n_long_out);
+int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint32_t k, uint64_t nbins, uint64_t nbytes, size_t *n_long_out);
 bool dvs_hist_rows_fit_u16(const dvs_ctx *ctx, uint64_t B, size_t n_long);
 int dvs_matrix_fill_freq_totals(dvs_ctx *ctx, dvs_matrix *m, const double *d_meta);
 int dvs_matrix_fill_compacted(dvs_ctx *ctx, dvs_matrix *m, const double *d_in, const double *d_meta);
@@ -342,7 +342,7 @@ static int matrix_build_view(dvs_ctx *ctx, const dvs_seq_view &sv, const uint64_
     // the offsets first: whether any sequence needs more than one tile decides the width of the rows
     size_t n_long = 0;
     if (nseq) {
-        const int prc = dvs_hist_prepare(ctx, offsets, nseq, k, sv.nbytes, &n_long);
+        const int prc = dvs_hist_prepare(ctx, offsets, nseq, k, B, sv.nbytes, &n_long);
         if (prc) return prc;
     }
     dvs_matrix *m = new dvs_matrix();
@@ -432,6 +432,7 @@ int dvs_matrix_build_packed(dvs_ctx *ctx, const dvs_packed *p, const uint64_t *o
     sv.codes = p->d_codes;
     sv.mask = p->d_mask;
     sv.nbytes = p->nbases;
+    p->async_readers = true;  // (dvs_packed_destroy waits for the kernels enqueued here)
     return matrix_build_view(ctx, sv, offsets, nseq, k, 4, !ctx->knobs.build_wait, out);
 }
 

@@ -188,6 +188,11 @@ struct dvs_packed {
     uint32_t *d_codes = nullptr;
     uint16_t *d_mask = nullptr;
     uint64_t nbases = 0, nwords = 0;
+    // kernels that read the planes were enqueued without being waited for (dvs_matrix_build_packed,
+    // dvs_sketches_build_packed -- on the context's stream or, for a split build, its stream_rest): the planes
+    // go back to the block cache, which orders reuse on the context's stream only, so dvs_packed_destroy drains
+    // those streams first
+    mutable bool async_readers = false;
 };
 // what the kernels take: either the byte form (seqs) or the packed planes
 struct dvs_seq_view {

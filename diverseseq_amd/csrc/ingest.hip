@@ -277,11 +277,21 @@ struct dvs_seqbatch {
     std::vector<uint64_t> offsets;     // nseq + 1
     std::vector<uint64_t> header_pos;  // file offset of the '>' of every record of the file
     dvs_packed *packed = nullptr;      // after dvs_seqbatch_pack: the bases at 3 bits each (d_codes released)
+    // the alphabet the batch was encoded with puts the four bases first (the library's own DNA / RNA table): only
+    // then is "symbol >= 4" the same as "not a base" and the batch may be re-stated in the packed form
+    bool four_state_alphabet = false;
+    // builds over d_codes that were not waited for (dvs_matrix_build_from_seqbatch: the context's stream or, for
+    // a split build, its stream_rest): dvs_seqbatch_destroy drains those streams before the block goes back
+    mutable bool async_readers = false;
 };
 
 extern "C" void dvs_seqbatch_destroy(dvs_seqbatch *b) {
     if (!b) return;
     if (b->packed) dvs_packed_destroy(b->packed);
+    if (b->d_codes && b->async_readers && b->ctx) {
+        if (b->ctx->stream_rest) (void)hipStreamSynchronize(b->ctx->stream_rest);
+        (void)hipStreamSynchronize(b->ctx->stream);
+    }
     if (b->d_codes) dvs_dev_free(b->ctx, b->d_codes);
     dvs_ctx_release(b->ctx);
     delete b;
@@ -312,6 +322,12 @@ extern "C" int dvs_seqbatch_from_fasta(dvs_ctx *ctx, const uint8_t *raw, int raw
     const uint8_t gap = lut[(unsigned char)'-'];
     dvs_seqbatch *b = new dvs_seqbatch;
     b->ctx = ctx;
+    {
+        uint8_t dna[256], rna[256];
+        dvs_default_alphabet_lut(0, dna);
+        dvs_default_alphabet_lut(1, rna);
+        b->four_state_alphabet = memcmp(lut, dna, 256) == 0 || memcmp(lut, rna, 256) == 0;
+    }
     dvs_ctx_retain(ctx);
     const uint64_t nb = (nbytes + ING_BLOCK - 1) / ING_BLOCK;
     uint8_t *d_raw = nullptr, *d_lut = nullptr;
@@ -505,6 +521,10 @@ extern "C" int dvs_seqbatch_get_codes(dvs_ctx *ctx, const dvs_seqbatch *b, uint8
 extern "C" int dvs_seqbatch_pack(dvs_ctx *ctx, dvs_seqbatch *b) {
     if (!ctx || !b) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
     if (b->packed) return DVS_OK;
+    if (!b->four_state_alphabet)
+        return dvs_set_error(ctx, DVS_ERR_VALUE,
+                             "only a batch encoded with the DNA / RNA alphabet can be packed (2 bits per base): "
+                             "another alphabet's symbols >= 4 would all become \"invalid\"");
     dvs_packed *p = nullptr;
     int rc = dvs_packed_alloc(ctx, b->total, &p);
     if (!rc) rc = dvs_packed_fill_from_device(ctx, p, b->d_codes);
@@ -526,6 +546,7 @@ extern "C" int dvs_matrix_build_from_seqbatch(dvs_ctx *ctx, const dvs_seqbatch *
             return dvs_set_error(ctx, DVS_ERR_VALUE, "a packed batch holds four-state sequences, not %u states", num_states);
         return dvs_matrix_build_packed(ctx, b->packed, b->offsets.data(), b->nseq, k, out);
     }
+    b->async_readers = true;  // (dvs_seqbatch_destroy waits for the kernels enqueued here)
     return dvs_matrix_build(ctx, b->d_codes, 1, b->offsets.data(), b->nseq, k, num_states, out);
 }
 extern "C" int dvs_sketches_build_from_seqbatch(dvs_ctx *ctx, const dvs_seqbatch *b, uint32_t k, uint32_t sketch_size,
@@ -536,5 +557,6 @@ extern "C" int dvs_sketches_build_from_seqbatch(dvs_ctx *ctx, const dvs_seqbatch
             return dvs_set_error(ctx, DVS_ERR_VALUE, "a packed batch holds four-state sequences, not %u states", num_states);
         return dvs_sketches_build_packed(ctx, b->packed, b->offsets.data(), b->nseq, k, sketch_size, mash_canonical, out);
     }
+    b->async_readers = true;
     return dvs_sketches_build(ctx, b->d_codes, 1, b->offsets.data(), b->nseq, k, sketch_size, num_states, mash_canonical, out);
 }

@@ -494,7 +494,7 @@ void dvs_matrix_free_fields(dvs_matrix *m) {
 // The offsets of a build: validated, the tile lists of genome-length sequences derived, everything
 // uploaded -- or found unchanged in the context's cache.  *n_long = sequences needing more than one
 // tile (none: every row's counts fit 16 bits and the matrix may be built as kind 2).
-int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint32_t k, uint64_t nbytes,
+int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint32_t k, uint64_t nbins, uint64_t nbytes,
                      size_t *n_long_out) {
     dvs_ctx::OffsetsCache &oc = ctx->off_cache;
     const size_t n_off = size_t(nseq) + 1;
@@ -572,9 +572,10 @@ int dvs_hist_prepare(dvs_ctx *ctx, const uint64_t *offsets, uint32_t nseq, uint3
             // (The tiles of a long row count in 32-bit LDS words: no limit from the packed 16-bit counters.)
             uint64_t tile_long = TILE_LEN;
             {
-                const uint64_t B_ = k < 16 ? uint64_t(1) << (2 * k) : ~0ull;  // (the usual alphabet's; any length is correct)
+                const uint64_t B_ = nbins ? nbins : 1;  // (num_states^k of this build; any tile length counts correctly)
                 while (tile_long < 262144 && tile_long < 16 * B_ && long_windows / (2 * tile_long) >= 2048) tile_long *= 2;
-                if (ctx->knobs.test_long_tile >= TILE_LEN) tile_long = ctx->knobs.test_long_tile;  // (tests: small inputs, long tiles)
+                // (tests: small inputs, long tiles -- at most 2^20 windows, far below what a 32-bit counter holds)
+                if (ctx->knobs.test_long_tile >= TILE_LEN) tile_long = std::min<uint64_t>(ctx->knobs.test_long_tile, uint64_t(1) << 20);
             }
             for (uint32_t r = 0; r < nseq; r++) {
                 const uint64_t s0 = offsets[r], s1 = offsets[r + 1];

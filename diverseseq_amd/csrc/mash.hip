@@ -963,6 +963,7 @@ extern "C" int dvs_sketches_build_packed(dvs_ctx *ctx, const dvs_packed *p, cons
         sv.codes = p->d_codes;
         sv.mask = p->d_mask;
         sv.nbytes = p->nbases;
+        p->async_readers = true;  // (dvs_packed_destroy waits for the kernels enqueued here)
         rc = mash_sketch_view(ctx, sv, offsets, nseq, k, sketch_size, 4, mash_canonical, &sk->d_sk, &sk->d_lens);
         if (rc) {
             dvs_ctx_release(ctx);

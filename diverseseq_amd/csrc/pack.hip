@@ -93,6 +93,10 @@ int dvs_packed_alloc(dvs_ctx *ctx, uint64_t nbases, dvs_packed **out) {
 
 extern "C" void dvs_packed_destroy(dvs_packed *p) {
     if (!p) return;
+    if (p->async_readers && p->ctx) {  // (a build that was not waited for may still be reading the planes)
+        if (p->ctx->stream_rest) (void)hipStreamSynchronize(p->ctx->stream_rest);
+        (void)hipStreamSynchronize(p->ctx->stream);
+    }
     dvs_dev_free(p->ctx, p->d_codes);
     dvs_dev_free(p->ctx, p->d_mask);
     dvs_ctx_release(p->ctx);

@@ -969,6 +969,9 @@ __global__ __launch_bounds__(P_THREADS, 2) void persist_nmost_kernel(SelDev d, c
     st.mean_d = ctl->mean_delta;
     st.std_d = ctl->std_delta;
     st.cov_d = ctl->cov_delta;
+    // (rows scored by the launches in front of this one: global memory is quiescent here, and this launch's own
+    // additions come at its exit)
+    if (lead && tid == 0) ctl->rows_before_launch = ctl->rows_scored;
     if (ctl->status != SEL_RUN || ctl->ev_kind != 0 || st.n > maxn || st.n < 2) {
         if (lead && tid == 0 && ctl->status == SEL_RUN) ctl->why[7]++;  // (a pending event or a set the replica cannot hold)
         return;

@@ -20,6 +20,7 @@ struct SelCtl {
     unsigned long long arb_pos;
     unsigned long long rows_scored, rows_rechecked;
     unsigned long long rows_coarse_passed;  // rows the persistent engine's COARSE tier handed to the FAST tier
+    unsigned long long rows_before_launch;  // rows_scored as the latest persistent launch found it (its own share = the difference)
     uint32_t window, window_min, window_max;
     uint32_t status, arb_stage, forced, forced_lowest;
     uint32_t size, lowest, mode, max_size, stat;
@@ -134,8 +135,10 @@ struct dvs_select {
     std::vector<hipEvent_t> ev_pool;  // pairs (start, stop), one per scan launch
     size_t ev_used = 0;
     double scan_ms = 0.0;
+    double scan_ms_last = 0.0;  // ... the last launch's own
     uint64_t scan_launches = 0;
     uint32_t n_arbitrated = 0;
+    double arbiter_ms = 0.0;    // host wall clock inside dvs_select_arbitrate
     void *arbiter = nullptr;  // ExactSet*, created on first use
 };
 

@@ -27,6 +27,7 @@
 #include "select_dev.h"
 
 #include <algorithm>
+#include <chrono>
 #include <type_traits>
 #include <cmath>
 #include <cstring>
@@ -1243,8 +1244,10 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
         if (s->time_scan && s->ev_used) {  // the poll synchronised the stream: events are complete
             for (size_t i = 0; i + 1 < s->ev_used; i += 2) {
                 float ms = 0.f;
-                if (hipEventElapsedTime(&ms, s->ev_pool[i], s->ev_pool[i + 1]) == hipSuccess)
+                if (hipEventElapsedTime(&ms, s->ev_pool[i], s->ev_pool[i + 1]) == hipSuccess) {
                     s->scan_ms += ms;
+                    s->scan_ms_last = ms;
+                }
                 s->scan_launches++;
             }
             s->ev_used = 0;
@@ -1380,7 +1383,11 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
                                      "ambiguous decision at stream position %llu (stage %u): "
                                      "|score - threshold| within the rounding band",
                                      (unsigned long long)c.arb_pos, c.arb_stage);
-            rc = dvs_select_arbitrate(ctx, s);
+            {
+                const auto t_arb = std::chrono::steady_clock::now();
+                rc = dvs_select_arbitrate(ctx, s);
+                s->arbiter_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_arb).count();
+            }
             if (rc) return rc;
             persist_was_last = false;
             launch_iteration<T>(ctx, s, mat, c.arb_stage == ARB_RESOLVE ? 1 : 2);
@@ -1722,6 +1729,9 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
                                                          : n_seed);
         const double expect = double(n_eff) * (1.0 + std::log(std::max(1.0, double(npos) / double(n_eff))));
         uint64_t want = uint64_t(4.0 * expect) + 64;
+        // ... but that expectation is a randomly ordered stream's: one ordered by rising divergence accepts far more
+        // (10 k sequences, n = 10: thousands, not 380), so the log is never smaller than 256 MB worth of rows
+        want = std::max<uint64_t>(want, (uint64_t(256) << 20) / (B * 8));
         want = std::min<uint64_t>(want, std::max<uint64_t>(64, (uint64_t(2) << 30) / (B * 8)));
         want = std::min<uint64_t>(want, npos - n_seed + 2);
         d.rowlog_cap = uint32_t(want);
@@ -1883,6 +1893,9 @@ extern "C" int dvs_select_get_summary(dvs_ctx *ctx, const dvs_select *s, dvs_sel
     out->scan_launches = s->scan_launches;
     out->engine = s->persist ? 1u : 0u;
     out->rows_coarse_passed = uint32_t(std::min<unsigned long long>(c.rows_coarse_passed, 0xFFFFFFFFull));
+    out->scan_ms_last = s->scan_ms_last;
+    out->rows_scored_last = s->persist ? c.rows_scored - std::min(c.rows_before_launch, c.rows_scored) : 0;
+    out->arbiter_ms = s->arbiter_ms;
     return DVS_OK;
 }
 
@@ -2134,7 +2147,11 @@ extern "C" int dvs_select_step_poll(dvs_ctx *ctx, dvs_select *s, uint32_t *statu
                                  "|score - threshold| within the rounding band",
                                  (unsigned long long)s->h_ctl->arb_pos, s->h_ctl->arb_stage);
         const uint32_t stage = s->h_ctl->arb_stage;
-        rc = dvs_select_arbitrate(ctx, s);
+        {
+            const auto t_arb = std::chrono::steady_clock::now();
+            rc = dvs_select_arbitrate(ctx, s);
+            s->arbiter_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_arb).count();
+        }
         if (rc) return rc;
         dvs_mat_dispatch(s->mat, [&](auto *mp) {
             launch_iteration(ctx, s, mp, stage == ARB_RESOLVE ? 1 : 2);

@@ -116,6 +116,7 @@ class Sketches:
             self.ctx.check(L.dvs_sketches_build(self.ctx._h, src, on_dev, _lib.ptr(offsets, C.c_uint64), self.n, k,
                                                self.stride, num_states, flag, C.byref(h)))
         self._h = h
+        self._source = batch if batch is not None else packed  # (its planes must outlive the sketch kernels)
 
     def close(self):
         if getattr(self, "_h", None):

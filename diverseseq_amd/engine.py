@@ -171,7 +171,9 @@ class Context:
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         self.check(self._L.dvs_matrix_build_packed(self._h, packed._h, _lib.ptr(offsets, C.c_uint64), offsets.size - 1,
                                                    k, C.byref(h)))
-        return CountMatrix(self, h, k, 4)
+        m = CountMatrix(self, h, k, 4)
+        m._source = packed  # (the build is not waited for: the planes must outlive its kernels)
+        return m
 
     # ---- ingest ---------------------------------------------------------------
     def encode_fasta(self, raw, join_records: bool = False, moltype: str = "dna",
@@ -326,13 +328,19 @@ class SeqBatch:
     @property
     def packed(self) -> "Packed | None":
         h = self.ctx._L.dvs_seqbatch_packed(self._h)
-        return Packed(self.ctx, C.c_void_p(h), owned=False) if h else None
+        if not h:
+            return None
+        view = Packed(self.ctx, C.c_void_p(h), owned=False)
+        view._batch = self  # (a view of this batch's planes: the batch lives as long as the view)
+        return view
 
     def build_matrix(self, k: int, num_states: int = 4) -> "CountMatrix":
         """k-mer count matrix straight from the encoded bases in HBM (no host round trip)"""
         h = C.c_void_p()
         self.ctx.check(self.ctx._L.dvs_matrix_build_from_seqbatch(self.ctx._h, self._h, k, num_states, C.byref(h)))
-        return CountMatrix(self.ctx, h, k, num_states)
+        m = CountMatrix(self.ctx, h, k, num_states)
+        m._source = self  # (the build is not waited for: the batch must outlive its kernels)
+        return m
 
     def close(self):
         if getattr(self, "_h", None):
@@ -351,6 +359,7 @@ class CountMatrix:
 
     def __init__(self, ctx: Context, handle, k: int, num_states: int):
         self.ctx, self._h, self.k, self.num_states = ctx, handle, k, num_states
+        self._source = None  # the Packed / SeqBatch the matrix was built from, kept alive beside it
         L = ctx._L
         self.nrows = int(L.dvs_matrix_nrows(handle))
         self.nbins = int(L.dvs_matrix_nbins(handle))

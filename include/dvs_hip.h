@@ -168,7 +168,9 @@ int dvs_matrix_build_from_seqbatch(dvs_ctx *ctx, const dvs_seqbatch *b, uint32_t
  * collection then sits in HBM at 3/8 of the bytes, and dvs_matrix_build_from_seqbatch /
  * dvs_sketches_build_from_seqbatch (num_states 4) read the packed words.  dvs_seqbatch_dev_codes returns
  * NULL afterwards, dvs_seqbatch_get_codes unpacks (invalid symbols come back as 255), and
- * dvs_seqbatch_packed hands out the planes (NULL before). */
+ * dvs_seqbatch_packed hands out the planes (NULL before).  DVS_ERR_VALUE for a batch that was encoded
+ * with a caller's alphabet table instead of the library's DNA / RNA one (its symbols >= 4 are states, not
+ * "invalid"). */
 int dvs_seqbatch_pack(dvs_ctx *ctx, dvs_seqbatch *b);
 const dvs_packed *dvs_seqbatch_packed(const dvs_seqbatch *b);
 
@@ -217,6 +219,12 @@ typedef struct dvs_select_summary {
     uint64_t scan_launches;  /* scan-kernel launches the events bracket (no-op launches included) */
     uint32_t engine;         /* 0: one scan launch per window + state kernels; 1: persistent single launch */
     uint32_t rows_coarse_passed; /* persistent engine: rows its all-f32 tier could not decide (scored again by the f32-log tier) */
+    /* the LAST scan launch on its own (a selection that starts with a head phase has two very different launches:
+     * the event-dense head of the stream on the head CUs, then the full grid): its duration when timing is on, and the
+     * rows it scored; the launches in front of it are scan_ms - scan_ms_last and rows_scored - rows_scored_last */
+    double scan_ms_last;
+    uint64_t rows_scored_last;
+    double arbiter_ms;       /* host time spent in tie arbitration (n_arbitrated calls), wall clock */
 } dvs_select_summary;
 
 int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t *order,

@@ -92,8 +92,9 @@ def select_case(name, nseq, lo, hi, k, mode, reps=3, composition=False, **kw):
         sel = m.nmost(kw["n"]) if mode == "nmost" else m.max_divergent(kw["min_size"], nseq, "stdev")
         s = sel.summary()
         out = dict(size=s.size, accepts=s.n_accepts, rows_scored=s.rows_scored, rechecked=s.rows_rechecked, windows=s.n_windows, engine=s.engine,
-                   arbitrations=s.n_arbitrated, events=s.n_events, launches=s.scan_launches, engine_ms=round(s.scan_ms, 3),
-                   total_jsd=s.total_jsd)
+                   n_arbitrated=s.n_arbitrated, host_arbiter_ms=round(s.arbiter_ms, 3), events=s.n_events,
+                   launches=s.scan_launches, engine_ms=round(s.scan_ms, 3), last_launch_ms=round(s.scan_ms_last, 3),
+                   last_launch_rows=s.rows_scored_last, total_jsd=s.total_jsd)
         sel.close()
         m.close()
         return out

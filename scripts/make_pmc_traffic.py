@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """profiles/pmc_traffic.json from the two PMC summaries (scripts/rocpd_summary.py pmc ...):
 
-  python scripts/make_pmc_traffic.py profiles/r01_e_pmc_fetch_size.csv profiles/r01_e_pmc_write_size.csv r01_e
+  python scripts/make_pmc_traffic.py profiles/r01_e_pmc_fetch_size.csv profiles/r01_e_pmc_write_size.csv r01_e [bench.json]
+
+The optional fourth argument is the bench line of the SAME build and command line family (the kernel-trace run of
+scripts/profile_round.sh, `bench_kt.json`): its `roofline.bytes_per_launch` -- rows scored x 4^k x sizeof(count) per
+scan launch -- goes into the file as `algorithmic_bytes_per_launch`, which is what bench.py's `roofline.traffic_stale`
+compares a later run's own bytes per launch with.
 
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> B): rocprofv3 reports both in KiB and,
 on gfx950, FETCH_SIZE prices the 128-B requests of wide coalesced reads at 64 B
@@ -26,6 +31,12 @@ def load(path):
 
 fetch, write = load(sys.argv[1]), load(sys.argv[2])
 tag = sys.argv[3]
+alg = None
+if len(sys.argv) > 4:
+    for line in open(sys.argv[4]):
+        line = line.strip()
+        if line.startswith("{"):
+            alg = json.loads(line)["roofline"]["bytes_per_launch"]
 doc = {
     "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), "
               f"bench.py --steps 2 --warmup 1 --no-side-runs, MI355X (build {tag}); summaries in "
@@ -42,5 +53,8 @@ for label in KERNELS.values():
         continue  # (the profiled run skips the side passes: bench.py --no-side-runs)
     f, w = fetch[label], write[label]
     doc[label] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2 * f + w) * 1024}
+    if label == "persist_nmost_kernel" and alg:
+        doc[label]["algorithmic_bytes_per_launch"] = alg
+        doc[label]["traffic_over_algorithmic"] = (2 * f + w) * 1024 / alg
 json.dump(doc, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: doc[k] for k in KERNELS.values() if k in doc}, indent=1))

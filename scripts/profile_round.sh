@@ -20,5 +20,7 @@ python3 scripts/rocpd_summary.py stats $(db kt) > $out/kernel_stats.csv
 python3 scripts/rocpd_summary.py pmc $(db pmc_fetch) > $out/pmc_fetch_size.csv
 python3 scripts/rocpd_summary.py pmc $(db pmc_write) > $out/pmc_write_size.csv
 rm -rf $out/kt $out/pmc_fetch $out/pmc_write   # the databases are large; the summaries are what is kept
+# profiles/pmc_traffic.json of this build, with the algorithmic bytes per launch of the kernel-trace run beside the counters
+python3 scripts/make_pmc_traffic.py $out/pmc_fetch_size.csv $out/pmc_write_size.csv $tag $out/bench_kt.json > /dev/null && cp profiles/pmc_traffic.json $out/pmc_traffic.json
 head -4 $out/kernel_stats.csv | cut -c1-160
 cat $out/bench.json | cut -c1-400

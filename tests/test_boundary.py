@@ -152,59 +152,6 @@ def test_argument_errors_before_any_device_work():
         _dvs.final_nmost([], n=5)
 
 
-def test_id_lists_compared_beside_the_build_host_logic(monkeypatch):
-    """_dvs._build_beside_the_id_check without a device (a stand-in context that records what it is asked to build):
-    taken for the store's own list (other string objects, equal contents), left alone below the length limit, for
-    another length, other ends, k = 0 or too few sequences; a list that differs in the middle -- or a build that
-    raises while the lists differ -- costs a discarded matrix and returns None; a build that raises while the lists
-    are equal raises; and no view of the store's arena outlives any of it"""
-    class Mat:
-        closed = 0
-
-        def close(self):
-            Mat.closed += 1
-
-    class Ctx:
-        calls, fail = [], False
-
-        def build_matrix_concat(self, data, offsets, k, num_states):
-            Ctx.calls.append((int(data.size), int(offsets.size), k, num_states))
-            if Ctx.fail:
-                raise RuntimeError("device says no")
-            return Mat()
-
-    import gc
-
-    monkeypatch.setattr(engine, "default_context", lambda: Ctx())
-    monkeypatch.setattr(_dvs, "_SPEC_IDS", 50)
-    gc.collect()
-    gc.disable()  # (the views must go by reference counting: nobody can count on the collector before the next write)
-    st = _dvs.make_zarr_store()
-    for i in range(120):
-        st.write(f"s{i:04d}", bytes([i % 4] * (20 + i % 3)))
-    own = [f"s{i:04d}" for i in range(120)]
-    total = sum(20 + i % 3 for i in range(120))
-    r = _dvs._build_beside_the_id_check(st, own, 10, 3, 4)
-    assert r is not None and r[0] is own and isinstance(r[1], Mat) and r[2].tolist() == list(range(120))
-    assert Ctx.calls == [(total, 121, 3, 4)]
-    for ids, n_min, k in ((own[:40], 10, 3), (own[:-1], 10, 3), (own, 121, 3), (own, 10, 0),
-                          (["x"] + own[1:], 10, 3), (own[:-1] + ["x"], 10, 3), (tuple(own), 10, 3)):
-        assert _dvs._build_beside_the_id_check(st, ids, n_min, k, 4) is None
-    assert len(Ctx.calls) == 1 and Mat.closed == 0  # (none of those was built)
-    swapped = list(own)
-    swapped[5], swapped[60] = swapped[60], swapped[5]
-    assert _dvs._build_beside_the_id_check(st, swapped, 10, 3, 4) is None
-    assert len(Ctx.calls) == 2 and Mat.closed == 1  # (built on the assumption, thrown away)
-    Ctx.fail = True
-    assert _dvs._build_beside_the_id_check(st, swapped, 10, 3, 4) is None  # (the ordinary way will meet its own errors)
-    with pytest.raises(RuntimeError, match="device says no"):
-        _dvs._build_beside_the_id_check(st, list(own), 10, 3, 4)
-    try:
-        st.write("one more", b"\x00\x01")  # (a live view of the arena would make this a BufferError)
-    finally:
-        gc.enable()
-
-
 def test_concat():
     data, offs = engine.concat([b"\x00\x01", np.array([2, 3, 0], dtype=np.uint8), b""])
     assert data.tolist() == [0, 1, 2, 3, 0] and offs.tolist() == [0, 2, 5, 5]

@@ -82,48 +82,6 @@ def test_dvs_module_runs_the_persistent_engine():
     assert abs(mm.total_jsd - exp.total_jsd) <= RTOL * exp.total_jsd
 
 
-def test_long_id_lists_are_compared_beside_the_build(monkeypatch):
-    """from _dvs._SPEC_IDS ids on, an id list that looks like the in-memory store's own (same length, same ends) is
-    compared with it on a thread beside the upload and histogram of the store's arena: equal lists give the ordinary
-    answer; two ids swapped in the middle, or an unknown id there, must fall back to the ordinary way -- the
-    reference's answer for THAT order, the reference's error for the unknown id"""
-    from diverseseq_amd import _dvs as dvs
-
-    monkeypatch.setattr(dvs, "_SPEC_IDS", 2000)
-    seqs = synth_seqs(3000, 400, 91, invalid_frac=0.001)
-    st = _store_of(seqs)
-    ids = list(st.unique_seqids)
-    taken = []
-    real = dvs._build_beside_the_id_check
-
-    def spy(*a):
-        r = real(*a)
-        taken.append(r is not None)
-        return r
-
-    monkeypatch.setattr(dvs, "_build_beside_the_id_check", spy)
-    exp = oracle.nmost(seqs, 9, 5, 4)
-    got = dvs.nmost_divergent(st, n=9, k=5, seqids=[s[:3] + s[3:] for s in ids])  # (equal strings, other objects)
-    assert taken == [True] and got.stats["engine"] == 1
-    assert got.record_names == [ids[i] for i in exp.members()[0]]
-    got = dvs.max_divergent(st, min_size=5, max_size=30, k=5, seqids=list(ids))
-    assert taken == [True, True]
-    assert got.record_names == [ids[i] for i in oracle.max_divergent(seqs, 5, 30, 5, 4, "stdev").members()[0]]
-    order = list(range(3000))
-    order[3], order[1500] = order[1500], order[3]
-    got = dvs.nmost_divergent(st, n=9, k=5, seqids=[ids[i] for i in order])
-    assert taken == [True, True, False]
-    assert got.record_names == [ids[order[i]] for i in oracle.nmost([seqs[i] for i in order], 9, 5, 4).members()[0]]
-    wrong = list(ids)
-    wrong[777] = "no such sequence"
-    with pytest.raises(ValueError, match="not in store"):
-        dvs.nmost_divergent(st, n=9, k=5, seqids=wrong)
-    assert taken == [True, True, False, False]
-    with pytest.raises(ValueError, match="k cannot be 0"):  # (the shortcut leaves the argument checks to the ordinary way)
-        dvs.nmost_divergent(st, n=9, k=0, seqids=list(ids))
-    st.write("one more", seqs[0].tobytes())  # (no view of the arena is left behind by either way)
-
-
 def test_repeated_ids_keep_the_label_aware_engine():
     """an id listed twice (records.rs:71-73: a member's own id scores 0.0) needs the labels: the
     multi-launch engine serves it, with the reference's answer"""

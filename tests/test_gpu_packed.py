@@ -233,3 +233,54 @@ def test_ingested_batch_packed_in_place(ctx):
     with pytest.raises(ValueError):
         b.build_matrix(2, 17)  # a packed batch has four states
     b.close()
+
+
+def test_packed_batch_dropped_right_after_the_build(ctx):
+    """A build over packed planes is not waited for; the planes go back to the context's block cache when the
+    `Packed` goes.  Both guards: the C side (dvs_packed_destroy drains the streams its readers were enqueued on --
+    exercised by destroying the handle behind the Python object's back) and the Python side (the matrix keeps the
+    `Packed` it was built from), with an allocation of the same size filled right behind the destroy."""
+    from gpu_synth import synth_device
+
+    seqs_t, offsets = synth_device(30_000, 1900, 2100, seed=5)
+    host = seqs_t.cpu().numpy()
+    exp = np.stack([oracle.count_kmers(host[int(offsets[i]): int(offsets[i + 1])], 4, 6) for i in (0, 1023, 1024, 17_000, 29_999)])
+    for via_c in (True, False):
+        p = ctx.pack_device(seqs_t.data_ptr(), int(offsets[-1]))
+        m = ctx.build_matrix_packed(p, offsets, 6)
+        if via_c:  # the caller of the C ABI that destroys the batch right after the build call
+            ctx._L.dvs_packed_destroy(p._h)
+            p._h = None
+            m._source = None
+        del p
+        # the blocks the planes lived in are handed out again at once, for other content
+        other = (seqs_t + 1) % 4
+        q = ctx.pack_device(other.data_ptr(), int(offsets[-1]))
+        got = m.counts()
+        for j, i in enumerate((0, 1023, 1024, 17_000, 29_999)):
+            assert (got[i] == exp[j]).all(), (via_c, i)
+        assert (m.totals() == got.sum(axis=1)).all()
+        q.close()
+        m.close()
+        del other
+
+
+def test_only_the_dna_alphabet_packs(ctx):
+    """dvs_seqbatch_pack refuses a batch encoded with a caller's alphabet table (its symbols >= 4 are states)"""
+    import ctypes as C
+
+    from diverseseq_amd import _lib, engine
+
+    raw = np.frombuffer(b">p1\nMKVLAAGIVALLLAAGCSSA\n>p2\nMKKLLPTAAAGLLLLAAQPAMA\n", dtype=np.uint8)
+    lut = np.full(256, 255, dtype=np.uint8)
+    for i, ch in enumerate(b"ACDEFGHIKLMNPQRSTVWY"):
+        lut[ch] = i
+    h = C.c_void_p()
+    ctx.check(ctx._L.dvs_seqbatch_from_fasta(ctx._h, C.c_void_p(raw.ctypes.data), 0, raw.size, _lib.ptr(lut, C.c_uint8), 0,
+                                             C.byref(h)))
+    b = engine.SeqBatch(ctx, h, raw)
+    before = b.codes()
+    with pytest.raises(ValueError, match="DNA / RNA alphabet"):
+        b.pack()
+    assert b.packed is None and (b.codes() == before).all()  # (nothing was released)
+    b.close()
