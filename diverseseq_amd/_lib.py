@@ -36,6 +36,7 @@ EXPORTS = (
     "dvs_select_gather_members",
     "dvs_select_delta_jsd", "dvs_select_step_pack",
     "dvs_select_step_apply", "dvs_select_step_poll", "dvs_select_bench_scan", "dvs_selftest_fast_log2", "dvs_selftest_log2_acc", "dvs_selftest_log2_f32", "dvs_selftest_exact_div", "dvs_selftest_handover", "dvs_mash_sketch", "dvs_mash_distances", "dvs_euclidean_distances", "dvs_sketches_build", "dvs_sketches_destroy", "dvs_sketches_get", "dvs_sketches_dev", "dvs_sketches_dev_lens", "dvs_sketches_distances",
+    "dvs_sketches_from_device", "dvs_sketches_copy_to_device", "dvs_sketches_distances_device",
     "dvs_default_alphabet_lut", "dvs_seqbatch_from_fasta", "dvs_seqbatch_destroy", "dvs_seqbatch_info",
     "dvs_seqbatch_offsets", "dvs_seqbatch_header_positions", "dvs_seqbatch_dev_codes", "dvs_seqbatch_get_codes",
     "dvs_matrix_build_from_seqbatch",
@@ -176,6 +177,9 @@ def load() -> C.CDLL:
             getattr(L, n).argtypes = [vp]
             getattr(L, n).restype = vp
         L.dvs_sketches_distances.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, f64p]
+        L.dvs_sketches_from_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+        L.dvs_sketches_copy_to_device.argtypes = [vp, vp, vp, C.c_uint32, vp]
+        L.dvs_sketches_distances_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp]
         L.dvs_default_alphabet_lut.argtypes = [C.c_int, u8p]
         L.dvs_default_alphabet_lut.restype = None
         L.dvs_seqbatch_from_fasta.argtypes = [vp, vp, C.c_int, C.c_uint64, u8p, C.c_int, C.POINTER(vp)]

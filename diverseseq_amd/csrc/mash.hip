@@ -559,7 +559,10 @@ __global__ __launch_bounds__(PAIR_THREADS) void mash_pairs_kernel(
         for (int q = 0; q < PAIR_ADV; q++)
             if (have + q < pf_hi) pf[q] = fetch(have + q);
     };
-    if (staged && __all(!run || (nl >= s && nr >= s))) {
+    // (a wave without a single pair -- the columns right of the diagonal in a row's last block -- must not walk the
+    // full-sketch loop: with sketch_size = 4 000 000 000, which the reference's own ctree tests pass to mean "every
+    // k-mer", such a wave idled through a billion trips -- 90 s per call)
+    if (staged && __any(run) && __all(!run || (nl >= s && nr >= s))) {
         // Full sketches (the usual case): a pair takes exactly s steps -- li <= uni <= s <= nl, and the same for
         // ri, so neither sketch can run out first -- and a step needs no "still running" mask: two reads, three
         // compares, three adds-with-carry and the two addresses.  (Lanes without a pair idle through it.)
@@ -655,14 +658,32 @@ __global__ __launch_bounds__(EUC_THREADS) void euclid_kernel(const T *__restrict
     }
 }
 
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
+// The tile list of a batch, written on the device: tile t belongs to the sequence q with tpre[q] <= t < tpre[q + 1]
+// (binary search by the tile's own thread); every tile but a sequence's first begins on a packed word -- an absolute
+// position that is a multiple of 16 -- and a full tile ends on one, so its windows are exactly 512 groups of sixteen.
+// (The list used to be built on the host and uploaded: 366 000 entries, 8.8 MB from pageable memory, for 1000
+// genomes -- 2 ms of every sketch call that no kernel ran beside.)
+__global__ __launch_bounds__(256) void mash_tiles_kernel(const uint64_t *__restrict__ off, const uint64_t *__restrict__ tpre,
+                                                        uint32_t nseq, uint32_t k, uint64_t ntiles, MTile *__restrict__ tiles) {
+    const uint64_t t = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= ntiles) return;
+    uint32_t lo = 0, hi = nseq;  // tpre[lo] <= t < tpre[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tpre[mid] <= t) lo = mid;
+        else hi = mid;
     }
-    template <typename T>
-    T *as() { return static_cast<T *>(p); }
-};
+    const uint64_t o = off[lo], w = off[lo + 1] - o - (k - 1);  // (a sequence with tiles has at least one window)
+    auto mn = [](uint64_t a, uint64_t b) { return a < b ? a : b; };
+    const uint64_t first = mn(uint64_t(MASH_TILE) - (o & 15), w);
+    const uint64_t j = t - tpre[lo];
+    const uint64_t b = j == 0 ? 0 : first + (j - 1) * MASH_TILE;
+    MTile m;
+    m.begin = o + b;
+    m.count = uint32_t(j == 0 ? first : mn(uint64_t(MASH_TILE), w - b));
+    m.seq = lo;
+    tiles[t] = m;
+}
 
 struct PooledBuf {  // a block of the context's cache, handed back on scope exit
     dvs_ctx *ctx;
@@ -697,10 +718,9 @@ static int mash_sketch_view(dvs_ctx *ctx, const dvs_seq_view &sv, const uint64_t
     // tiles and the first hash range (lo, hi] per sequence: hashes are ~uniform, so
     // hi = 2^32 * (1.5 s + 256) / n_windows holds ~1.5 s candidates; a sequence of
     // at most SORT_CAP windows takes the whole range at once
-    std::vector<MTile> tiles;
     std::vector<long long> lo(nseq, -1);
     std::vector<uint32_t> hi(nseq), cap(nseq), nwin(nseq);
-    std::vector<uint64_t> coff(nseq + 1, 0);
+    std::vector<uint64_t> coff(nseq + 1, 0), tpre(nseq + 1, 0);
     const uint64_t want = uint64_t(s) + s / 2 + 256;
     for (uint32_t q = 0; q < nseq; q++) {
         const uint64_t len = offsets[q + 1] - offsets[q];
@@ -716,43 +736,57 @@ static int mash_sketch_view(dvs_ctx *ctx, const dvs_seq_view &sv, const uint64_t
             hi[q] = tv >= 4294967295.0L ? 0xFFFFFFFFu : uint32_t(tv);
         }
         coff[q + 1] = coff[q] + cap[q];
-        // (every tile but a sequence's first begins on a packed word -- an absolute position that is a
-        // multiple of 16 -- and a full tile ends on one: its windows are exactly 512 groups of sixteen, two
-        // rounds of the DNA kernel's 256 lanes with no straggler)
-        for (uint64_t b = 0; b < w;) {
-            MTile t;
-            t.begin = offsets[q] + b;
-            t.count = uint32_t(std::min<uint64_t>(MASH_TILE - (t.begin & 15), w - b));
-            t.seq = q;
-            tiles.push_back(t);
-            b += t.count;
+        // tiles of this sequence (mash_tiles_kernel lays them out): a first one up to the next packed word
+        // boundary + MASH_TILE windows, then whole tiles
+        uint64_t nt = 0;
+        if (w) {
+            const uint64_t first = std::min<uint64_t>(uint64_t(MASH_TILE) - (offsets[q] & 15), w);
+            nt = 1 + (w - first + MASH_TILE - 1) / MASH_TILE;
         }
+        tpre[q + 1] = tpre[q] + nt;
     }
-    DevBuf d_tiles, d_lo, d_hi, d_cap, d_coff, d_cnt, d_active, d_cand, d_list, d_status;
-    PooledBuf d_sk{ctx}, d_lens{ctx};  // (the two results live in the context's cache; released here unless handed over)
-    const size_t ntile = std::max<size_t>(tiles.size(), 1);
-    DVS_HIP(ctx, hipMalloc(&d_tiles.p, ntile * sizeof(MTile)));
-    DVS_HIP(ctx, hipMalloc(&d_lo.p, nseq * 8));
-    DVS_HIP(ctx, hipMalloc(&d_hi.p, nseq * 4));
-    DVS_HIP(ctx, hipMalloc(&d_cap.p, nseq * 4));
-    DVS_HIP(ctx, hipMalloc(&d_coff.p, (nseq + 1) * 8));
-    DVS_HIP(ctx, hipMalloc(&d_cnt.p, nseq * 4));
-    DVS_HIP(ctx, hipMalloc(&d_active.p, nseq));
-    DVS_HIP(ctx, hipMalloc(&d_cand.p, std::max<uint64_t>(coff[nseq], 1) * 4));
-    DVS_HIP(ctx, hipMalloc(&d_list.p, nseq * 4));
+    const uint64_t n_tiles = tpre[nseq];
+    if (n_tiles > 0xFFFFFFFFull) return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "more than 2^32 - 1 tiles in one batch");
+    // (every block comes from the context's cache: a sketch call used to hipMalloc and hipFree a dozen buffers)
+    PooledBuf d_tiles{ctx}, d_lo{ctx}, d_hi{ctx}, d_cap{ctx}, d_coff{ctx}, d_cnt{ctx}, d_active{ctx}, d_cand{ctx}, d_list{ctx},
+        d_status{ctx}, d_off{ctx}, d_tpre{ctx};
+    PooledBuf d_sk{ctx}, d_lens{ctx};  // (the two results; released here unless handed over)
     {
-        int arc = dvs_dev_alloc(ctx, &d_sk.p, size_t(nseq) * s * 4, "sketches");
+        const size_t ntile = std::max<size_t>(size_t(n_tiles), 1);
+        int arc = dvs_dev_alloc(ctx, &d_tiles.p, ntile * sizeof(MTile), "sketch tiles");
+        if (!arc) arc = dvs_dev_alloc(ctx, &d_lo.p, size_t(nseq) * 8, "hash range (lo)");
+        if (!arc) arc = dvs_dev_alloc(ctx, &d_hi.p, size_t(nseq) * 4, "hash range (hi)");
+        if (!arc) arc = dvs_dev_alloc(ctx, &d_cap.p, size_t(nseq) * 4, "candidate caps");
+        if (!arc) arc = dvs_dev_alloc(ctx, &d_coff.p, (size_t(nseq) + 1) * 8, "candidate offsets");
+        if (!arc) arc = dvs_dev_alloc(ctx, &d_cnt.p, size_t(nseq) * 4, "candidate counts");
+        if (!arc) arc = dvs_dev_alloc(ctx, &d_active.p, size_t(nseq), "active flags");
+        if (!arc) arc = dvs_dev_alloc(ctx, &d_cand.p, std::max<uint64_t>(coff[nseq], 1) * 4, "candidates");
+        if (!arc) arc = dvs_dev_alloc(ctx, &d_list.p, size_t(nseq) * 4, "active list");
+        if (!arc) arc = dvs_dev_alloc(ctx, &d_status.p, size_t(nseq) * 4, "sort status");
+        if (!arc) arc = dvs_dev_alloc(ctx, &d_off.p, (size_t(nseq) + 1) * 8, "sequence offsets");
+        if (!arc) arc = dvs_dev_alloc(ctx, &d_tpre.p, (size_t(nseq) + 1) * 8, "tile prefix");
+        if (!arc) arc = dvs_dev_alloc(ctx, &d_sk.p, size_t(nseq) * s * 4, "sketches");
         if (!arc) arc = dvs_dev_alloc(ctx, &d_lens.p, size_t(nseq) * 4, "sketch lengths");
         if (arc) return arc;
     }
-    DVS_HIP(ctx, hipMalloc(&d_status.p, nseq * 4));
-    if (!tiles.empty())
-        DVS_HIP(ctx, hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(MTile),
-                                    hipMemcpyHostToDevice, ctx->stream));
-    DVS_HIP(ctx, hipMemcpyAsync(d_cap.p, cap.data(), nseq * 4, hipMemcpyHostToDevice, ctx->stream));
-    DVS_HIP(ctx, hipMemcpyAsync(d_coff.p, coff.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    DVS_HIP(ctx, hipMemsetAsync(d_lens.p, 0, nseq * 4, ctx->stream));
-    DVS_HIP(ctx, hipMemsetAsync(d_sk.p, 0, size_t(nseq) * s * 4, ctx->stream));
+    // (host vectors are the sources of asynchronous copies: the stream is drained before this function returns on
+    // every path -- the round loop below ends each round with a synchronisation -- except the early error
+    // returns, which drain it themselves)
+    hipError_t ue = hipMemcpyAsync(d_off.p, offsets, (size_t(nseq) + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (ue == hipSuccess) ue = hipMemcpyAsync(d_tpre.p, tpre.data(), (size_t(nseq) + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (ue == hipSuccess) ue = hipMemcpyAsync(d_cap.p, cap.data(), size_t(nseq) * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (ue == hipSuccess) ue = hipMemcpyAsync(d_coff.p, coff.data(), (size_t(nseq) + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (ue == hipSuccess) ue = hipMemsetAsync(d_lens.p, 0, size_t(nseq) * 4, ctx->stream);
+    if (ue == hipSuccess) ue = hipMemsetAsync(d_sk.p, 0, size_t(nseq) * s * 4, ctx->stream);
+    if (ue == hipSuccess && n_tiles) {
+        hipLaunchKernelGGL(mash_tiles_kernel, dim3(uint32_t((n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, d_off.as<uint64_t>(),
+                           d_tpre.as<uint64_t>(), nseq, k, n_tiles, d_tiles.as<MTile>());
+        ue = hipGetLastError();
+    }
+    if (ue != hipSuccess) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return dvs_hip_fail(ctx, ue, "sketch set-up");
+    }
 
     std::vector<uint8_t> active(nseq, 1);
     std::vector<uint32_t> status(nseq, 0), lens(nseq, 0);
@@ -784,10 +818,10 @@ static int mash_sketch_view(dvs_ctx *ctx, const dvs_seq_view &sv, const uint64_t
                 if (frac * MASH_TILE > 512.0L) small = false;
             }
             // (sixteen workgroups' worth of tiles per CU at most: every workgroup loops over its share)
-            const uint32_t dna_grid = uint32_t(std::min<size_t>(tiles.size(), size_t(ctx->n_cu) * 16));
+            const uint32_t dna_grid = uint32_t(std::min<size_t>(size_t(n_tiles), size_t(ctx->n_cu) * 16));
 #define DVS_LAUNCH_DNA(K16, TBLW, PKD)                                                                         \
     hipLaunchKernelGGL((hash_filter_dna_kernel<K16, TBLW, PKD>), dim3(dna_grid), dim3(MASH_THREADS), 0, \
-                       ctx->stream, d_seqs, d_pmask, nbytes, d_tiles.as<MTile>(), uint32_t(tiles.size()), k, mash_canonical, d_lo.as<long long>(), \
+                       ctx->stream, d_seqs, d_pmask, nbytes, d_tiles.as<MTile>(), uint32_t(n_tiles), k, mash_canonical, d_lo.as<long long>(), \
                        d_hi.as<uint32_t>(), d_active.as<uint8_t>(), d_cand.as<uint32_t>(), d_coff.as<uint64_t>(), \
                        d_cap.as<uint32_t>(), d_cnt.as<uint32_t>())
 #define DVS_LAUNCH_DNA_ANY(PKD)                                  \
@@ -802,7 +836,7 @@ static int mash_sketch_view(dvs_ctx *ctx, const dvs_seq_view &sv, const uint64_t
 #undef DVS_LAUNCH_DNA_ANY
 #undef DVS_LAUNCH_DNA
         } else
-            hipLaunchKernelGGL(hash_filter_kernel, dim3(uint32_t(tiles.size())), dim3(MASH_THREADS), 0,
+            hipLaunchKernelGGL(hash_filter_kernel, dim3(uint32_t(n_tiles)), dim3(MASH_THREADS), 0,
                                ctx->stream, d_seqs, d_tiles.as<MTile>(), k, num_states, mash_canonical,
                                d_lo.as<long long>(), d_hi.as<uint32_t>(), d_active.as<uint8_t>(),
                                d_cand.as<uint32_t>(), d_coff.as<uint64_t>(), d_cap.as<uint32_t>(),
@@ -920,6 +954,7 @@ struct dvs_sketches {
     dvs_ctx *ctx = nullptr;
     uint32_t nseq = 0, stride = 0;
     uint32_t *d_sk = nullptr, *d_lens = nullptr;
+    bool borrowed = false;  // dvs_sketches_from_device: the caller's buffers, not handed back to the cache
 };
 
 extern "C" int dvs_sketches_build(dvs_ctx *ctx, const uint8_t *seqs, int seqs_on_device, const uint64_t *offsets,
@@ -977,8 +1012,10 @@ extern "C" int dvs_sketches_build_packed(dvs_ctx *ctx, const dvs_packed *p, cons
 
 extern "C" void dvs_sketches_destroy(dvs_sketches *sk) {
     if (!sk) return;
-    dvs_dev_free(sk->ctx, sk->d_sk);
-    dvs_dev_free(sk->ctx, sk->d_lens);
+    if (!sk->borrowed) {
+        dvs_dev_free(sk->ctx, sk->d_sk);
+        dvs_dev_free(sk->ctx, sk->d_lens);
+    }
     dvs_ctx_release(sk->ctx);
     delete sk;
 }
@@ -1049,6 +1086,61 @@ extern "C" int dvs_sketches_distances(dvs_ctx *ctx, const dvs_sketches *sk, uint
     if (!sk->d_sk) return dvs_set_error(ctx, DVS_ERR_ZERODIV, "division by zero");  // every sketch empty
     return mash_pairs_device(ctx, sk->d_sk, sk->d_lens, sk->nseq, sk->stride, k, sketch_size, row_start, row_stride,
                              symmetric, dist);
+}
+
+// ---- the sharded ctree (diverse_seq/cluster.py:607-644) without a trip through the host: sketches gathered from the
+// other ranks sit in a device buffer of the caller's (an all_gather's output), the strided rows of the lower triangle
+// go into a device matrix of the caller's (an all_reduce's input).
+extern "C" int dvs_sketches_from_device(dvs_ctx *ctx, const uint32_t *d_sketches, const uint32_t *d_lens, uint32_t nseq,
+                                        uint32_t stride, dvs_sketches **out) {
+    if (!ctx || !out || (nseq && (!d_lens || (stride && !d_sketches)))) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    dvs_sketches *sk = new dvs_sketches();
+    sk->ctx = ctx;
+    sk->nseq = nseq;
+    sk->stride = stride;
+    sk->d_sk = const_cast<uint32_t *>(d_sketches);
+    sk->d_lens = const_cast<uint32_t *>(d_lens);
+    sk->borrowed = true;
+    dvs_ctx_retain(ctx);
+    *out = sk;
+    return DVS_OK;
+}
+
+extern "C" int dvs_sketches_copy_to_device(dvs_ctx *ctx, const dvs_sketches *sk, uint32_t *d_dst, uint32_t dst_stride,
+                                           uint32_t *d_dst_lens) {
+    if (!ctx || !sk || !d_dst || !d_dst_lens) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (dst_stride < sk->stride) return dvs_set_error(ctx, DVS_ERR_VALUE, "destination stride %u < sketch stride %u", dst_stride, sk->stride);
+    if (!sk->nseq) return DVS_OK;
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    if (!sk->d_sk) {  // (sketch_size 0: every sketch empty)
+        DVS_HIP(ctx, hipMemsetAsync(d_dst_lens, 0, size_t(sk->nseq) * 4, ctx->stream));
+        return DVS_OK;
+    }
+    DVS_HIP(ctx, hipMemcpy2DAsync(d_dst, size_t(dst_stride) * 4, sk->d_sk, size_t(sk->stride) * 4, size_t(sk->stride) * 4, sk->nseq,
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+    DVS_HIP(ctx, hipMemcpyAsync(d_dst_lens, sk->d_lens, size_t(sk->nseq) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return DVS_OK;
+}
+
+// enqueued on the context's stream, nothing waited for: d_dist[nseq x nseq] receives the visited cells (the others keep
+// what they hold), *d_zerodiv is set when a visited pair has two empty sketches (distance.py:283)
+extern "C" int dvs_sketches_distances_device(dvs_ctx *ctx, const dvs_sketches *sk, uint32_t k, uint32_t sketch_size,
+                                             uint32_t row_start, uint32_t row_stride, int symmetric, double *d_dist,
+                                             uint32_t *d_zerodiv) {
+    if (!ctx || !sk || !d_dist || !d_zerodiv) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (sk->nseq < 2 || row_start >= sk->nseq) return DVS_OK;
+    if (row_stride == 0) row_stride = 1;
+    if (k == 0) return dvs_set_error(ctx, DVS_ERR_ZERODIV, "float division by zero");
+    if (!sk->d_sk) return dvs_set_error(ctx, DVS_ERR_ZERODIV, "division by zero");
+    DVS_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t nseq = sk->nseq;
+    const uint32_t nrows = (nseq - 1 - row_start) / row_stride + 1;
+    const dim3 grid(nrows, (nseq + PAIR_THREADS - 1) / PAIR_THREADS);
+    const uint32_t row_lds = std::min(sk->stride, PAIR_ROW_LDS);
+    hipLaunchKernelGGL(mash_pairs_kernel, grid, dim3(PAIR_THREADS), (row_lds + 4) * 4, ctx->stream, sk->d_sk, sk->d_lens, nseq, k,
+                       sketch_size, sk->stride, row_start, row_stride, symmetric, row_lds, d_dist, d_zerodiv);
+    DVS_HIP(ctx, hipGetLastError());
+    return DVS_OK;
 }
 
 extern "C" int dvs_mash_distances(dvs_ctx *ctx, const uint32_t *sketches, uint32_t sketch_stride,

@@ -1314,6 +1314,16 @@ static int sel_run_loop(dvs_ctx *ctx, dvs_select *s, const T *mat, bool first_un
                                                 (double(t7[b]) - double(tg[2])) / 100.0, late[i].first);
                                     }
                                 }
+                                {   // when the speculative jobs were handed over (mailboxes: stored), relative to the release
+                                    std::vector<double> sp;
+                                    for (uint32_t b = 0; b + 2 < G; b++)
+                                        if (t7[b] && t4[b] > tg[2]) sp.push_back((double(t7[b]) - double(tg[2])) / 100.0);
+                                    if (!sp.empty()) {
+                                        srt(sp);
+                                        fprintf(stderr, "[dvs persist trace] window %d: speculative jobs handed over %.2f / %.2f / %.2f / %.2f us after the release was stored "
+                                                "(min/median/90%%/max over %zu workgroups; negative: before)\n", w_ * 12 + 12, sp.front(), q_(sp, 0.5), q_(sp, 0.9), sp.back(), sp.size());
+                                    }
+                                }
                                 srt(pub); srt(tot); srt(end_);
                                 fprintf(stderr, "[dvs persist trace] window %d, its accept (us after the release was stored; min/median/max): job published %.2f / %.2f / %.2f, "
                                         "totals read %.2f / %.2f / %.2f, rebuild done %.2f / %.2f / %.2f\n", w_ * 12 + 12, pub.front(), q_(pub, 0.5), pub.back(),

@@ -136,6 +136,34 @@ class Sketches:
         self.ctx.check(self.ctx._L.dvs_sketches_get(self.ctx._h, self._h, _lib.ptr(sk, C.c_uint32), _lib.ptr(lens, C.c_uint32)))
         return sk, lens
 
+    @classmethod
+    def from_device(cls, ctx: engine.Context, sk_ptr: int, lens_ptr: int, n: int, stride: int, k: int,
+                    sketch_size: int, keep=None) -> "Sketches":
+        """sketches that already sit in HBM (uint32 [n, stride] ascending, uint32 [n] lengths) -- e.g. an
+        all_gather's output -- wrapped without a copy; `keep`: whatever owns the two buffers, kept alive beside the
+        handle"""
+        self = cls.__new__(cls)
+        self.ctx, self.n, self.k, self.sketch_size, self.stride = ctx, int(n), k, int(sketch_size), int(stride)
+        h = C.c_void_p()
+        ctx.check(ctx._L.dvs_sketches_from_device(ctx._h, C.c_void_p(sk_ptr), C.c_void_p(lens_ptr), self.n, self.stride,
+                                                  C.byref(h)))
+        self._h, self._source = h, keep
+        return self
+
+    def copy_to_device(self, dst_ptr: int, dst_stride: int, dst_lens_ptr: int):
+        """this batch's sketches into a caller's device buffer whose rows are dst_stride words apart (a collective's
+        send buffer); enqueued on the context's stream"""
+        self.ctx.check(self.ctx._L.dvs_sketches_copy_to_device(self.ctx._h, self._h, C.c_void_p(dst_ptr), int(dst_stride),
+                                                               C.c_void_p(dst_lens_ptr)))
+
+    def distances_device(self, dist_ptr: int, zerodiv_ptr: int, *, row_start: int = 0, row_stride: int = 1,
+                         symmetric: bool = True):
+        """the visited cells into a device matrix (float64 [n, n]) of the caller's; enqueued, not waited for;
+        the uint32 at zerodiv_ptr is set where `distances` would raise ZeroDivisionError"""
+        self.ctx.check(self.ctx._L.dvs_sketches_distances_device(self.ctx._h, self._h, self.k, min(self.sketch_size, _U32_MAX),
+                                                                 row_start, row_stride, int(symmetric), C.c_void_p(dist_ptr),
+                                                                 C.c_void_p(zerodiv_ptr)))
+
     def distances(self, *, row_start: int = 0, row_stride: int = 1, symmetric: bool = True,
                   out: np.ndarray | None = None) -> np.ndarray:
         if out is not None and (not isinstance(out, np.ndarray) or out.shape != (self.n, self.n)

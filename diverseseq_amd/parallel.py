@@ -340,17 +340,23 @@ def max_exact(ctx, matrix, order: np.ndarray, min_size: int, max_size: int, stat
 # of the N x N f64 assembles it; symmetrise as cluster.py:294 does (D + D^T - diag).
 def mash_distances_sharded(seqs, k: int, sketch_size: int, rank: int, world: int, device, *,
                            num_states: int = 4, mash_canonical: bool = False,
-                           sketcher=None, pair_rows=None) -> np.ndarray:
+                           sketcher=None, pair_rows=None, collectives=None) -> np.ndarray:
     """`seqs`: the full list (every rank sees the store, as the reference's workers do); only
     this rank's chunk is sketched here.  `sketcher(chunk) -> (uint32 [m, stride], uint32 [m])`
     and `pair_rows(sk, lens, row_start, row_stride) -> N x N lower-triangle rows` default to the
-    HIP kernels (dvs_mash_sketch / dvs_mash_distances); the CPU tests inject the oracle."""
+    HIP kernels (dvs_mash_sketch / dvs_mash_distances); the CPU tests inject the oracle.  On a GPU with the
+    defaults everything stays in HBM (`_mash_distances_sharded_device`); `collectives` = (all_gather_into_tensor,
+    all_reduce) replaces torch.distributed's there (the GPU test of two ranks sharing one card runs over gloo,
+    which has no all_gather of device tensors)."""
     import torch
     import torch.distributed as dist
 
     from . import distance
 
     n = len(seqs)
+    if sketcher is None and pair_rows is None and torch.device(device).type == "cuda":
+        return _mash_distances_sharded_device(seqs, k, sketch_size, rank, world, device, num_states, mash_canonical,
+                                              collectives)
     if sketcher is None:
         def sketcher(chunk):
             return distance.sketch_batch(chunk, k, sketch_size, num_states, mash_canonical)
@@ -384,3 +390,62 @@ def mash_distances_sharded(seqs, k: int, sketch_size: int, rank: int, world: int
     dist.all_reduce(t_d, op=dist.ReduceOp.SUM)  # every entry is written by exactly one rank
     lower = t_d.cpu().numpy()
     return lower + lower.T - np.diag(np.diag(lower))
+
+
+def _mash_distances_sharded_device(seqs, k, sketch_size, rank, world, device, num_states, mash_canonical,
+                                   collectives=None) -> np.ndarray:
+    """The same on the HIP kernels with nothing but the result crossing PCIe: this rank's sketches are copied
+    device-to-device into the all_gather's send buffer, the gathered N sketches are read in place by the pair kernel
+    (rows rank, rank + world, ... of the lower triangle into a device matrix), the SUM all_reduce assembles it and the
+    symmetrisation (cluster.py:294) runs on the device; the N x N matrix is copied out once, at the end."""
+    import torch
+    import torch.distributed as dist
+
+    from . import distance, engine
+
+    n = len(seqs)
+    dev = torch.device(device)
+    ctx = engine.default_context()
+    gather, reduce_ = collectives if collectives else (dist.all_gather_into_tensor, dist.all_reduce)
+    longest = max((len(s) for s in seqs), default=0) - k + 1
+    stride = max(1, min(int(sketch_size), max(0, longest)))  # same on every rank
+    bounds = chunk_bounds(n, world)
+    lo, hi = bounds[rank]
+    cap = max(1, max(e - s for s, e in bounds))
+    t_sk = torch.zeros((cap, stride), dtype=torch.int32, device=dev)
+    t_len = torch.zeros((cap,), dtype=torch.int32, device=dev)
+    own = None
+    if hi > lo and sketch_size:
+        own = distance.Sketches(seqs[lo:hi], k, sketch_size, num_states, mash_canonical, ctx=ctx)
+        torch.cuda.current_stream(dev).synchronize()  # (the send buffers' zero fill, on torch's stream)
+        if own.stride:
+            own.copy_to_device(t_sk.data_ptr(), stride, t_len.data_ptr())
+        ctx.sync()  # (the library's stream -> torch's stream: the collective reads the buffers)
+    all_sk = torch.empty((world * cap, stride), dtype=torch.int32, device=dev)
+    all_len = torch.empty((world * cap,), dtype=torch.int32, device=dev)
+    gather(all_sk, t_sk)
+    gather(all_len, t_len)
+    if all(e - s == cap for s, e in bounds):  # (equal chunks: the gathered rows ARE the N sketches, in order)
+        sk_all, len_all = all_sk, all_len
+    else:  # the real rows of every rank's padded block, gathered on the device
+        idx = torch.tensor([r * cap + i for r, (s, e) in enumerate(bounds) for i in range(e - s)], dtype=torch.long, device=dev)
+        sk_all, len_all = all_sk.index_select(0, idx).contiguous(), all_len.index_select(0, idx).contiguous()
+    t_d = torch.zeros((n, n), dtype=torch.float64, device=dev)
+    t_flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+    torch.cuda.current_stream(dev).synchronize()  # (torch's stream -> the library's)
+    if n >= 2:
+        gathered = distance.Sketches.from_device(ctx, sk_all.data_ptr(), len_all.data_ptr(), n, stride, k, sketch_size,
+                                                 keep=(sk_all, len_all))
+        try:
+            gathered.distances_device(t_d.data_ptr(), t_flag.data_ptr(), row_start=rank, row_stride=world, symmetric=False)
+            ctx.sync()
+        finally:
+            gathered.close()
+    if own is not None:
+        own.close()
+    reduce_(t_d, op=dist.ReduceOp.SUM)  # every entry is written by exactly one rank
+    reduce_(t_flag, op=dist.ReduceOp.MAX)
+    if int(t_flag.item()):
+        raise ZeroDivisionError("division by zero")  # two empty sketches (distance.py:283)
+    full = t_d + t_d.T - torch.diag(torch.diagonal(t_d))
+    return full.cpu().numpy()

@@ -340,6 +340,19 @@ const void *dvs_sketches_dev(const dvs_sketches *sk);      /* uint32 [nseq x ske
 const void *dvs_sketches_dev_lens(const dvs_sketches *sk); /* uint32 [nseq] */
 int dvs_sketches_distances(dvs_ctx *ctx, const dvs_sketches *sk, uint32_t k, uint32_t sketch_size,
                            uint32_t row_start, uint32_t row_stride, int symmetric, double *dist);
+/* The distance stage of the sharded ctree (`dvs_par_ctree`, diverse_seq/cluster.py:607-644: worker g takes rows g,
+ * g + G, ... of the lower triangle of ALL sketches) with everything left in HBM: a rank's own sketches are copied
+ * into its send buffer (dvs_sketches_copy_to_device: rows dst_stride words apart), the gathered N sketches are
+ * wrapped without a copy (dvs_sketches_from_device: the caller's buffers, which must outlive the handle) and the
+ * strided rows are written into a device matrix (dvs_sketches_distances_device: enqueued on the context's stream and
+ * not waited for; *d_zerodiv is set where dvs_sketches_distances would return DVS_ERR_ZERODIV). */
+int dvs_sketches_from_device(dvs_ctx *ctx, const uint32_t *d_sketches, const uint32_t *d_lens, uint32_t nseq,
+                             uint32_t stride, dvs_sketches **out);
+int dvs_sketches_copy_to_device(dvs_ctx *ctx, const dvs_sketches *sk, uint32_t *d_dst, uint32_t dst_stride,
+                                uint32_t *d_dst_lens);
+int dvs_sketches_distances_device(dvs_ctx *ctx, const dvs_sketches *sk, uint32_t k, uint32_t sketch_size,
+                                  uint32_t row_start, uint32_t row_stride, int symmetric, double *d_dist,
+                                  uint32_t *d_zerodiv);
 /* euclidean_distances (diverse_seq/distance.py:294-336): ||f_i - f_j||_2 over
  * the rows of m, full symmetric nrows x nrows matrix */
 int dvs_euclidean_distances(dvs_ctx *ctx, const dvs_matrix *m, double *dist);
