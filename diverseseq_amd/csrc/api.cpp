@@ -130,6 +130,8 @@ void dvs_knobs_from_env(dvs_knobs *k) {
     const char *tk = getenv("DVS_TEST_KNOBS");
     k->test_persist_fake_error = tk && strstr(tk, "fake_persist_error") != nullptr;
     if (const char *lt = tk ? strstr(tk, "long_tile_") : nullptr) k->test_long_tile = uint32_t(strtoul(lt + 10, nullptr, 10));
+    k->test_rowlog_ring = 0;
+    if (const char *rr = tk ? strstr(tk, "rowlog_ring_") : nullptr) k->test_rowlog_ring = uint32_t(strtoul(rr + 12, nullptr, 10));
 }
 
 extern "C" {

@@ -44,6 +44,9 @@ struct dvs_knobs {
     // test-only (DVS_TEST_KNOBS=long_tile_<n>): long rows are cut into tiles of n windows whatever the input's size
     // (the tiles only grow beyond 32768 windows for inputs of 2^27 bases and more: kmer_hist.hip dvs_hist_prepare)
     uint32_t test_long_tile = 0;
+    // test-only (DVS_TEST_KNOBS=rowlog_ring_<n>): the stepwise selections' device-side ring of accepted rows holds n rows
+    // (>= 4), so that a few dozen accepts wrap it several times before a tie is arbitrated
+    uint32_t test_rowlog_ring = 0;
 };
 void dvs_knobs_from_env(dvs_knobs *k);
 

@@ -351,6 +351,18 @@ int fetch_dev_row(dvs_ctx *ctx, const dvs_select *s, uint64_t p, const double *d
     return DVS_OK;
 }
 
+// ... and from a frequency row in host memory (the stepwise selections' log of accepted rows)
+int fetch_host_row(dvs_ctx *ctx, const dvs_select *s, uint64_t p, const double *h_row, ExactSet &scratch, ExactRow &out) {
+    const uint64_t B = s->mat->nbins;
+    const uint32_t row = s->h_order.empty() ? uint32_t(p) : s->h_order[p];
+    out.pos = p;
+    out.label = row == DVS_ROW_REMOTE ? 0xFFFFFFFFu : (s->h_labels.empty() ? row : s->h_labels[p]);
+    out.f.resize(B);
+    std::memcpy(out.f.data(), h_row, B * sizeof(double));
+    if (!scratch.entropy(out.f.data(), B, out.H)) return dvs_set_error(ctx, DVS_ERR_VALUE, "%s", scratch.err.c_str());
+    return DVS_OK;
+}
+
 // The decision goes to the control block with blocking copies AND a device synchronisation behind them: a
 // small copy from pageable memory returns once the bytes are staged, not once they are in device memory,
 // and the context's stream is a non-blocking one -- without the wait the kernels queued next saw, one time in
@@ -404,10 +416,11 @@ int dvs_select_arbitrate(dvs_ctx *ctx, dvs_select *s) {
             ExactRow r;
             if (stepwise) {
                 const uint32_t at = a.replayed + i;
-                if (at >= s->dev.rowlog_cap)
-                    return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "tie arbitration in the stepwise mode: more than %u "
-                                         "accepted events, the row log is full", s->dev.rowlog_cap);
-                rc = fetch_dev_row(ctx, s, pos[i], s->dev.rowlog + uint64_t(at) * B, set, r);
+                // (the whole log is on the host: dvs_select_step_poll drained the device ring before it called here)
+                if (uint64_t(at) >= s->rowlog_have)
+                    return dvs_set_error(ctx, DVS_ERR_RUNTIME, "tie arbitration in the stepwise mode: event %u is not in the "
+                                         "accepted rows' log (%llu rows)", at, (unsigned long long)s->rowlog_have);
+                rc = fetch_host_row(ctx, s, pos[i], s->h_rowlog.data() + uint64_t(at) * B, set, r);
             } else {
                 rc = fetch_row(ctx, s, pos[i], set, r);
             }

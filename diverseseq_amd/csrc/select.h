@@ -77,7 +77,8 @@ struct SelDev {
     // the earliest event itself and takes the candidate from there instead of the local matrix
     const double *gather_all = nullptr;
     uint32_t gather_world = 0;
-    // ... and the frequency row of every accepted event, in event-log order (rowlog_cap rows): what the
+    // ... and the frequency row of every accepted event, in event-log order, as a RING of rowlog_cap rows that the
+    // host drains at every poll (dvs_select::h_rowlog holds the whole log): what the
     // tie arbiter replays from when the rows themselves live on other ranks
     double *rowlog = nullptr;
     uint32_t rowlog_cap = 0;
@@ -139,6 +140,10 @@ struct dvs_select {
     uint64_t scan_launches = 0;
     uint32_t n_arbitrated = 0;
     double arbiter_ms = 0.0;    // host wall clock inside dvs_select_arbitrate
+    // stepwise selections: the accepted rows' log on the host (drained from the device ring by dvs_select_step_poll)
+    std::vector<double> h_rowlog;
+    uint64_t rowlog_have = 0;       // rows of it that are on the host
+    uint32_t steps_since_poll = 0;  // dvs_select_step_apply calls since the last poll (bounded by the ring)
     void *arbiter = nullptr;  // ExactSet*, created on first use
 };
 

@@ -406,7 +406,7 @@ __device__ void resolve_body(SelDev &d, const T *__restrict__ mat, double *scrat
         const uint32_t s = d.ord[li];
         double *mrow = d.M + uint64_t(s) * d.B;
         const uint32_t log_at = ctl->n_logged;  // (read by every thread before thread 0 moves it on, below)
-        double *logrow = (d.rowlog && log_at < d.rowlog_cap) ? d.rowlog + uint64_t(log_at) * d.B : nullptr;
+        double *logrow = d.rowlog ? d.rowlog + uint64_t(log_at % d.rowlog_cap) * d.B : nullptr;  // (a ring: the host drains it at every poll)
         __syncthreads();
         if (tid == 0) ctl->s_is_resum = 0;
         for (uint64_t i = tid; i < d.B; i += WIDE) {
@@ -720,9 +720,9 @@ __device__ void finalize_body(SelDev &d, double *scratch, int &s_go) {
     const int go = s_go;
     if (go < 0) return;
     if (go == 1) {
-        if (kind == 2 && d.rowlog && ctl->n_logged && ctl->n_logged - 1 < d.rowlog_cap) {  // the kept push's row
+        if (kind == 2 && d.rowlog && ctl->n_logged) {  // the kept push's row
             const double *src = d.M + uint64_t(n - 1) * d.B;
-            double *dst = d.rowlog + uint64_t(ctl->n_logged - 1) * d.B;
+            double *dst = d.rowlog + uint64_t((ctl->n_logged - 1) % d.rowlog_cap) * d.B;
             for (uint64_t i = tid; i < d.B; i += WIDE) dst[i] = src[i];
         }
         for (uint32_t r = tid; r < n; r += WIDE) d.mDelta[r] = d.dtmp[r];
@@ -1729,23 +1729,15 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     SEL_ALLOC(d.evlog_pos, size_t(npos - n_seed + 2) * 8);
     SEL_ALLOC(d.evlog_kind, size_t(npos - n_seed + 2) * 4);
     if (s->params.flags & DVS_SELECT_STEPWISE) {
-        // the arbiter's row log (rows of accepted candidates may live on other ranks), sized from what a
-        // selection of this shape accepts: a greedy stream over N positions with a set of n takes about
-        // n (1 + ln(N / n)) events (position i is accepted with probability ~ n / i); four times that plus
-        // slack, never more than the stream has positions, at most 2 GiB (a log that still fills up ends
-        // the arbitration with DVS_ERR_UNSUPPORTED, exact_set.cpp)
-        const uint64_t n_eff = std::max<uint64_t>(1, params->mode == DVS_MODE_MAX
-                                                         ? std::min<uint64_t>(std::max<uint64_t>(params->max_size, n_seed), npos)
-                                                         : n_seed);
-        const double expect = double(n_eff) * (1.0 + std::log(std::max(1.0, double(npos) / double(n_eff))));
-        uint64_t want = uint64_t(4.0 * expect) + 64;
-        // ... but that expectation is a randomly ordered stream's: one ordered by rising divergence accepts far more
-        // (10 k sequences, n = 10: thousands, not 380), so the log is never smaller than 256 MB worth of rows
-        want = std::max<uint64_t>(want, (uint64_t(256) << 20) / (B * 8));
-        want = std::min<uint64_t>(want, std::max<uint64_t>(64, (uint64_t(2) << 30) / (B * 8)));
-        want = std::min<uint64_t>(want, npos - n_seed + 2);
-        d.rowlog_cap = uint32_t(want);
-        SEL_ALLOC(d.rowlog, size_t(want) * B * 8);
+        // The arbiter's row log (rows of accepted candidates may live on other ranks): the frequency row of every
+        // accepted event in event-log order.  On the device it is a RING of `ring` rows that dvs_select_step_poll
+        // drains into host memory (s->h_rowlog) at every look -- a step logs at most one row, and dvs_select_step_apply
+        // refuses to run more than `ring` steps behind the last poll -- so the log itself has no cap: a stream ordered
+        // by rising divergence accepts thousands of rows where a shuffled one accepts n (1 + ln(N / n)).
+        uint64_t ring = std::min<uint64_t>(256, std::max<uint64_t>(16, (uint64_t(256) << 20) / (B * 8)));
+        if (ctx->knobs.test_rowlog_ring >= 4) ring = ctx->knobs.test_rowlog_ring;  // (tests: a ring that wraps after a few accepts)
+        d.rowlog_cap = uint32_t(ring);
+        SEL_ALLOC(d.rowlog, size_t(ring) * B * 8);
     }
     if (order) {
         SEL_ALLOC(d.order, size_t(npos) * 4);
@@ -2131,6 +2123,9 @@ extern "C" int dvs_select_step_pack(dvs_ctx *ctx, dvs_select *s, double *d_slot)
 
 extern "C" int dvs_select_step_apply(dvs_ctx *ctx, dvs_select *s, const double *d_all, uint32_t world) {
     if (!ctx || !s || !d_all || !world) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (s->dev.rowlog && ++s->steps_since_poll > s->dev.rowlog_cap)
+        return dvs_set_error(ctx, DVS_ERR_VALUE, "dvs_select_step_poll must be called at least every %u steps (it drains the "
+                             "accepted rows' log)", s->dev.rowlog_cap);
     s->dev.gather_all = d_all;
     s->dev.gather_world = world;
     dvs_mat_dispatch(s->mat, [&](auto *mp) {
@@ -2147,6 +2142,21 @@ extern "C" int dvs_select_step_poll(dvs_ctx *ctx, dvs_select *s, uint32_t *statu
     if (rc) return rc;
     if (status) *status = s->h_ctl->status;
     if (cursor) *cursor = s->h_ctl->cursor;
+    if (s->dev.rowlog) {  // the rows logged since the last look: ring -> host (the stream is idle: sel_poll waited)
+        const uint64_t B = s->dev.B, ring = s->dev.rowlog_cap, logged = s->h_ctl->n_logged;
+        if (logged - s->rowlog_have > ring)
+            return dvs_set_error(ctx, DVS_ERR_RUNTIME, "the accepted rows' log was overrun (%llu rows since the last poll, ring of %llu)",
+                                 (unsigned long long)(logged - s->rowlog_have), (unsigned long long)ring);
+        s->h_rowlog.resize(size_t(logged) * B);
+        while (s->rowlog_have < logged) {
+            const uint64_t at = s->rowlog_have % ring;
+            const uint64_t cnt = std::min<uint64_t>(logged - s->rowlog_have, ring - at);
+            DVS_HIP(ctx, hipMemcpy(s->h_rowlog.data() + s->rowlog_have * B, s->dev.rowlog + at * B, size_t(cnt) * B * 8,
+                                   hipMemcpyDeviceToHost));
+            s->rowlog_have += cnt;
+        }
+        s->steps_since_poll = 0;
+    }
     if (s->h_ctl->status == SEL_ARBITER) {
         // A decision inside the rounding band: every rank holds the same replicated state, the same row
         // log and the same pending candidate, so every rank's arbiter reaches the same verdict on its own

@@ -1370,3 +1370,42 @@ def test_large_sets_and_other_alphabets(ctx):
     tri = [rng.integers(0, 4, size=int(rng.integers(60, 300)), dtype=np.uint8) for _ in range(400)]
     mt = ctx.build_matrix(tri, 3, 3)
     _assert_selection(mt.nmost(8), oracle.nmost(tri, 8, 3, 3))
+
+
+def test_exact_mode_row_log_has_no_cap(ctx, monkeypatch):
+    """The stepwise (row-sharded) mode keeps the frequency row of every accepted event for the tie arbiter: a ring on
+    the device that dvs_select_step_poll drains into a host-side log without a cap.  With a ring of eight rows
+    (DVS_TEST_KNOBS=rowlog_ring_8) the degenerate stream's accepts wrap it many times before and between its
+    arbitrations: the oracle's answer, arbitrations > 0; and a driver that lets more than a ring's worth of steps pass
+    between two polls is refused, not left to a log with holes."""
+    import ctypes as C
+
+    import torch
+
+    from diverseseq_amd import _lib, engine, parallel
+
+    monkeypatch.setenv("DVS_TEST_KNOBS", "rowlog_ring_8")  # (the autouse fixture has every live context re-read its switches)
+    if True:
+        seqs = _degenerate_seqs()
+        n, k = 7, 3
+        dev = torch.device("cuda", 0)
+        _, order = parallel.shard_order(len(seqs), n, 0, 1, block=32)
+        m = ctx.build_matrix(seqs, k, 4)
+        sel = parallel.nmost_exact(ctx, m, order, n, dev, 1, window=256, poll_every=4)
+        s = sel.summary()
+        exp, acc = oracle.nmost_concat(*engine.concat(seqs), n, k, 4)
+        assert s.n_accepts == acc and acc > 3 * 8, (s.n_accepts, acc)  # (the ring went round several times)
+        assert s.n_arbitrated > 0
+        elab, edelta, _, _ = exp.members()
+        mem = sel.members(with_freqs=False)
+        assert mem.positions.tolist() == elab.tolist()
+        np.testing.assert_allclose(mem.delta_jsd, edelta, rtol=RTOL, atol=1e-13)
+        sel.close()
+        # too many steps between two polls: refused
+        sel = m.select(_lib.MODE_NMOST, n, order=order, window=256, flags=_lib.SELECT_STEPWISE)
+        stepper = parallel.HipStepper(ctx, sel, m.nbins, dev)
+        with pytest.raises(ValueError, match="dvs_select_step_poll must be called at least every 8 steps"):
+            for _ in range(9):
+                stepper.apply(stepper.pack(), 1)
+        sel.close()
+        m.close()
