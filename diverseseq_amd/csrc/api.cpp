@@ -118,6 +118,7 @@ void dvs_knobs_from_env(dvs_knobs *k) {
     k->no_packed_upload = on("DVS_NO_PACKED_UPLOAD");
     k->cu_mask_set = on("HSA_CU_MASK") || on("ROC_GLOBAL_CU_MASK");
     k->no_persist = on("DVS_NO_PERSIST");
+    k->no_fast_step = on("DVS_NO_FAST_STEP");
     k->no_head_phase = on("DVS_NO_HEAD_PHASE");
     k->persist_no_seeded = on("DVS_PERSIST_NO_SEEDED");
     k->persist_no_small = on("DVS_PERSIST_NO_SMALL");

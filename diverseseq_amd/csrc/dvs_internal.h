@@ -29,6 +29,7 @@ struct dvs_knobs {
     bool no_packed_upload = false;    // DVS_NO_PACKED_UPLOAD: host sequences cross PCIe one byte per base
     bool cu_mask_set = false;         // HSA_CU_MASK / ROC_GLOBAL_CU_MASK present: the device reports CUs it will not give
     // selection engines (select.hip, persist.hip)
+    bool no_fast_step = false;        // DVS_NO_FAST_STEP: the stepwise (row-sharded) mode runs scan / resolve / leave-one-out / finalize per step, as rounds 1-4 did
     bool no_persist = false;          // DVS_NO_PERSIST: the multi-launch engine serves every selection
     bool no_head_phase = false;       // DVS_NO_HEAD_PHASE: no head phase on the CU-masked stream beside the histogram
     bool persist_no_seeded = false;   // DVS_PERSIST_NO_SEEDED: the set-up kernels build the initial set

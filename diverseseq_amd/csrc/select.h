@@ -140,6 +140,15 @@ struct dvs_select {
     uint64_t scan_launches = 0;
     uint32_t n_arbitrated = 0;
     double arbiter_ms = 0.0;    // host wall clock inside dvs_select_arbitrate
+    // stepwise selections, MODE_NMOST without labels: the fast step (select.hip fs_jobs_kernel / fs_step_kernel)
+    bool fast_step = false;
+    bool fs_need_scan = false;   // the next dvs_select_step_pack must scan first (selection start, behind an arbitration)
+    double *fs_slot = nullptr;   // the caller's slot of the last dvs_select_step_pack (the next step's kernel packs into it)
+    double *fs_packed = nullptr; // ... and the slot the last fs_step_kernel launch packed (nullptr: none)
+    double *d_jobres = nullptr;  // the leave-one-out jobs' sums of the current step
+    void *d_fsync = nullptr;     // FsSync
+    uint32_t fs_K = 1, fs_jobs = 0, fs_grid = 0;
+    size_t fs_lds = 0;
     // stepwise selections: the accepted rows' log on the host (drained from the device ring by dvs_select_step_poll)
     std::vector<double> h_rowlog;
     uint64_t rowlog_have = 0;       // rows of it that are on the host

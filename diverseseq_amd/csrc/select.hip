@@ -749,6 +749,819 @@ __device__ void finalize_body(SelDev &d, double *scratch, int &s_go) {
 }
 
 
+// ---- The stepwise (row-sharded) mode's FAST STEP (MODE_NMOST, no caller's labels): three launches per greedy step
+// instead of five, and no single-block kernel on the chain.
+//   fs_jobs_kernel   (n + 1) K workgroups: the gathered slots' earliest event is this step's event on every rank; each
+//                    workgroup works out one part of one leave-one-out job of the set WITH that candidate in place of the
+//                    lowest member (resolve_body's S update and loo_body's pass, bin for bin) -- the job of the whole
+//                    set also carries the candidate's own score -- and leaves its sums in jobres.  Nothing else is
+//                    written: whether the candidate is accepted at all is decided one launch later.
+//   fs_step_kernel   every workgroup takes the SAME decisions from the same sums (resolve's candidate test, finalize's
+//                    argmin, bands and statistics: identical code, identical bits), builds the next scan vector
+//                    (S' - lowest') / n in its own LDS and scans this rank's rows from the event + 1 to the FIRST local
+//                    event wherever it is -- no windows: a step is an event, and the kernel's end is the rendezvous.
+//                    The last workgroup scans nothing: it writes the state resolve_kernel / finalize_kernel would have
+//                    left (the kernels the arbiter re-enters with, get_members, the next step's jobs read it), and only
+//                    after every other workgroup has said -- one relaxed add to a monotonic counter, behind the loads
+//                    whose values it has consumed -- that it has read what it needs of the old one.
+//   pack_event_kernel  as before: the first local event into this rank's slot.
+// A decision inside a rounding band stops the step exactly where the old kernels would have stopped (same status,
+// stage, pending candidate, half-applied state): dvs_select_step_poll arbitrates and re-enters THEM; the fast step
+// resumes with a scan of its own.  Per step at world 1, n = 10, 4^6 bins: ~20 us against ~64.
+constexpr int FS_JOB_THREADS = 256;
+constexpr int FS_THREADS = 512;
+constexpr uint32_t FS_MAXJOBS = 2048;
+constexpr uint32_t FS_RES = 8;  // doubles per job: h, sum, min; the whole set's job: + the score's h, sum, min, clamp flag
+struct FsLine {  // a polled word on a line of its own
+    unsigned long long v;
+    unsigned long long pad[31];
+};
+struct FsSync {
+    // workgroups that have read the old state, all applied steps of the selection so far (monotonic); group g = blockIdx % 8
+    // adds to arrived[g] -- 512 additions to one word are performed one after the other at the memory side, ~5 us of them
+    FsLine arrived[8];
+    unsigned int steps;  // applied steps so far (written by the state-writing workgroup at the end of one, read at the start of the next)
+    unsigned int pad1[63];
+    // copies of the scan's event word, one per group: 4096 waves looking at ONE word before every row queue up at the
+    // memory side (the persistent engine's lesson, NOTES_r01_r04.md 4.2); the finder posts to all eight and to ctl->event_pos
+    FsLine hint[8];
+    // workgroups of the running launch that are through (the last one packs this rank's slot for the next exchange, and
+    // clears the word)
+    FsLine finished;
+};
+
+__device__ __forceinline__ bool fs_applies(const SelCtl *ctl, const SelDev &d) {
+    return ctl->status == SEL_RUN && ctl->ev_kind == 0 && ctl->forced == FORCE_NONE && ctl->mode == DVS_MODE_NMOST &&
+           d.labels == nullptr && ctl->size >= 2;
+}
+// the earliest event among the gathered slots ([pos, H, row] per rank; pos < 0: none) -- every thread, same answer
+__device__ __forceinline__ unsigned long long fs_pick(const SelDev &d, const double **slot_out) {
+    const uint64_t stride = d.B + 2;
+    int best = -1;
+    double bp = 0.0;
+    for (uint32_t r = 0; r < d.gather_world; r++) {
+        const double q = d.gather_all[uint64_t(r) * stride];
+        if (q >= 0.0 && (best < 0 || q < bp)) {
+            best = int(r);
+            bp = q;
+        }
+    }
+    *slot_out = d.gather_all + uint64_t(best < 0 ? 0 : best) * stride;
+    return best < 0 ? SEL_NONE : (unsigned long long)bp;
+}
+
+__global__ __launch_bounds__(FS_JOB_THREADS) void fs_jobs_kernel(SelDev d, double *__restrict__ jobres, uint32_t K, FsSync *sync) {
+    __shared__ double scratch[48];
+    SelCtl *ctl = d.ctl;
+    if (!fs_applies(ctl, d)) return;
+    const double *slot;
+    const unsigned long long p = fs_pick(d, &slot);
+    // (the event word and its copies are the NEXT scan's from here on: the step kernel behind this launch posts into them)
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->event_pos = SEL_NONE;
+    if (blockIdx.x == 0 && threadIdx.x < 8) sync->hint[threadIdx.x].v = SEL_NONE;
+    if (p == SEL_NONE) return;
+    const uint32_t n = ctl->size, li = ctl->lowest;
+    const uint32_t job = blockIdx.x, r = job / K, part = job % K;
+    if (r > n) return;
+    const double *low = d.M + uint64_t(d.ord[li]) * d.B;
+    const double *cand = slot + 2;
+    const double dn = double(n), div = dn - 1.0;
+    // member r of the NEW order (the lowest removed, the candidate appended): an old member, or the candidate
+    const double *mrow = (r + 1 < n) ? d.M + uint64_t(d.ord[r < li ? r : r + 1]) * d.B : cand;
+    Ent e, es;
+    int cl = 0;
+    for (uint64_t i = uint64_t(part) * FS_JOB_THREADS + threadIdx.x; i < d.B; i += uint64_t(K) * FS_JOB_THREADS) {
+        const double v = d.S[i] - low[i];
+        const double f = cand[i];
+        double vc = v;
+        if (vc <= DVS_EPS) vc = 0.0;  // drop_lowest's clamp (records.rs:100-105)
+        const double sp = vc + f;     // S' of the bin, as resolve_body leaves it
+        if (r == n) {
+            cl |= (v <= DVS_EPS && v != 0.0) ? 1 : 0;
+            es.add((v + f) / dn);  // the candidate's score (block_delta_jsd: no clamp, records.rs:78-81)
+            e.add(sp / dn);        // H(S' / n) (block_entropy_div)
+        } else {
+            double u = (sp - mrow[i]) / div;  // updated_mean_freqs, records.rs:276-286 (loo_body)
+            if (u <= DVS_EPS) u = 0.0;
+            e.add(u);
+        }
+    }
+    double h = e.h, mn = e.mn, sm = e.sum;
+    block_red3(h, mn, sm, scratch);
+    double hs = es.h, mns = es.mn, sms = es.sum;
+    int cl_any = 0;
+    if (r == n) {  // (block-uniform)
+        block_red3(hs, mns, sms, scratch);
+        cl_any = __syncthreads_or(cl);
+    }
+    if (threadIdx.x == 0) {
+        double *o = jobres + uint64_t(job) * FS_RES;
+        o[0] = h;
+        o[1] = sm;
+        o[2] = mn;
+        o[3] = hs;
+        o[4] = sms;
+        o[5] = mns;
+        o[6] = cl_any ? 1.0 : 0.0;
+    }
+}
+
+// ---- the scan of the fast step.  A wave a row, as everywhere; what differs from scan_rows_general:
+//  * count rows of 256-bin multiples take the all-f32 COARSE tier first (select_dev.h: a row farther than its proven band from
+//    the threshold is decided there, ~5 vector instructions a bin instead of ~17); what it cannot decide, and every other row
+//    form, takes the f32-log FAST tier and, inside that one's band, the f64 one;
+//  * the event word is polled through eight copies (FsSync::hint), and a finder posts to all of them;
+//  * for rows of FS_BURST bins (k = 6 DNA) the WHOLE row is requested at once (16 wave instructions of 512 B / 1 KiB in flight,
+//    one round trip a row instead of four), and a wave's FIRST row is requested at the top of the kernel, before the step's
+//    decisions are known: the cursor those leave is the event's position + 1 whatever they are, so the matrix streams in
+//    while the decisions and the scan vector are made.
+constexpr uint64_t FS_BURST = 4096;
+// (raw[j] holds chunk (j + rot) % 16 of the row: waves that start together -- all of them, at the top of every step -- do not
+// walk their rows in step)
+template <typename T>
+__device__ __forceinline__ void fs_row_issue(const SelDev &d, const T *__restrict__ mat, uint64_t p, uint32_t lane, uint32_t rot,
+                                             Raw4<T> (&raw)[16], uint32_t &row, uint32_t &tot, double &hrow) {
+    row = d.order ? d.order[p] : uint32_t(p);
+    tot = 0;
+    hrow = 0.0;
+    if (row == DVS_ROW_REMOTE) return;  // another rank scores this position
+    tot = d.totals[row];
+    hrow = d.rowH[row];
+    const T *rp = mat + uint64_t(row) * FS_BURST;
+#pragma unroll
+    for (int j = 0; j < 16; j++) raw[j].load(rp + ((j + rot) & 15u) * 256 + lane * 4);
+}
+struct FsThr {
+    double c_lo, c_hi;  // COARSE: sure reject below, sure event above
+};
+// true: the row's score may clear the threshold (an event, for the next step's exact evaluation to decide)
+template <typename T>
+__device__ __forceinline__ bool fs_row_score(const Raw4<T> (&raw)[16], uint32_t row, uint32_t tot, double hrow,
+                                             const T *__restrict__ mat, const double *sb, const float *slf, const ScanState &st,
+                                             const FsThr &ft, uint32_t lane, uint32_t rot, uint32_t &nprecise) {
+    const double rinv = 1.0 / (double(tot) * st.dsize);
+    const double mean_entropy = (st.he_base + hrow) / st.dsize;
+    const float rtn = float(rinv);
+    const dvs_f2 r2 = {rtn, rtn};
+    double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        const uint32_t i0 = ((j + rot) & 15u) * 256 + lane * 4, i1 = ((j + 1 + rot) & 15u) * 256 + lane * 4;
+        c0 += double(coarse4(raw[j].c, *reinterpret_cast<const float4 *>(slf + i0), r2));
+        c1 += double(coarse4(raw[j + 1].c, *reinterpret_cast<const float4 *>(slf + i1), r2));
+    }
+    const double jf0 = -dvs_wave_sum(c0 + c1) - mean_entropy;
+    if (!(jf0 > ft.c_lo)) return false;  // (NaN: a negative bin, rejected as the reference does)
+    if (jf0 > ft.c_hi) return true;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, xmin = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t i = ((j + rot) & 15u) * 256 + lane * 4;
+        double v0, v1, v2, v3;
+        raw[j].get(v0, v1, v2, v3);
+        const double2 b01 = *reinterpret_cast<const double2 *>(sb + i);
+        const double2 b23 = *reinterpret_cast<const double2 *>(sb + i + 2);
+        fast4(b01, b23, v0, v1, v2, v3, rinv, a0, a1, a2, a3, xmin);
+    }
+    const double hf = dvs_wave_sum((a0 + a1) + (a2 + a3));
+    const double mn = dvs_wave_min(xmin);
+    if (mn < 0.0) return false;
+    const double jf = hf - mean_entropy;
+    if (!(jf > st.thr_fast)) return false;
+    if (jf > st.thr_sure) return true;
+    nprecise++;
+    return precise_row(mat + uint64_t(row) * FS_BURST, sb, FS_BURST, rinv, mean_entropy, st.thr_lo, lane);
+}
+
+__device__ __forceinline__ void fs_post(SelCtl *ctl, FsSync *sync, uint32_t lane, uint64_t p) {
+    if (lane < 8) atomicMin(&sync->hint[lane].v, (unsigned long long)p);
+    if (lane == 8) atomicMin(&ctl->event_pos, (unsigned long long)p);
+}
+
+// any other row form
+template <typename T>
+__device__ __forceinline__ void fs_scan_rows(SelCtl *ctl, FsSync *sync, const SelDev &d, const T *__restrict__ mat,
+                                             const double *sb, const float *slf, uint64_t B, const ScanState &st,
+                                             double thr, double band, uint64_t first, uint64_t stride, uint32_t lane,
+                                             uint32_t &nread, uint32_t &nprecise) {
+    const unsigned long long *hintp = &sync->hint[blockIdx.x & 7u].v;
+    constexpr bool COUNTS = sizeof(T) <= 4;
+    const bool coarse = COUNTS && (B & 1023) == 0;
+    const double cband = coarse_band(B);
+    const double thr_c_lo = thr - band - cband, thr_c_hi = thr + band + cband;
+    for (uint64_t r = first; r < st.nrows; r += stride) {
+        const uint64_t p = st.cursor + r;
+        const unsigned long long ev = __hip_atomic_load(hintp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t row = d.order ? d.order[p] : uint32_t(p);
+        if (ev < p) break;                    // an earlier event ends the scan: later rows are void
+        if (row == DVS_ROW_REMOTE) continue;  // another rank scores this position
+        const uint32_t tot = d.totals[row];
+        if (tot == 0) continue;
+        const T *rp = mat + uint64_t(row) * B;
+        const double rinv = 1.0 / (double(tot) * st.dsize);
+        const double mean_entropy = (st.he_base + d.rowH[row]) / st.dsize;
+        nread++;
+        if constexpr (COUNTS) {
+            if (coarse) {
+                const float rtn = float(rinv);
+                const dvs_f2 r2 = {rtn, rtn};
+                double c0 = 0.0, c1 = 0.0;
+                for (uint64_t i0 = 0; i0 < B; i0 += 1024) {  // four chunks requested together
+                    Raw4<T> raw[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) raw[j].load(rp + i0 + uint64_t(j) * 256 + lane * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; j += 2) {
+                        const uint64_t i = i0 + uint64_t(j) * 256 + lane * 4;
+                        c0 += double(coarse4(raw[j].c, *reinterpret_cast<const float4 *>(slf + i), r2));
+                        c1 += double(coarse4(raw[j + 1].c, *reinterpret_cast<const float4 *>(slf + i + 256), r2));
+                    }
+                }
+                const double jf0 = -dvs_wave_sum(c0 + c1) - mean_entropy;
+                if (!(jf0 > thr_c_lo)) continue;  // (NaN: a negative bin, rejected as the reference does)
+                if (jf0 > thr_c_hi) {
+                    fs_post(ctl, sync, lane, p);
+                    continue;
+                }
+            }
+        }
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, xmin = 0.0;
+        if ((B & 255) == 0) {
+            for (uint64_t i0 = 0; i0 < B; i0 += 256) {
+                const uint64_t i = i0 + lane * 4;
+                double v0, v1, v2, v3;
+                load4(rp, i, v0, v1, v2, v3);
+                const double2 b01 = *reinterpret_cast<const double2 *>(sb + i);
+                const double2 b23 = *reinterpret_cast<const double2 *>(sb + i + 2);
+                fast4(b01, b23, v0, v1, v2, v3, rinv, a0, a1, a2, a3, xmin);
+            }
+        } else {
+            for (uint64_t i = lane; i < B; i += 64) {
+                const double x = fma(row_value(rp, i), rinv, sb[i]);
+                a0 += fast_neg_xlog2x(x);
+                xmin = fmin(xmin, x);
+            }
+        }
+        const double hf = dvs_wave_sum((a0 + a1) + (a2 + a3));
+        const double mn = dvs_wave_min(xmin);
+        if (mn < 0.0) continue;
+        const double jf = hf - mean_entropy;
+        if (!(jf > st.thr_fast)) continue;
+        bool hit = jf > st.thr_sure;
+        if (!hit) {
+            nprecise++;
+            hit = precise_row(rp, sb, B, rinv, mean_entropy, st.thr_lo, lane);
+        }
+        if (hit) fs_post(ctl, sync, lane, p);
+    }
+}
+
+// LDS (dynamic): [B f64: the scan vector | the state writer's new S][B f64: the scan vector in f32 | the state writer's
+// copy of the candidate][s_h cap + 1][s_s cap + 1][s_dl cap + 1][s_job 7 x jobs f64 staging]
+constexpr int FS_HOLD = 8;  // bins a thread holds in registers across the decisions (FS_THREADS x FS_HOLD = 4096 of them)
+template <typename T>
+__device__ __forceinline__ void fs_step_body(const SelDev &d, const T *__restrict__ mat, const double *__restrict__ jobres,
+                                             uint32_t K, int apply, FsSync *sync, uint32_t cap, unsigned char *fs_smem) {
+    __shared__ double s_whole[16];
+    constexpr bool COUNTS = sizeof(T) <= 4;
+    const uint64_t B = d.B;
+    const uint64_t Bp = (B + 1) & ~1ull;
+    double *sb = reinterpret_cast<double *>(fs_smem);
+    double *cf = sb + Bp;                        // (the state writer's)
+    float *slf = reinterpret_cast<float *>(cf);  // (the scanning workgroups')
+    double *s_h = cf + Bp;
+    double *s_s = s_h + cap + 1;
+    double *s_dl = s_s + cap + 1;
+    double *s_job = s_dl + cap + 1;  // [jobs][7]
+    SelCtl *ctl = d.ctl;
+    const int tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (a wave's row, its address and its chunk phase: scalars)
+    const uint32_t nscan = gridDim.x - 1;  // scanning workgroups 1 .. nscan; workgroup 0 writes the state (it is resident first)
+    const bool lead = blockIdx.x == 0;
+    if (!fs_applies(ctl, d)) return;  // (stopped, done, or a step the old kernels own: a no-op on every rank alike)
+    const unsigned int steps_done = sync->steps;  // (launches that returned above never counted: the counters stay in step)
+#ifdef DVS_FS_TRACE
+    unsigned long long *trc = reinterpret_cast<unsigned long long *>(const_cast<double *>(jobres) + uint64_t(FS_MAXJOBS) * FS_RES) + uint64_t(blockIdx.x) * 8;
+    const bool trace = apply && steps_done == 20 && tid == 0 && blockIdx.x < 1024;
+    if (trace) trc[0] = __builtin_amdgcn_s_memrealtime();
+#define FS_T(k) do { if (trace) trc[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FS_T(k) do { } while (0)
+#endif
+    // ---- the old state, read before anything is written
+    const uint32_t n = ctl->size, li = ctl->lowest;
+    const uint64_t npos = ctl->npos;
+    const double sumH = ctl->sum_entropy, thr = ctl->thr, band = ctl->band;
+    const uint32_t low_slot = d.ord[li];
+    const double dn = double(n), div = dn - 1.0;
+    const double *slot = nullptr;
+    unsigned long long p = SEL_NONE;
+    if (apply) p = fs_pick(d, &slot);
+    uint64_t cursor = ctl->cursor;
+    if (apply && p == SEL_NONE) {  // no rank found an event behind the cursor: the stream is through
+        if (lead && tid == 0) {
+            ctl->n_windows++;
+            ctl->cursor = npos;
+            ctl->status = SEL_DONE;
+        }
+        return;
+    }
+    if (p != SEL_NONE) cursor = p + 1;  // (where every outcome that scans on leaves it)
+    const double *low = d.M + uint64_t(low_slot) * B;
+    const double *cand = p != SEL_NONE ? slot + 2 : nullptr;
+    const uint64_t wpb = FS_THREADS / 64;
+    const uint64_t first = uint64_t(blockIdx.x - 1) * wpb + wave, stride = uint64_t(nscan) * wpb;
+    const uint32_t rot = uint32_t(first >> 2) & 15u;  // (with the row's index mod 4: 64 consecutive waves, 64 different phases)
+    // ---- requested now, consumed after the decisions: this wave's first row
+    const bool burst = COUNTS && B == FS_BURST;
+    Raw4<T> raw0[16];
+    uint32_t row0 = DVS_ROW_REMOTE, tot0 = 0;
+    double hrow0 = 0.0;
+    bool pre = false;
+    if (!lead) {
+        if constexpr (COUNTS) {
+            if (burst && cursor + first < npos) {
+                fs_row_issue<T>(d, mat, cursor + first, lane, rot, raw0, row0, tot0, hrow0);
+                pre = true;
+            }
+        }
+    }
+    // what the decisions below leave: 0 nothing applied (no event: scan only), 1 rejected, 2 accepted,
+    // 3 stop at the candidate test (ARB_RESOLVE), 4 stop at the argmin (ARB_FINALIZE)
+    int outcome = 0;
+    double jsd = 0.0, cand_H = 0.0, sh_new = sumH, total_new = ctl->total_jsd, band_new = band, thr_new = thr;
+    double mean_d = ctl->mean_delta, sd_d = ctl->std_delta;
+    uint32_t lowest_new = li;
+    bool ev_risky = false;
+    if (p != SEL_NONE) {
+        cand_H = slot[1];
+        // the jobs' sums: every job's seven words requested at once (a thread a job), then a member's K parts added in
+        // part order by one thread -- as a chain of dependent loads per member this phase was 10 us of every step
+        const uint32_t jobs = (n + 1) * K;
+        for (uint32_t j = tid; j < jobs; j += FS_THREADS) {
+            const double *o = jobres + uint64_t(j) * FS_RES;
+            double v[7];
+#pragma unroll
+            for (int q = 0; q < 7; q++) v[q] = o[q];
+#pragma unroll
+            for (int q = 0; q < 7; q++) s_job[uint64_t(j) * 7 + q] = v[q];
+        }
+        // the entropies of the new order's members (member r < n - 1: an old one; n - 1: the candidate)
+        for (uint32_t r = tid; r < n; r += FS_THREADS) s_dl[r] = (r + 1 < n) ? d.mH[d.ord[r < li ? r : r + 1]] : cand_H;
+        __syncthreads();
+        for (uint32_t r = tid; r <= n; r += FS_THREADS) {
+            double h = 0.0, sm = 0.0, hs = 0.0, sms = 0.0, mns = 0.0, cl = 0.0;
+            for (uint32_t q = 0; q < K; q++) {
+                const double *o = s_job + (uint64_t(r) * K + q) * 7;
+                h += o[0];
+                sm += o[1];
+                hs += o[3];
+                sms += o[4];
+                mns = fmin(mns, o[5]);
+                cl += o[6];
+            }
+            s_h[r] = h;
+            s_s[r] = sm;
+            if (r == n) {
+                s_whole[0] = hs;
+                s_whole[1] = sms;
+                s_whole[2] = mns;
+                s_whole[3] = cl;
+            }
+        }
+        __syncthreads();
+        const double hs = s_whole[0], sms = s_whole[1], mns = s_whole[2];
+        const bool clamped = s_whole[3] != 0.0;
+        const double mH_low = d.mH[low_slot];
+        jsd = (mns < 0.0) ? NAN : hs - (sumH - mH_low + cand_H) / dn;  // block_delta_jsd
+        if (sum_risky(sms, B) || fabs(jsd - thr) <= band) {
+            outcome = 3;
+        } else if (!(jsd > thr)) {  // rejected (NaN included, records.rs:91)
+            outcome = 1;
+        } else {
+            outcome = 2;
+            sh_new = sumH - mH_low;  // (resolve_body's order of additions)
+            sh_new += cand_H;
+            const double hm = clamped ? s_h[n] : hs;
+            const double sm2 = clamped ? s_s[n] : sms;
+            total_new = hm - sh_new / dn;
+            ev_risky = sum_risky(sm2, B) || !(hm == hm);
+            // finalize_body's delta_jsd of every member of the new order, argmin (strict '<' from 1e6, earliest index),
+            // runner-up and statistics, by ONE wave: lane l owns members l, l + 64, ... (the same code in every
+            // workgroup: the same bits)
+            if (wave == 0) {
+                for (uint32_t r = lane; r < n; r += 64) s_dl[r] = total_new - (s_h[r] - (sh_new - s_dl[r]) / div);  // loo_body
+                bool risky = false;
+                double best = 1e6, acc = 0.0;
+                for (uint32_t r = lane; r < n; r += 64) {
+                    if (sum_risky(s_s[r], B)) risky = true;
+                    acc += s_dl[r];
+                    if (s_dl[r] < best) best = s_dl[r];
+                }
+                const double dmin = dvs_wave_min(best);
+                double fi = 4294967295.0;
+                for (uint32_t r = lane; r < n; r += 64)
+                    if (dmin < 1e6 && s_dl[r] == dmin) fi = fmin(fi, double(r));
+                const double dfirst = dvs_wave_min(fi);
+                const uint32_t lw = (dfirst < 4294967295.0) ? uint32_t(dfirst) : 0u;
+                const double mu = dvs_wave_sum(acc) / dn;
+                double second = 1e6, tv = 0.0;
+                for (uint32_t r = lane; r < n; r += 64) {
+                    if (r != lw && s_dl[r] < second) second = s_dl[r];
+                    const double t = s_dl[r] - mu;
+                    tv += t * t;
+                }
+                second = dvs_wave_min(second);
+                const double var = dvs_wave_sum(tv);
+                const unsigned long long anyr = __ballot(risky);
+                if (lane == 0) {
+                    s_whole[8] = dmin;
+                    s_whole[9] = double(lw);
+                    s_whole[10] = second;
+                    s_whole[11] = mu;
+                    s_whole[12] = sqrt(var / div);
+                    s_whole[13] = anyr ? 1.0 : 0.0;
+                }
+            }
+            __syncthreads();
+            const double dmin = s_whole[8], dsecond = s_whole[10];
+            lowest_new = uint32_t(s_whole[9]);
+            mean_d = s_whole[11];
+            sd_d = s_whole[12];
+            const bool any_risky = s_whole[13] != 0.0;
+            band_new = sel_band(total_new + sh_new / dn, B);
+            thr_new = total_new + DVS_EPS;
+            if (any_risky || ev_risky || (n > 1 && dsecond - dmin <= band_new && dsecond < 1e6)) outcome = 4;
+        }
+    }
+    FS_T(1);
+    const bool stop = outcome == 3 || outcome == 4 || cursor >= npos;
+    // the new lowest member's row and entropy, in terms of the OLD order (the candidate, if it is the new one)
+    const uint32_t nl_old = lowest_new < li ? lowest_new : lowest_new + 1;
+    const bool nl_is_cand = !(lowest_new + 1 < n);
+    if (!lead) {
+        // ---- the scan vector of the state the decisions leave: (S' - lowest') / n, f64 and f32, in this workgroup's LDS
+        double he_base = ctl->he_base;
+        if (!stop) {
+            // (a thread's FS_HOLD bins of every operand requested together: one round trip)
+            if (outcome == 2) {
+                const double *nl = nl_is_cand ? cand : d.M + uint64_t(d.ord[nl_old]) * B;
+                const double mH_nl = nl_is_cand ? cand_H : d.mH[d.ord[nl_old]];
+                for (uint64_t i0 = tid; i0 < B; i0 += uint64_t(FS_HOLD) * FS_THREADS) {
+                    double h_s[FS_HOLD], h_lo[FS_HOLD], h_cd[FS_HOLD], h_nl[FS_HOLD];
+#pragma unroll
+                    for (int k = 0; k < FS_HOLD; k++) {
+                        const uint64_t i = i0 + uint64_t(k) * FS_THREADS;
+                        const bool in = i < B;
+                        h_s[k] = in ? d.S[i] : 0.0;
+                        h_lo[k] = in ? low[i] : 0.0;
+                        h_cd[k] = in ? cand[i] : 0.0;
+                        h_nl[k] = in ? nl[i] : 0.0;
+                    }
+#pragma unroll
+                    for (int k = 0; k < FS_HOLD; k++) {
+                        const uint64_t i = i0 + uint64_t(k) * FS_THREADS;
+                        double v = h_s[k] - h_lo[k];
+                        if (v <= DVS_EPS) v = 0.0;
+                        const double b = ((v + h_cd[k]) - h_nl[k]) / dn;
+                        if (i < B) {
+                            sb[i] = b;
+                            slf[i] = b == 0.0 ? 1e-30f : float(b);
+                        }
+                    }
+                }
+                he_base = sh_new - mH_nl;
+            } else {
+                for (uint64_t i0 = tid; i0 < B; i0 += uint64_t(FS_HOLD) * FS_THREADS) {
+                    double h_s[FS_HOLD], h_lo[FS_HOLD];
+#pragma unroll
+                    for (int k = 0; k < FS_HOLD; k++) {
+                        const uint64_t i = i0 + uint64_t(k) * FS_THREADS;
+                        const bool in = i < B;
+                        h_s[k] = in ? d.S[i] : 0.0;
+                        h_lo[k] = in ? low[i] : 0.0;
+                    }
+#pragma unroll
+                    for (int k = 0; k < FS_HOLD; k++) {
+                        const uint64_t i = i0 + uint64_t(k) * FS_THREADS;
+                        const double b = (h_s[k] - h_lo[k]) / dn;
+                        if (i < B) {
+                            sb[i] = b;
+                            slf[i] = b == 0.0 ? 1e-30f : float(b);
+                        }
+                    }
+                }
+                he_base = sumH - d.mH[low_slot];
+            }
+        }
+        __syncthreads();
+        FS_T(2);
+        // ---- arrival: this workgroup has consumed what it reads of the old state
+        if (tid == 0 && apply)
+            __hip_atomic_fetch_add(&sync->arrived[blockIdx.x & 7u].v, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (stop) return;
+        // ---- this rank's rows from the cursor to the first local event (a wave a row; the event word's copies end the scan)
+        ScanState st;
+        st.cursor = cursor;
+        st.nrows = npos - cursor;
+        st.thr_lo = thr_new - band_new;
+        st.thr_fast = st.thr_lo - FAST_BAND;
+        st.thr_sure = thr_new + band_new + FAST_BAND;
+        st.he_base = he_base;
+        st.dsize = dn;
+        uint32_t nread = 0, nprecise = 0;
+        bool done = false;
+        if constexpr (COUNTS) {
+            if (burst) {
+                // rows first, first + stride, ...: the first one's data are here already
+                const unsigned long long *hintp = &sync->hint[blockIdx.x & 7u].v;
+                const double cband = coarse_band(FS_BURST);
+                FsThr ft;
+                ft.c_lo = thr_new - band_new - cband;
+                ft.c_hi = thr_new + band_new + cband;
+                uint64_t r = first;
+                if (pre) {
+#ifdef DVS_FS_TRACE
+                    if (trace) {
+                        trc[5] = __builtin_amdgcn_s_memrealtime();
+                        asm volatile("s_waitcnt vmcnt(0)");
+                        trc[3] = __builtin_amdgcn_s_memrealtime();
+                    }
+#endif
+                    if (tot0 != 0) {  // (0: another rank's, or "No valid k-mers", records.rs:332-335)
+                        nread++;
+                        if (fs_row_score<T>(raw0, row0, tot0, hrow0, mat, sb, slf, st, ft, lane, rot, nprecise)) fs_post(ctl, sync, lane, cursor + r);
+                    }
+                    FS_T(4);
+                    r += stride;
+                }
+                for (; r < st.nrows; r += stride) {
+                    const uint64_t q = cursor + r;
+                    if (__hip_atomic_load(hintp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < q) break;  // an earlier event ends the scan
+                    Raw4<T> raw[16];
+                    uint32_t row, tot;
+                    double hrow;
+                    fs_row_issue<T>(d, mat, q, lane, rot, raw, row, tot, hrow);
+                    if (tot == 0) continue;
+                    nread++;
+                    if (fs_row_score<T>(raw, row, tot, hrow, mat, sb, slf, st, ft, lane, rot, nprecise)) fs_post(ctl, sync, lane, q);
+                }
+                done = true;
+            }
+        }
+        if (!done) fs_scan_rows<T>(ctl, sync, d, mat, sb, slf, B, st, thr_new, band_new, first, stride, lane, nread, nprecise);
+        FS_T(6);
+#ifdef DVS_FS_TRACE
+        if (trace) trc[7] = nread;
+#endif
+        // (a workgroup's count, not a wave's: two thousand additions to one word queue up for ~10 ns each at the memory side)
+        unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_whole + 14);
+        __syncthreads();
+        if (tid < 2) s_cnt[tid] = 0;
+        __syncthreads();
+        if (lane == 0 && nread) {
+            atomicAdd(&s_cnt[0], nread);
+            if (nprecise) atomicAdd(&s_cnt[1], nprecise);
+        }
+        __syncthreads();
+        if (tid == 0 && s_cnt[0]) {
+            atomicAdd(&ctl->rows_scored, (unsigned long long)s_cnt[0]);
+            if (s_cnt[1]) atomicAdd(&ctl->rows_rechecked, (unsigned long long)s_cnt[1]);
+        }
+        return;
+    }
+    // ================= the state writer (workgroup 0)
+    if (!apply) return;  // (a scan-only launch: nothing to write)
+    // ---- before the others have arrived: everything the new state needs of the old one, into LDS and registers
+    const uint32_t row = d.order ? d.order[p] : uint32_t(p);
+    const uint32_t old_lab = d.mLabel[low_slot];
+    const uint32_t log_at = ctl->n_logged;
+    // (the counters and the window's constants too: after the wait the lead thread only stores -- a load between two
+    // stores to the control block waits for a round trip each, under the scan's traffic)
+    const unsigned long long c_windows = ctl->n_windows, c_events = ctl->n_events, c_accepts = ctl->n_accepts;
+    const uint32_t c_wmin = ctl->window_min, c_wmax = ctl->window_max;
+    const double c_wscale = ctl->wscale;
+    const uint32_t nl_slot = nl_is_cand ? low_slot : d.ord[nl_old];  // (the candidate takes the lowest member's slot)
+    double he_base_new = 0.0;
+    const double *nlrow = nl_is_cand ? cand : d.M + uint64_t(nl_slot) * B;  // (an old member's row: not the one written below)
+    if (outcome == 2) he_base_new = sh_new - (nl_is_cand ? cand_H : d.mH[nl_slot]);
+    // FS_THREADS x FS_HOLD bins (k = 6 DNA: all of them) go through registers -- the new S, the candidate, finalize's scan
+    // vector -- so that what follows the wait is stores in a straight line: a wait for a load in there would wait for every
+    // store in front of it (one counter), a round trip each under the scan's traffic.  Bins beyond go through LDS.
+    const bool full = B == uint64_t(FS_HOLD) * FS_THREADS;
+    double h_sn[FS_HOLD], h_cd[FS_HOLD], h_bn[FS_HOLD];
+    if (full) {
+        double h_s[FS_HOLD], h_lo[FS_HOLD], h_nl[FS_HOLD];
+#pragma unroll
+        for (int k = 0; k < FS_HOLD; k++) {
+            const uint32_t i = uint32_t(tid) + uint32_t(k) * FS_THREADS;
+            h_s[k] = d.S[i];
+            h_lo[k] = low[i];
+            h_cd[k] = cand[i];
+            h_nl[k] = nlrow[i];
+        }
+#pragma unroll
+        for (int k = 0; k < FS_HOLD; k++) {
+            double v = h_s[k] - h_lo[k];
+            if (v <= DVS_EPS) v = 0.0;
+            h_sn[k] = v + h_cd[k];
+            h_bn[k] = (h_sn[k] - h_nl[k]) / dn;
+        }
+    } else if (outcome == 2 || outcome == 4) {
+        for (uint64_t i = tid; i < B; i += FS_THREADS) {
+            double v = d.S[i] - low[i];
+            if (v <= DVS_EPS) v = 0.0;
+            sb[i] = v + cand[i];
+            cf[i] = cand[i];
+        }
+    } else if (outcome == 3) {
+        for (uint64_t i = tid; i < B; i += FS_THREADS) cf[i] = cand[i];
+    }
+    // Vec::remove(li) + push on the member order: the new order's slots, staged in s_h's place (the sums are in s_s / s_dl)
+    uint32_t *s_ord = reinterpret_cast<uint32_t *>(s_h);
+    if (outcome == 2 || outcome == 4)
+        for (uint32_t r = tid; r < n; r += FS_THREADS) s_ord[r] = (r + 1 < n) ? d.ord[r < li ? r : r + 1] : low_slot;
+    const uint32_t win_new = sel_next_window(p + 1, n, c_wmin, c_wmax, c_wscale);  // (ctl_next_window)
+    const double cov_new = sd_d / mean_d;
+    const uint32_t log_slot = log_at % d.rowlog_cap;
+    // (every loaded word is made to BE in its register here: left to the compiler, the wait for a word first used behind the
+    // stores below lands behind them, and one counter counts loads and stores)
+    asm volatile("" ::"v"(row), "v"(old_lab), "v"(log_at), "v"(log_slot), "v"(win_new), "v"(c_windows), "v"(c_events), "v"(c_accepts),
+                 "v"(he_base_new), "v"(cov_new), "v"(nl_slot));
+    FS_T(2);
+    if (tid == 0) s_whole[7] = 1.0;
+    __syncthreads();
+    if (wave == 0) {  // (lanes 0-7 read a copy each: eight loads in flight, not eight round trips a look)
+        const unsigned long long target = (unsigned long long)nscan * (steps_done + 1u);
+        uint32_t spins = 0;
+        for (;;) {
+            const unsigned long long mine = lane < 8 ? __hip_atomic_load(&sync->arrived[lane].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            unsigned long long got = mine;
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) got += __shfl_xor(got, o, 64);
+            got = __shfl(got, 0, 64);
+            if (got >= target) break;
+            if (++spins > (1u << 22)) {
+                if (lane == 0) s_whole[7] = 0.0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    if (s_whole[7] == 0.0) {  // (never: every workgroup of the grid arrives; an error, not a hang)
+        if (tid == 0) ctl->status = SEL_ERROR;
+        return;
+    }
+    if (tid == 0) sync->steps = steps_done + 1u;
+    FS_T(3);
+    // ---- the state resolve_kernel / finalize_kernel would have left: stores only from here
+    if (outcome == 3) {
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < FS_HOLD; k++) d.cand[uint32_t(tid) + uint32_t(k) * FS_THREADS] = h_cd[k];
+        } else {
+            for (uint64_t i = tid; i < B; i += FS_THREADS) d.cand[i] = cf[i];
+        }
+        if (tid == 0) {
+            ctl->status = SEL_ARBITER;
+            ctl->arb_stage = ARB_RESOLVE;
+            ctl->arb_pos = p;
+            ctl->arb_H = cand_H;
+        }
+    } else if (outcome == 1) {
+        if (tid == 0) {
+            ctl->n_windows = c_windows + 1;
+            ctl->n_events = c_events + 1;
+            ctl->cursor = p + 1;
+            ctl->last_jsd = jsd;
+            if (p + 1 >= npos) ctl->status = SEL_DONE;
+        }
+    } else {  // accepted: replace_lowest = drop_lowest (records.rs:94-109) + push (:120-147)
+        double *mrow = d.M + uint64_t(low_slot) * B;
+        double *logrow = d.rowlog + uint64_t(log_slot) * B;  // (the stepwise mode always keeps the row log)
+        for (uint32_t r = tid; r < n; r += FS_THREADS) {  // (LDS reads: in front of the stores)
+            d.ord[r] = s_ord[r];
+            d.dtmp[r] = s_dl[r];
+            d.dsum[r] = s_s[r];
+            if (outcome == 2) d.mDelta[r] = s_dl[r];
+        }
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < FS_HOLD; k++) {
+                const uint32_t i = uint32_t(tid) + uint32_t(k) * FS_THREADS;
+                d.S[i] = h_sn[k];
+                mrow[i] = h_cd[k];
+                logrow[i] = h_cd[k];
+            }
+            if (outcome == 2) {  // finalize's scan vector (the multi-launch kernels and the persistent engine resume from it)
+#pragma unroll
+                for (int k = 0; k < FS_HOLD; k++) d.base[uint32_t(tid) + uint32_t(k) * FS_THREADS] = h_bn[k];
+            }
+        } else {
+            for (uint64_t i = tid; i < B; i += FS_THREADS) {
+                const double f = cf[i];
+                d.S[i] = sb[i];
+                mrow[i] = f;
+                logrow[i] = f;
+            }
+            if (outcome == 2)
+                for (uint64_t i = tid; i < B; i += FS_THREADS) d.base[i] = (sb[i] - nlrow[i]) / dn;
+        }
+        if (tid == 0) {
+            if (old_lab < d.nlabels) d.inset[old_lab] = 0;
+            if (row < d.nlabels) d.inset[row] = 1;  // (no caller's labels: the label of a position is its row, or REMOTE)
+            d.mH[low_slot] = cand_H;
+            d.mLabel[low_slot] = row;
+            d.mPos[low_slot] = p;
+            d.evlog_pos[log_at] = p;
+            d.evlog_kind[log_at] = 1;
+            ctl->n_logged = log_at + 1;
+            ctl->n_accepts = c_accepts + 1;
+            ctl->n_windows = c_windows + 1;
+            ctl->n_events = c_events + 1;
+            ctl->cursor = p + 1;
+            ctl->last_jsd = jsd;
+            ctl->s_is_resum = 0;
+            ctl->sum_entropy = sh_new;
+            ctl->total_jsd = total_new;
+            if (outcome == 4) {  // argmin (or a sum check) too close to call: finalize's stop
+                ctl->ev_kind = 1;
+                ctl->ev_n = n;
+                ctl->ev_risky = ev_risky ? 1 : 0;
+                ctl->status = SEL_ARBITER;
+                ctl->arb_stage = ARB_FINALIZE;
+                ctl->arb_pos = p;
+            } else {
+                ctl->lowest = lowest_new;
+                ctl->mean_delta = mean_d;
+                ctl->std_delta = sd_d;
+                ctl->cov_delta = cov_new;
+                ctl->band = band_new;
+                ctl->thr = thr_new;
+                ctl->ev_kind = 0;
+                ctl->ev_risky = 0;
+                ctl->he_base = he_base_new;
+                ctl->window = win_new;
+                if (p + 1 >= npos) ctl->status = SEL_DONE;
+            }
+        }
+    }
+    FS_T(5);
+}
+
+// The step's kernel: the body above, then -- in the workgroup that is through last -- this rank's slot of the NEXT
+// exchange (pack_event_body's: the first event the scan found, its row's entropy and frequencies), which as a launch of its
+// own cost ~6 us of kernel and ~5 us of launch boundary a step.
+template <typename T>
+__global__ __launch_bounds__(FS_THREADS, 2) void fs_step_kernel(SelDev d, const T *__restrict__ mat,
+                                                             const double *__restrict__ jobres, uint32_t K, int apply,
+                                                             FsSync *sync, uint32_t cap, double *__restrict__ slot_next) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fs_smem[];
+    __shared__ unsigned int s_last;
+    fs_step_body<T>(d, mat, jobres, K, apply, sync, cap, fs_smem);
+    if (!slot_next) return;
+    __syncthreads();  // (every wave's stores and posts are issued and counted)
+    if (threadIdx.x == 0) {
+        const unsigned long long before =
+            __hip_atomic_fetch_add(&sync->finished.v, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = before + 1 == gridDim.x;
+        if (s_last) __hip_atomic_store(&sync->finished.v, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // (every other workgroup's stores -- the state writer's status word, the finders' posts -- are behind the counter)
+    const SelCtl *ctl = d.ctl;
+    const unsigned long long p = __hip_atomic_load(&ctl->event_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t status = __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t row = DVS_ROW_REMOTE;
+    if (status == SEL_RUN && p != SEL_NONE) row = d.order ? d.order[p] : uint32_t(p);
+    if (row == DVS_ROW_REMOTE) {
+        if (threadIdx.x == 0) slot_next[0] = -1.0;  // (the rest of the slot is not read)
+        return;
+    }
+    const double tot = double(d.totals[row]);
+    const double hrow = d.rowH[row];
+    const T *rp = mat + uint64_t(row) * d.B;
+    for (uint64_t i0 = threadIdx.x; i0 < d.B; i0 += uint64_t(FS_HOLD) * FS_THREADS) {  // (a thread's bins requested together)
+        T c[FS_HOLD];
+#pragma unroll
+        for (int k = 0; k < FS_HOLD; k++) {
+            const uint64_t i = i0 + uint64_t(k) * FS_THREADS;
+            c[k] = i < d.B ? rp[i] : T(0);
+        }
+#pragma unroll
+        for (int k = 0; k < FS_HOLD; k++) {
+            const uint64_t i = i0 + uint64_t(k) * FS_THREADS;
+            if (i < d.B) slot_next[2 + i] = cand_freq(&c[k], 0, tot);
+        }
+    }
+    if (threadIdx.x == 0) {
+        slot_next[0] = double(p);  // (exact below 2^53)
+        slot_next[1] = hrow;
+    }
+}
+
 // ---- MODE_MAX while the set may grow: a BATCH of rows against the unchanged set.
 // A tentative push that is rolled back leaves the set as it was (records.rs:439-450), and so does a row that
 // is no event: the rows from the cursor up to the next push that is KEPT all face the same set.  Where
@@ -1117,6 +1930,29 @@ __global__ __launch_bounds__(LOO_THREADS) void pack_event_kernel(SelDev d, const
 // ------------------------------------------------------------------ host side
 static void sel_free(dvs_select *s) {
     if (!s) return;
+#ifdef DVS_FS_TRACE
+    if (s->d_jobres && getenv("DVS_FS_DEBUG")) {
+        std::vector<unsigned long long> t(8 * 1024);
+        (void)hipDeviceSynchronize();
+        if (hipMemcpy(t.data(), reinterpret_cast<char *>(s->d_jobres) + size_t(2048) * 8 * 8, t.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long t0 = ~0ull;
+            for (uint32_t b = 0; b < s->fs_grid; b++) if (t[b * 8]) t0 = std::min(t0, t[b * 8]);
+            auto us = [&](unsigned long long x) { return x ? (double(x) - double(t0)) / 100.0 : -1.0; };
+            double mx[8] = {0}, mn[8]; for (int k = 0; k < 8; k++) mn[k] = 1e9;
+            for (uint32_t b = 1; b < s->fs_grid; b++) for (int k = 0; k < 7; k++) if (t[b * 8 + k]) { mx[k] = std::max(mx[k], us(t[b * 8 + k])); mn[k] = std::min(mn[k], us(t[b * 8 + k])); }
+            fprintf(stderr, "[fs trace] scanning workgroups (us, min/max): start %.1f/%.1f decided %.1f/%.1f base+arrived %.1f/%.1f scan end %.1f/%.1f\n", mn[0], mx[0], mn[1], mx[1], mn[2], mx[2], mn[6], mx[6]);
+            std::vector<double> e, r1, c1, sc; double posted = -1; unsigned long long nr = 0, nrmax = 0;
+            for (uint32_t b = 1; b < s->fs_grid; b++) { if (t[b * 8 + 6]) e.push_back(us(t[b * 8 + 6])); if (t[b * 8 + 3]) r1.push_back(us(t[b * 8 + 3])); if (t[b * 8 + 4]) c1.push_back(us(t[b * 8 + 4]));
+                if (t[b * 8 + 5]) sc.push_back(us(t[b * 8 + 5])); nr += t[b * 8 + 7]; nrmax = std::max(nrmax, t[b * 8 + 7]); }
+            std::sort(e.begin(), e.end()); std::sort(r1.begin(), r1.end()); std::sort(c1.begin(), c1.end()); std::sort(sc.begin(), sc.end());
+            auto pc = [&](std::vector<double> &v, double q) { return v.empty() ? -1.0 : v[size_t(q * (v.size() - 1))]; };
+            fprintf(stderr, "[fs trace] wave 0s: scan loop entered p10/50/90/max %.1f %.1f %.1f %.1f; first row's data there %.1f %.1f %.1f %.1f; its score %.1f %.1f %.1f %.1f; scan end %.1f %.1f %.1f %.1f; first post (wave 0s only) %.1f; rows read sum %llu max %llu\n",
+                    pc(sc, .1), pc(sc, .5), pc(sc, .9), pc(sc, 1), pc(r1, .1), pc(r1, .5), pc(r1, .9), pc(r1, 1), pc(c1, .1), pc(c1, .5), pc(c1, .9), pc(c1, 1), pc(e, .1), pc(e, .5), pc(e, .9), pc(e, 1), posted, nr, nrmax);
+            const uint32_t L = 0;
+            fprintf(stderr, "[fs trace] state writer: start %.1f decided %.1f base %.1f all arrived %.1f S written %.1f done %.1f\n", us(t[L * 8]), us(t[L * 8 + 1]), us(t[L * 8 + 2]), us(t[L * 8 + 3]), us(t[L * 8 + 4]), us(t[L * 8 + 5]));
+        }
+    }
+#endif
     // Work this selection queued on the context's side streams (the head phase's sync block, the seed
     // list, set-up kernels) may still be pending on an error path; the pool only orders reuse on the
     // context's own stream, so those streams are drained before their blocks go back to it.
@@ -1133,6 +1969,8 @@ static void sel_free(dvs_select *s) {
     dvs_pinned_put(s->ctx, s->h_ctl);
     for (hipEvent_t e : s->ev_pool) dvs_event_put(s->ctx, e);
     dvs_dev_free(s->ctx, s->d_mbres);
+    dvs_dev_free(s->ctx, s->d_jobres);
+    dvs_dev_free(s->ctx, s->d_fsync);
     dvs_dev_free(s->ctx, s->psync);
     dvs_dev_free(s->ctx, s->ppart);
     dvs_dev_free(s->ctx, s->psync_head);
@@ -1731,13 +2569,31 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
     if (s->params.flags & DVS_SELECT_STEPWISE) {
         // The arbiter's row log (rows of accepted candidates may live on other ranks): the frequency row of every
         // accepted event in event-log order.  On the device it is a RING of `ring` rows that dvs_select_step_poll
-        // drains into host memory (s->h_rowlog) at every look -- a step logs at most one row, and dvs_select_step_apply
-        // refuses to run more than `ring` steps behind the last poll -- so the log itself has no cap: a stream ordered
-        // by rising divergence accepts thousands of rows where a shuffled one accepts n (1 + ln(N / n)).
-        uint64_t ring = std::min<uint64_t>(256, std::max<uint64_t>(16, (uint64_t(256) << 20) / (B * 8)));
+        // drains into host memory (s->h_rowlog) once it is half full (or the arbiter is about to read it) -- a step logs
+        // at most one row, and dvs_select_step_apply refuses to run more than ring / 2 steps behind the last poll -- so the
+        // log itself has no cap: a stream ordered by rising divergence accepts thousands of rows where a shuffled one
+        // accepts n (1 + ln(N / n)), and the common selection (fewer accepts than half the ring) never pays for a copy.
+        uint64_t ring = std::min<uint64_t>(256, std::max<uint64_t>(32, (uint64_t(256) << 20) / (B * 8)));
         if (ctx->knobs.test_rowlog_ring >= 4) ring = ctx->knobs.test_rowlog_ring;  // (tests: a ring that wraps after a few accepts)
         d.rowlog_cap = uint32_t(ring);
         SEL_ALLOC(d.rowlog, size_t(ring) * B * 8);
+        // the fast step (fs_jobs_kernel / fs_step_kernel): select_nmost_divergent without a caller's labels
+        // (the scan vector in f64 and f32, the members' sums, a staging area for the jobs' words)
+        uint32_t fsK = 1;
+        while (uint64_t(cap + 1) * fsK * 2 <= 96 && uint64_t(fsK) * 2 * FS_JOB_THREADS <= B) fsK *= 2;
+        const size_t fs_lds = ((B + 1) & ~1ull) * 16 + size_t(cap + 1) * 3 * 8 + size_t(cap + 1) * fsK * 7 * 8 + 64;
+        if (params->mode == DVS_MODE_NMOST && params->n_seed >= 2 && !labels && !ctx->knobs.no_fast_step && fs_lds <= ctx->lds_per_block &&
+            uint64_t(cap + 1) <= FS_MAXJOBS) {
+            s->fs_K = fsK;
+            s->fs_lds = fs_lds;
+            s->fs_grid = uint32_t(ctx->n_cu);  // (one workgroup a CU: 256 registers a lane hold a row in flight across the decisions; all resident at once, the state writer among them)
+            SEL_ALLOC(s->d_jobres, size_t(FS_MAXJOBS) * FS_RES * 8 + 8 * 8 * 1024);
+            SEL_HIP(hipMemsetAsync(s->d_jobres, 0, size_t(FS_MAXJOBS) * FS_RES * 8 + 8 * 8 * 1024, ctx->stream));
+            SEL_ALLOC(s->d_fsync, sizeof(FsSync));
+            SEL_HIP(hipMemsetAsync(s->d_fsync, 0, sizeof(FsSync), ctx->stream));
+            s->fast_step = true;
+            s->fs_need_scan = true;
+        }
     }
     if (order) {
         SEL_ALLOC(d.order, size_t(npos) * 4);
@@ -2105,6 +2961,33 @@ extern "C" int dvs_selftest_fast_log2(dvs_ctx *ctx, double *max_abs_err) {
 // framework's: ONE all_gather of every rank's slot per greedy step)
 extern "C" int dvs_select_step_pack(dvs_ctx *ctx, dvs_select *s, double *d_slot) {
     if (!ctx || !s || !d_slot) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (s->fast_step) {
+        // the scan ran behind the previous step's apply, and that launch's last workgroup packed this slot (fs_step_kernel):
+        // nothing to launch, unless there was no such launch (selection start, behind an arbitration) or it packed elsewhere
+        s->fs_slot = d_slot;
+        if (!s->fs_need_scan && s->fs_packed == d_slot) return DVS_OK;
+        int lrc = DVS_OK;
+        dvs_mat_dispatch(s->mat, [&](auto *mp) {
+            using T = std::remove_cv_t<std::remove_pointer_t<decltype(mp)>>;
+            if (s->fs_need_scan) {
+                lrc = dvs_raise_dyn_lds(ctx, reinterpret_cast<const void *>(fs_step_kernel<T>), s->fs_lds);
+                // (no jobs kernel before this launch: the event word's copies are cleared here -- SEL_NONE is all ones)
+                if (!lrc && hipMemsetAsync(&static_cast<FsSync *>(s->d_fsync)->hint, 0xFF, sizeof(FsLine) * 8, ctx->stream) != hipSuccess)
+                    lrc = dvs_set_error(ctx, DVS_ERR_RUNTIME, "hipMemsetAsync of the event word's copies failed");
+                if (!lrc)
+                    hipLaunchKernelGGL((fs_step_kernel<T>), dim3(s->fs_grid), dim3(FS_THREADS), s->fs_lds, ctx->stream, s->dev, mp,
+                                       s->d_jobres, s->fs_K, 0, static_cast<FsSync *>(s->d_fsync), s->cap, d_slot);
+            } else {
+                hipLaunchKernelGGL((pack_event_kernel<T>), dim3(1), dim3(LOO_THREADS), 0, ctx->stream, s->dev, mp, d_slot);
+            }
+            return 0;
+        });
+        if (lrc) return lrc;
+        s->fs_need_scan = false;
+        s->fs_packed = d_slot;
+        DVS_HIP(ctx, hipGetLastError());
+        return DVS_OK;
+    }
     dvs_mat_dispatch(s->mat, [&](auto *mp) {
         using T = std::remove_cv_t<std::remove_pointer_t<decltype(mp)>>;
         // (scan and pack as ONE launch -- the last workgroup to arrive at a counter packs -- measured
@@ -2123,11 +3006,29 @@ extern "C" int dvs_select_step_pack(dvs_ctx *ctx, dvs_select *s, double *d_slot)
 
 extern "C" int dvs_select_step_apply(dvs_ctx *ctx, dvs_select *s, const double *d_all, uint32_t world) {
     if (!ctx || !s || !d_all || !world) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
-    if (s->dev.rowlog && ++s->steps_since_poll > s->dev.rowlog_cap)
+    if (s->dev.rowlog && ++s->steps_since_poll > s->dev.rowlog_cap / 2)
         return dvs_set_error(ctx, DVS_ERR_VALUE, "dvs_select_step_poll must be called at least every %u steps (it drains the "
-                             "accepted rows' log)", s->dev.rowlog_cap);
+                             "accepted rows' log)", s->dev.rowlog_cap / 2);
     s->dev.gather_all = d_all;
     s->dev.gather_world = world;
+    if (s->fast_step) {
+        int lrc = DVS_OK;
+        dvs_mat_dispatch(s->mat, [&](auto *mp) {
+            using T = std::remove_cv_t<std::remove_pointer_t<decltype(mp)>>;
+            lrc = dvs_raise_dyn_lds(ctx, reinterpret_cast<const void *>(fs_step_kernel<T>), s->fs_lds);
+            if (lrc) return 0;
+            // (a set of ctl->size <= cap - 1 members: at most cap * K jobs; a workgroup beyond the set's jobs leaves at once)
+            hipLaunchKernelGGL(fs_jobs_kernel, dim3(s->cap * s->fs_K), dim3(FS_JOB_THREADS), 0, ctx->stream, s->dev, s->d_jobres, s->fs_K,
+                               static_cast<FsSync *>(s->d_fsync));
+            hipLaunchKernelGGL((fs_step_kernel<T>), dim3(s->fs_grid), dim3(FS_THREADS), s->fs_lds, ctx->stream, s->dev, mp,
+                               s->d_jobres, s->fs_K, 1, static_cast<FsSync *>(s->d_fsync), s->cap, s->fs_slot);
+            s->fs_packed = s->fs_slot;  // (the caller's slot of the last dvs_select_step_pack: the next one finds it packed)
+            return 0;
+        });
+        if (lrc) return lrc;
+        DVS_HIP(ctx, hipGetLastError());
+        return DVS_OK;
+    }
     dvs_mat_dispatch(s->mat, [&](auto *mp) {
         launch_iteration(ctx, s, mp, 1);
         return 0;
@@ -2142,7 +3043,10 @@ extern "C" int dvs_select_step_poll(dvs_ctx *ctx, dvs_select *s, uint32_t *statu
     if (rc) return rc;
     if (status) *status = s->h_ctl->status;
     if (cursor) *cursor = s->h_ctl->cursor;
-    if (s->dev.rowlog) {  // the rows logged since the last look: ring -> host (the stream is idle: sel_poll waited)
+    if (s->dev.rowlog) s->steps_since_poll = 0;
+    // the rows logged since the last drain: ring -> host (the stream is idle: sel_poll waited).  Put off while less than
+    // half the ring is waiting -- at most half a ring's worth of steps, a row each, can pass before the next look.
+    if (s->dev.rowlog && (s->h_ctl->n_logged - s->rowlog_have >= s->dev.rowlog_cap / 2 || s->h_ctl->status == SEL_ARBITER)) {
         const uint64_t B = s->dev.B, ring = s->dev.rowlog_cap, logged = s->h_ctl->n_logged;
         if (logged - s->rowlog_have > ring)
             return dvs_set_error(ctx, DVS_ERR_RUNTIME, "the accepted rows' log was overrun (%llu rows since the last poll, ring of %llu)",
@@ -2155,7 +3059,6 @@ extern "C" int dvs_select_step_poll(dvs_ctx *ctx, dvs_select *s, uint32_t *statu
                                    hipMemcpyDeviceToHost));
             s->rowlog_have += cnt;
         }
-        s->steps_since_poll = 0;
     }
     if (s->h_ctl->status == SEL_ARBITER) {
         // A decision inside the rounding band: every rank holds the same replicated state, the same row
@@ -2178,6 +3081,8 @@ extern "C" int dvs_select_step_poll(dvs_ctx *ctx, dvs_select *s, uint32_t *statu
             return 0;
         });
         DVS_HIP(ctx, hipGetLastError());
+        s->fs_need_scan = true;  // (the kernels just queued leave no event posted: the fast step scans before it packs)
+        s->fs_packed = nullptr;
         if (status) *status = SEL_RUN;
     }
     return DVS_OK;

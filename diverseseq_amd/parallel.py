@@ -253,7 +253,7 @@ class HipStepper:
         return status.value == 1
 
 
-def drive_exact(stepper, world: int, device, *, poll_every: int = 8, timing: dict | None = None):
+def drive_exact(stepper, world: int, device, *, poll_every: int = 16, timing: dict | None = None):
     """The greedy loop of the exact mode: `poll_every` steps are enqueued between two looks at the
     engine's status (a finished selection turns the remaining steps into no-ops).  One all_gather per
     step.  `stepper` is HipStepper on GPUs; the CPU tests drive the oracle through the same loop.
@@ -298,7 +298,7 @@ def drive_exact(stepper, world: int, device, *, poll_every: int = 8, timing: dic
 
 
 def _select_exact(ctx, matrix, order, mode, n_seed, device, world, *, max_size=0, stat=0, window=0,
-                  poll_every=8, timing=None):
+                  poll_every=16, timing=None):
     from . import _lib
 
     sel = matrix.select(mode, n_seed, max_size=max_size, stat=stat, order=order, window=window or 4096 * world,
@@ -308,7 +308,7 @@ def _select_exact(ctx, matrix, order, mode, n_seed, device, world, *, max_size=0
 
 
 def nmost_exact(ctx, matrix, order: np.ndarray, n: int, device, world: int, *, window: int = 0,
-                poll_every: int = 8, timing: dict | None = None):
+                poll_every: int = 16, timing: dict | None = None):
     """Greedy nmost over a row-sharded stream (select_nmost_divergent, src/records.rs:311-342).
     `ctx` must have been created on the torch stream that is current here
     (Context(device, stream=torch.cuda.current_stream().cuda_stream)), so the library's kernels and
@@ -321,7 +321,7 @@ def nmost_exact(ctx, matrix, order: np.ndarray, n: int, device, world: int, *, w
 
 
 def max_exact(ctx, matrix, order: np.ndarray, min_size: int, max_size: int, stat: str, device, world: int, *,
-              window: int = 0, poll_every: int = 8, timing: dict | None = None):
+              window: int = 0, poll_every: int = 16, timing: dict | None = None):
     """The same for select_max_divergent (src/records.rs:390-454): the set grows while the standard
     deviation (or coefficient of variation) of the members' delta_jsd rises; every rank takes the
     commit-or-rollback decision from the same numbers."""

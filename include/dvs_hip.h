@@ -262,8 +262,9 @@ int dvs_select_delta_jsd(dvs_ctx *ctx, const dvs_select *s, const dvs_matrix *qu
  *                          leave-one-out + finalize with that candidate, identical arithmetic on
  *                          every rank so the replicas stay bit-identical
  * dvs_select_step_poll syncs and returns the status (0 running, 1 done) / cursor; it must be called at least every 16
- * steps (it also drains the device-side ring of accepted rows into the host-side log the arbiter replays from, so
- * that log has no cap: dvs_select_step_apply returns DVS_ERR_VALUE when the ring would be overrun).  When the engine has
+ * steps (it also drains the device-side ring of accepted rows, once that is half full, into the host-side log the
+ * arbiter replays from, so that log has no cap: dvs_select_step_apply returns DVS_ERR_VALUE when more steps than half
+ * the ring holds -- 16 at least -- have passed since the last poll).  When the engine has
  * stopped at a decision inside the rounding band (src/records.rs:86-92,231,246-249) the poll runs the host
  * tie arbiter -- on every rank alike: same seeds, same row log of accepted candidates, same pending
  * candidate, hence the same verdict with no exchange -- and re-enters the step kernels; steps enqueued in

@@ -1,15 +1,16 @@
 #!/bin/bash
-# rocprofv3 kernel statistics of the exact (row-sharded, stepwise) mode at world 1.
-#   gpurun -- scripts/profile_exact.sh r02_x
+# Kernel statistics of the exact (stepwise, row-sharded) mode at world 1, old step kernels and the fast step:
+#   gpurun -- scripts/profile_exact.sh <tag>     -> gpurun_out/<tag>/{old,fast}_kernel_stats.csv
 set -u
-tag=${1:-rXX}
+tag=${1:-exact}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-db() { find $out/$1 -name '*.db' 2>/dev/null | head -1; }
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/kt_exact -- python3 $GRAFT_REPO_ROOT/bench.py --mode exact --no-cpu-baseline --no-side-runs --steps 5 --warmup 1 > $out/exact.json 2> $out/exact.err || [ -n "$(db kt_exact)" ] || { echo exact failed; tail -3 $out/exact.err; exit 1; }
-cd $GRAFT_REPO_ROOT
-python3 scripts/rocpd_summary.py stats $(db kt_exact) > $out/exact_kernel_stats.csv
-rm -rf $out/kt_exact
-tail -1 $out/exact.json | cut -c1-200
-head -12 $out/exact_kernel_stats.csv | cut -c1-160
+for v in old fast; do
+  if [ $v = old ]; then export DVS_NO_FAST_STEP=1; else unset DVS_NO_FAST_STEP; fi
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $out/prof_$v -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --mode exact --no-side-runs --no-cpu-baseline > $out/bench_$v.json 2> $out/bench_$v.err || [ -n "$(find $out/prof_$v -name '*.db' | head -1)" ] || { echo "profile failed ($v)"; tail -5 $out/bench_$v.err; exit 1; }
+  python3 $GRAFT_REPO_ROOT/scripts/rocpd_summary.py stats $(find $out/prof_$v -name '*.db' | head -1) > $out/${v}_kernel_stats.csv
+  python3 $GRAFT_REPO_ROOT/scripts/rocpd_summary.py gaps $(find $out/prof_$v -name '*.db' | head -1) > $out/${v}_kernel_gaps.csv
+  rm -rf $out/prof_$v
+  echo "== $v"; cut -c1-160 $out/${v}_kernel_stats.csv | head -12
+done

@@ -1376,8 +1376,8 @@ def test_exact_mode_row_log_has_no_cap(ctx, monkeypatch):
     """The stepwise (row-sharded) mode keeps the frequency row of every accepted event for the tie arbiter: a ring on
     the device that dvs_select_step_poll drains into a host-side log without a cap.  With a ring of eight rows
     (DVS_TEST_KNOBS=rowlog_ring_8) the degenerate stream's accepts wrap it many times before and between its
-    arbitrations: the oracle's answer, arbitrations > 0; and a driver that lets more than a ring's worth of steps pass
-    between two polls is refused, not left to a log with holes."""
+    arbitrations: the oracle's answer, arbitrations > 0; and a driver that lets more than half a ring's worth of steps pass
+    between two polls (the ring is drained once half full) is refused, not left to a log with holes."""
     import ctypes as C
 
     import torch
@@ -1404,8 +1404,8 @@ def test_exact_mode_row_log_has_no_cap(ctx, monkeypatch):
         # too many steps between two polls: refused
         sel = m.select(_lib.MODE_NMOST, n, order=order, window=256, flags=_lib.SELECT_STEPWISE)
         stepper = parallel.HipStepper(ctx, sel, m.nbins, dev)
-        with pytest.raises(ValueError, match="dvs_select_step_poll must be called at least every 8 steps"):
-            for _ in range(9):
+        with pytest.raises(ValueError, match="dvs_select_step_poll must be called at least every 4 steps"):
+            for _ in range(5):
                 stepper.apply(stepper.pack(), 1)
         sel.close()
         m.close()
