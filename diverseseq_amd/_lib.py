@@ -35,7 +35,7 @@ EXPORTS = (
     "dvs_select_destroy", "dvs_select_get_summary", "dvs_select_get_members",
     "dvs_select_gather_members",
     "dvs_select_delta_jsd", "dvs_select_step_pack",
-    "dvs_select_step_apply", "dvs_select_step_poll", "dvs_select_bench_scan", "dvs_selftest_fast_log2", "dvs_selftest_log2_acc", "dvs_selftest_log2_f32", "dvs_selftest_exact_div", "dvs_selftest_handover", "dvs_mash_sketch", "dvs_mash_distances", "dvs_euclidean_distances", "dvs_sketches_build", "dvs_sketches_destroy", "dvs_sketches_get", "dvs_sketches_dev", "dvs_sketches_dev_lens", "dvs_sketches_distances",
+    "dvs_select_step_apply", "dvs_select_step_poll", "dvs_select_step_peek", "dvs_select_bench_scan", "dvs_selftest_fast_log2", "dvs_selftest_log2_acc", "dvs_selftest_log2_f32", "dvs_selftest_exact_div", "dvs_selftest_handover", "dvs_mash_sketch", "dvs_mash_distances", "dvs_euclidean_distances", "dvs_sketches_build", "dvs_sketches_destroy", "dvs_sketches_get", "dvs_sketches_dev", "dvs_sketches_dev_lens", "dvs_sketches_distances",
     "dvs_sketches_from_device", "dvs_sketches_copy_to_device", "dvs_sketches_distances_device",
     "dvs_default_alphabet_lut", "dvs_seqbatch_from_fasta", "dvs_seqbatch_destroy", "dvs_seqbatch_info",
     "dvs_seqbatch_offsets", "dvs_seqbatch_header_positions", "dvs_seqbatch_dev_codes", "dvs_seqbatch_get_codes",
@@ -157,6 +157,7 @@ def load() -> C.CDLL:
         L.dvs_select_step_pack.argtypes = [vp, vp, vp]
         L.dvs_select_step_apply.argtypes = [vp, vp, vp, C.c_uint32]
         L.dvs_select_step_poll.argtypes = [vp, vp, u32p, u64p]
+        L.dvs_select_step_peek.argtypes = [vp, vp, C.c_uint32, u32p, C.POINTER(C.c_int)]
         L.dvs_select_bench_scan.argtypes = [vp, vp, C.c_int, f64p, u64p]
         L.dvs_selftest_fast_log2.argtypes = [vp, f64p]
         L.dvs_selftest_log2_acc.argtypes = [vp, f64p]

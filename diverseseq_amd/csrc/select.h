@@ -143,6 +143,9 @@ struct dvs_select {
     // stepwise selections, MODE_NMOST without labels: the fast step (select.hip fs_jobs_kernel / fs_step_kernel)
     bool fast_step = false;
     bool fs_need_scan = false;   // the next dvs_select_step_pack must scan first (selection start, behind an arbitration)
+    unsigned long long *h_fshist = nullptr;  // pinned: the status word of every apply launch (FS_HIST of them, dvs_select_step_peek)
+    unsigned long long fs_launches = 0;      // apply launches of the fast step so far
+    unsigned long long fs_peek_floor = 0;    // ... of them, those enqueued before the last dvs_select_step_poll
     double *fs_slot = nullptr;   // the caller's slot of the last dvs_select_step_pack (the next step's kernel packs into it)
     double *fs_packed = nullptr; // ... and the slot the last fs_step_kernel launch packed (nullptr: none)
     double *d_jobres = nullptr;  // the leave-one-out jobs' sums of the current step

@@ -771,6 +771,7 @@ __device__ void finalize_body(SelDev &d, double *scratch, int &s_go) {
 constexpr int FS_JOB_THREADS = 256;
 constexpr int FS_THREADS = 512;
 constexpr uint32_t FS_MAXJOBS = 2048;
+constexpr uint32_t FS_HIST = 512;  // words of the status history (a 4 KiB pinned block)
 constexpr uint32_t FS_RES = 8;  // doubles per job: h, sum, min; the whole set's job: + the score's h, sum, min, clamp flag
 struct FsLine {  // a polled word on a line of its own
     unsigned long long v;
@@ -788,6 +789,7 @@ struct FsSync {
     // workgroups of the running launch that are through (the last one packs this rank's slot for the next exchange, and
     // clears the word)
     FsLine finished;
+    unsigned long long launches;  // fs_step_kernel launches with apply = 1 so far (workgroup 0 counts; the word of launch L in the host's history is (L << 8) | status)
 };
 
 __device__ __forceinline__ bool fs_applies(const SelCtl *ctl, const SelDev &d) {
@@ -1446,6 +1448,7 @@ __device__ __forceinline__ void fs_step_body(const SelDev &d, const T *__restric
             d.dsum[r] = s_s[r];
             if (outcome == 2) d.mDelta[r] = s_dl[r];
         }
+        FS_T(4);
         if (full) {
 #pragma unroll
             for (int k = 0; k < FS_HOLD; k++) {
@@ -1468,6 +1471,7 @@ __device__ __forceinline__ void fs_step_body(const SelDev &d, const T *__restric
             if (outcome == 2)
                 for (uint64_t i = tid; i < B; i += FS_THREADS) d.base[i] = (sb[i] - nlrow[i]) / dn;
         }
+        FS_T(6);
         if (tid == 0) {
             if (old_lab < d.nlabels) d.inset[old_lab] = 0;
             if (row < d.nlabels) d.inset[row] = 1;  // (no caller's labels: the label of a position is its row, or REMOTE)
@@ -1516,10 +1520,19 @@ __device__ __forceinline__ void fs_step_body(const SelDev &d, const T *__restric
 template <typename T>
 __global__ __launch_bounds__(FS_THREADS, 2) void fs_step_kernel(SelDev d, const T *__restrict__ mat,
                                                              const double *__restrict__ jobres, uint32_t K, int apply,
-                                                             FsSync *sync, uint32_t cap, double *__restrict__ slot_next) {
+                                                             FsSync *sync, uint32_t cap, double *__restrict__ slot_next,
+                                                             unsigned long long *hist) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fs_smem[];
     __shared__ unsigned int s_last;
     fs_step_body<T>(d, mat, jobres, K, apply, sync, cap, fs_smem);
+    if (apply && hist && blockIdx.x == 0 && threadIdx.x == 0) {
+        // the engine's status behind this launch, where the host can see it without asking (pinned host memory, a word a
+        // launch, FS_HIST of them): dvs_select_step_peek reads the word of a launch some way back, so the driver's look at
+        // the status neither drains the queue nor differs between ranks
+        const unsigned long long L = sync->launches + 1;
+        sync->launches = L;
+        __hip_atomic_store(&hist[L % FS_HIST], (L << 8) | (unsigned long long)d.ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (!slot_next) return;
     __syncthreads();  // (every wave's stores and posts are issued and counted)
     if (threadIdx.x == 0) {
@@ -1949,7 +1962,7 @@ static void sel_free(dvs_select *s) {
             fprintf(stderr, "[fs trace] wave 0s: scan loop entered p10/50/90/max %.1f %.1f %.1f %.1f; first row's data there %.1f %.1f %.1f %.1f; its score %.1f %.1f %.1f %.1f; scan end %.1f %.1f %.1f %.1f; first post (wave 0s only) %.1f; rows read sum %llu max %llu\n",
                     pc(sc, .1), pc(sc, .5), pc(sc, .9), pc(sc, 1), pc(r1, .1), pc(r1, .5), pc(r1, .9), pc(r1, 1), pc(c1, .1), pc(c1, .5), pc(c1, .9), pc(c1, 1), pc(e, .1), pc(e, .5), pc(e, .9), pc(e, 1), posted, nr, nrmax);
             const uint32_t L = 0;
-            fprintf(stderr, "[fs trace] state writer: start %.1f decided %.1f base %.1f all arrived %.1f S written %.1f done %.1f\n", us(t[L * 8]), us(t[L * 8 + 1]), us(t[L * 8 + 2]), us(t[L * 8 + 3]), us(t[L * 8 + 4]), us(t[L * 8 + 5]));
+            fprintf(stderr, "[fs trace] state writer: start %.1f decided %.1f loaded %.1f all arrived %.1f small stores issued %.1f rows issued %.1f done %.1f\n", us(t[L * 8]), us(t[L * 8 + 1]), us(t[L * 8 + 2]), us(t[L * 8 + 3]), us(t[L * 8 + 4]), us(t[L * 8 + 6]), us(t[L * 8 + 5]));
         }
     }
 #endif
@@ -1967,6 +1980,7 @@ static void sel_free(dvs_select *s) {
     for (void *p : ptrs)
         dvs_dev_free(s->ctx, p);
     dvs_pinned_put(s->ctx, s->h_ctl);
+    if (s->h_fshist) dvs_pinned_put(s->ctx, s->h_fshist);
     for (hipEvent_t e : s->ev_pool) dvs_event_put(s->ctx, e);
     dvs_dev_free(s->ctx, s->d_mbres);
     dvs_dev_free(s->ctx, s->d_jobres);
@@ -2591,6 +2605,11 @@ extern "C" int dvs_select_run(dvs_ctx *ctx, const dvs_matrix *m, const uint32_t 
             SEL_HIP(hipMemsetAsync(s->d_jobres, 0, size_t(FS_MAXJOBS) * FS_RES * 8 + 8 * 8 * 1024, ctx->stream));
             SEL_ALLOC(s->d_fsync, sizeof(FsSync));
             SEL_HIP(hipMemsetAsync(s->d_fsync, 0, sizeof(FsSync), ctx->stream));
+            void *hh = nullptr;
+            if (dvs_pinned_get(ctx, &hh) == DVS_OK) {  // (without it the driver polls as before)
+                memset(hh, 0, 4096);
+                s->h_fshist = static_cast<unsigned long long *>(hh);
+            }
             s->fast_step = true;
             s->fs_need_scan = true;
         }
@@ -2976,7 +2995,7 @@ extern "C" int dvs_select_step_pack(dvs_ctx *ctx, dvs_select *s, double *d_slot)
                     lrc = dvs_set_error(ctx, DVS_ERR_RUNTIME, "hipMemsetAsync of the event word's copies failed");
                 if (!lrc)
                     hipLaunchKernelGGL((fs_step_kernel<T>), dim3(s->fs_grid), dim3(FS_THREADS), s->fs_lds, ctx->stream, s->dev, mp,
-                                       s->d_jobres, s->fs_K, 0, static_cast<FsSync *>(s->d_fsync), s->cap, d_slot);
+                                       s->d_jobres, s->fs_K, 0, static_cast<FsSync *>(s->d_fsync), s->cap, d_slot, (unsigned long long *)nullptr);
             } else {
                 hipLaunchKernelGGL((pack_event_kernel<T>), dim3(1), dim3(LOO_THREADS), 0, ctx->stream, s->dev, mp, d_slot);
             }
@@ -3021,7 +3040,8 @@ extern "C" int dvs_select_step_apply(dvs_ctx *ctx, dvs_select *s, const double *
             hipLaunchKernelGGL(fs_jobs_kernel, dim3(s->cap * s->fs_K), dim3(FS_JOB_THREADS), 0, ctx->stream, s->dev, s->d_jobres, s->fs_K,
                                static_cast<FsSync *>(s->d_fsync));
             hipLaunchKernelGGL((fs_step_kernel<T>), dim3(s->fs_grid), dim3(FS_THREADS), s->fs_lds, ctx->stream, s->dev, mp,
-                               s->d_jobres, s->fs_K, 1, static_cast<FsSync *>(s->d_fsync), s->cap, s->fs_slot);
+                               s->d_jobres, s->fs_K, 1, static_cast<FsSync *>(s->d_fsync), s->cap, s->fs_slot, s->h_fshist);
+            s->fs_launches++;
             s->fs_packed = s->fs_slot;  // (the caller's slot of the last dvs_select_step_pack: the next one finds it packed)
             return 0;
         });
@@ -3037,6 +3057,32 @@ extern "C" int dvs_select_step_apply(dvs_ctx *ctx, dvs_select *s, const double *
     return DVS_OK;
 }
 
+extern "C" int dvs_select_step_peek(dvs_ctx *ctx, dvs_select *s, uint32_t lag, uint32_t *status, int *must_poll) {
+    if (!ctx || !s || !status || !must_poll) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
+    if (!s->fast_step || !s->h_fshist || lag == 0 || lag >= FS_HIST / 2)
+        return dvs_set_error(ctx, DVS_ERR_UNSUPPORTED, "this selection keeps no status history (or the lag is out of range): poll");
+    *must_poll = s->dev.rowlog && s->steps_since_poll + lag > s->dev.rowlog_cap / 2;
+    *status = SEL_RUN;
+    if (s->fs_launches <= lag) return DVS_OK;  // (nothing that far back yet)
+    const unsigned long long L = s->fs_launches - lag;
+    if (L <= s->fs_peek_floor) return DVS_OK;  // (a launch the last poll has already accounted for: no-ops behind a stop among them)
+    const volatile unsigned long long *w = s->h_fshist + L % FS_HIST;
+    // (a launch that far back has long finished when the driver keeps `lag` steps queued: the loop is for the first looks)
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long long v;
+    unsigned spins = 0;
+    while (((v = *w) >> 8) != L) {
+        if ((++spins & 1023u) == 0) {
+            if (hipStreamQuery(ctx->stream) == hipSuccess && ((v = *w) >> 8) != L)
+                return dvs_set_error(ctx, DVS_ERR_RUNTIME, "the status history holds no word for launch %llu though the stream is idle", L);
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
+                return dvs_set_error(ctx, DVS_ERR_RUNTIME, "no status word for launch %llu after 30 s", L);
+        }
+    }
+    *status = uint32_t(v & 0xFFu);
+    return DVS_OK;
+}
+
 extern "C" int dvs_select_step_poll(dvs_ctx *ctx, dvs_select *s, uint32_t *status, uint64_t *cursor) {
     if (!ctx || !s) return dvs_set_error(ctx, DVS_ERR_VALUE, "null argument");
     int rc = sel_poll(ctx, s);
@@ -3044,6 +3090,7 @@ extern "C" int dvs_select_step_poll(dvs_ctx *ctx, dvs_select *s, uint32_t *statu
     if (status) *status = s->h_ctl->status;
     if (cursor) *cursor = s->h_ctl->cursor;
     if (s->dev.rowlog) s->steps_since_poll = 0;
+    s->fs_peek_floor = s->fs_launches;
     // the rows logged since the last drain: ring -> host (the stream is idle: sel_poll waited).  Put off while less than
     // half the ring is waiting -- at most half a ring's worth of steps, a row each, can pass before the next look.
     if (s->dev.rowlog && (s->h_ctl->n_logged - s->rowlog_have >= s->dev.rowlog_cap / 2 || s->h_ctl->status == SEL_ARBITER)) {

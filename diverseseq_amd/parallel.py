@@ -230,6 +230,7 @@ class HipStepper:
 
         self.ctx, self.sel, self.nbins = ctx, sel, nbins
         self.slot = torch.zeros(nbins + 2, dtype=torch.float64, device=device)
+        self._no_peek = False
 
     def pack(self):
         import ctypes as C
@@ -242,6 +243,23 @@ class HipStepper:
 
         self.ctx.check(self.ctx._L.dvs_select_step_apply(self.ctx._h, self.sel._h, C.c_void_p(all_slots.data_ptr()),
                                                          world))
+
+    def peek(self, lag: int):
+        """(status, must_poll) behind the apply launch `lag` launches back, without a sync (dvs_select_step_peek);
+        None when the selection keeps no status history -- the driver then polls"""
+        import ctypes as C
+
+        from . import _lib
+
+        if self._no_peek:
+            return None
+        status, must = C.c_uint32(), C.c_int()
+        rc = self.ctx._L.dvs_select_step_peek(self.ctx._h, self.sel._h, lag, C.byref(status), C.byref(must))
+        if rc == _lib.ERR_UNSUPPORTED:
+            self._no_peek = True
+            return None
+        self.ctx.check(rc)
+        return status.value, bool(must.value)
 
     def done(self) -> bool:
         import ctypes as C
@@ -275,8 +293,22 @@ def drive_exact(stepper, world: int, device, *, poll_every: int = 16, timing: di
                 flat_ok[0] = False
         dist.all_gather(list(dst.view(world, -1).unbind(0)), src)
     events = []
-    while not stepper.done():
-        for _ in range(poll_every):
+    peek = getattr(stepper, "peek", None)
+    first = True
+    batch = poll_every
+    while True:
+        # a look at the status every `poll_every` steps.  Where the engine keeps a status history the look is at the word
+        # of the launch `poll_every` steps back -- no sync, the queue stays full, and every rank reads the same word at the
+        # same step count (the number of all_gathers must not depend on timing) -- and the syncing poll (which also
+        # arbitrates ties and drains the accepted rows' ring) runs only when that word, or the ring, asks for it.
+        look = None if first or peek is None else peek(batch)
+        first = False
+        if look is None or look[0] != 0 or look[1]:
+            if stepper.done():
+                break
+        if look is not None:
+            batch = min(poll_every, 4)  # (a look costs nothing now, and the steps enqueued behind the end are no-ops that still launch)
+        for _ in range(batch):
             slot = stepper.pack()
             if world > 1:
                 if all_slots is None:

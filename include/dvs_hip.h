@@ -272,6 +272,14 @@ int dvs_select_delta_jsd(dvs_ctx *ctx, const dvs_select *s, const dvs_matrix *qu
 int dvs_select_step_pack(dvs_ctx *ctx, dvs_select *s, double *d_slot);
 int dvs_select_step_apply(dvs_ctx *ctx, dvs_select *s, const double *d_all, uint32_t world);
 int dvs_select_step_poll(dvs_ctx *ctx, dvs_select *s, uint32_t *status, uint64_t *cursor);
+/* A look at the status that neither syncs nor drains the queue: *status is the engine's status behind the apply launch
+ * `lag` launches before the last one enqueued (0 running while there is none that far back), read from a history the step
+ * kernel keeps in pinned host memory.  Every rank sees the same word for the same launch, so a driver that peeks at the same
+ * step counts on every rank takes the same decisions (the number of collectives must not depend on timing).  When *status
+ * is not 0, or *must_poll is set (half the accepted rows' ring would fill before the next look), call dvs_select_step_poll.
+ * DVS_ERR_UNSUPPORTED: this selection keeps no history (not the fast step): poll instead.  (No counterpart in the reference:
+ * its greedy loop is one thread, src/records.rs:311-342.) */
+int dvs_select_step_peek(dvs_ctx *ctx, dvs_select *s, uint32_t lag, uint32_t *status, int *must_poll);
 
 /* when on, every scan launch is bracketed by a pair of HIP events recorded on the
  * ctx stream (no extra host sync); they are read once the selection has finished

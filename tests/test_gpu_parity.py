@@ -1372,6 +1372,51 @@ def test_large_sets_and_other_alphabets(ctx):
     _assert_selection(mt.nmost(8), oracle.nmost(tri, 8, 3, 3))
 
 
+def test_exact_mode_status_history(ctx):
+    """dvs_select_step_peek: the engine's status behind an earlier apply launch, read from the history the step kernel keeps
+    in pinned host memory -- no sync.  Driven one step at a time with a look at the launch before the last: running until the
+    launch that found the stream's end, done from there on (steps behind the end are no-ops that still write their word) --
+    i.e. after exactly events + 2 launches; a lag longer than the launches so far reads running; a selection the fast
+    step does not drive (max_divergent) keeps no history and the driver polls.  (test_exact_row_sharded_mode drives every
+    world size through the peeking loop and checks its answer.)"""
+    import torch
+
+    from diverseseq_amd import _lib, parallel
+
+    seqs = synth_seqs(1500, 600, 123, invalid_frac=0.001, ragged=True)
+    dev = torch.device("cuda", 0)
+    m = ctx.build_matrix(seqs, 5, 4)
+    _, order = parallel.shard_order(len(seqs), 12, 0, 1, block=32)
+    sel = m.select(_lib.MODE_NMOST, 12, order=order, window=256, flags=_lib.SELECT_STEPWISE)
+    st = parallel.HipStepper(ctx, sel, m.nbins, dev)
+    assert not st.done()
+    assert st.peek(4) == (0, False)  # (nothing that far back yet)
+    steps = 0
+    while True:
+        st.apply(st.pack(), 1)
+        steps += 1
+        assert st.peek(steps + 3) == (0, False)
+        status, must = st.peek(1)
+        if status == 1:
+            break
+        assert status == 0 and steps < 2000
+        if must:  # (half the accepted rows' ring: the syncing poll drains it)
+            assert not st.done()
+    assert st.done()
+    summ = sel.summary()
+    exp = oracle.nmost(seqs, 12, 5, 4)
+    assert sel.members(with_freqs=False).positions.tolist() == exp.members()[0].tolist()
+    if summ.n_arbitrated == 0:
+        assert steps == summ.n_events + 2 and summ.n_events > 10, (steps, summ.n_events)
+    sel.close()
+    sel = m.select(_lib.MODE_MAX, 5, max_size=20, stat=_lib.STAT_STDEV, order=order, window=256, flags=_lib.SELECT_STEPWISE)
+    st = parallel.HipStepper(ctx, sel, m.nbins, dev)
+    assert not st.done()
+    assert st.peek(4) is None
+    sel.close()
+    m.close()
+
+
 def test_exact_mode_row_log_has_no_cap(ctx, monkeypatch):
     """The stepwise (row-sharded) mode keeps the frequency row of every accepted event for the tie arbiter: a ring on
     the device that dvs_select_step_poll drains into a host-side log without a cap.  With a ring of eight rows
