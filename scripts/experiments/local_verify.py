@@ -1,4 +1,4 @@
-"""The persistent engine's local decisions against the exchange's, on the north-star shape and a few others:
+"""(needs r05_local_argmin_small_sets.patch applied.)  The persistent engine's local decisions against the exchange's, on the north-star shape and a few others:
 DVS_PERSIST_VERIFY_LOCAL=1 python scripts/experiments/local_verify.py"""
 import sys
 import numpy as np
