@@ -897,7 +897,15 @@ def _degenerate_seqs():
     return seqs
 
 
-def _exact_worker(rank, world, port, q, degenerate=False):
+def _equal_length_seqs(nseq=3000, length=3000, seed=321):
+    """i.i.d. uniform sequences of ONE length (the benchmark's kind of stream): every row is as likely as any earlier one to
+    be the most divergent so far, so a greedy selection of n keeps accepting -- ~n ln(N / n) events; with ragged lengths the
+    shortest sequences (the noisiest k-mer frequencies) win early and hardly anything follows"""
+    rng = np.random.default_rng(seed)
+    return [rng.integers(0, 4, size=length, dtype=np.uint8) for _ in range(nseq)]
+
+
+def _exact_worker(rank, world, port, q, degenerate=False, k6=False):
     import os
     import sys
 
@@ -917,6 +925,9 @@ def _exact_worker(rank, world, port, q, degenerate=False):
         ctx = engine.Context(0, stream=stream.cuda_stream)
         seqs = _degenerate_seqs() if degenerate else synth_seqs(1500, 600, 123, invalid_frac=0.001, ragged=True)
         n, k = (7, 3) if degenerate else (12, 5)
+        if k6:  # rows of 4096 bins: the fast step's whole-row requests and its all-f32 tier
+            seqs = _equal_length_seqs()
+            n, k = 10, 6
         owned, order = parallel.shard_order(len(seqs), n, rank, world, block=32)
         local = seqs[:n] + [seqs[int(p)] for p in owned]
         m = ctx.build_matrix(local, k, 4)
@@ -925,7 +936,7 @@ def _exact_worker(rank, world, port, q, degenerate=False):
         mem = sel.members(with_freqs=False)
         s = sel.summary()
         out.append((mem.positions.tolist(), mem.delta_jsd.tolist(), s.total_jsd))
-        for stat in ("stdev", "cov"):  # the same rows, select_max_divergent: the set grows from n
+        for stat in (() if k6 else ("stdev", "cov")):  # the same rows, select_max_divergent: the set grows from n
             sel = parallel.max_exact(ctx, m, order, n, 40, stat, dev, world, window=256 * world, poll_every=4)
             mem = sel.members(with_freqs=False)
             s = sel.summary()
@@ -966,6 +977,39 @@ def test_exact_row_sharded_mode(world):
             assert pos == elab.tolist()
             np.testing.assert_allclose(delta, edelta, rtol=RTOL, atol=1e-13)
             np.testing.assert_allclose(total, exp.total_jsd, rtol=RTOL)
+    assert res[0][1:] == res[-1][1:]  # replicas are bit-identical
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_exact_row_sharded_mode_4096_bins(world):
+    """The same at k = 6 (rows of 4096 16-bit counts, n = 10: the north-star's shape in small): the fast step requests a
+    wave's whole row at once -- its first row before the step's decisions are known --, scores it in the all-f32 tier
+    first, and skips the positions another rank owns; ids bit-exact, delta_jsd and total_jsd within the tolerance."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_exact_worker, args=(r, world, port, q, False, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seqs = _equal_length_seqs()
+    exp, acc = oracle.nmost_concat(*__import__("diverseseq_amd.engine", fromlist=["concat"]).concat(seqs), 10, 6, 4)
+    elab, edelta, _, _ = exp.members()
+    assert acc >= 20  # (the stream held events: the steps ran)
+    for r in res:
+        pos, delta, total = r[1]
+        assert pos == elab.tolist()
+        np.testing.assert_allclose(delta, edelta, rtol=RTOL, atol=1e-13)
+        np.testing.assert_allclose(total, exp.total_jsd, rtol=RTOL)
     assert res[0][1:] == res[-1][1:]  # replicas are bit-identical
 
 
