@@ -1416,6 +1416,37 @@ def test_large_sets_and_other_alphabets(ctx):
     _assert_selection(mt.nmost(8), oracle.nmost(tri, 8, 3, 3))
 
 
+@pytest.mark.parametrize("k,ns,n,nseq,length", [(6, 4, 100, 2500, 3000), (6, 4, 2, 1500, 2000), (3, 4, 5, 3000, 300),
+                                                 (1, 4, 3, 2000, 200), (2, 20, 6, 2500, 400), (5, 4, 13, 3000, 1500),
+                                                 (4, 3, 7, 2000, 500)])
+def test_exact_mode_fast_step_shapes(ctx, k, ns, n, nseq, length):
+    """The stepwise mode's two-launch step (fs_jobs_kernel / fs_step_kernel) over the shapes its paths split on: rows of
+    4096 bins with a set of 100 (one part a job, the members' sums through LDS in several rounds) and of 2 (a
+    leave-one-out set of one member); bin counts below a workgroup's threads and not a multiple of 256 (k = 1, 3; 20 and 3
+    states): the row-form-agnostic scan and the state writer's LDS path; 1024 bins with 13 members.  ids bit-exact,
+    delta_jsd / total_jsd within the tolerance, the accept count the oracle's (records.rs:311-342)."""
+    import torch
+
+    from diverseseq_amd import engine, parallel
+
+    rng = np.random.default_rng(1000 * k + n)
+    seqs = [rng.integers(0, ns, size=length, dtype=np.uint8) for _ in range(nseq)]
+    dev = torch.device("cuda", 0)
+    m = ctx.build_matrix(seqs, k, ns)
+    _, order = parallel.shard_order(len(seqs), n, 0, 1, block=32)
+    sel = parallel.nmost_exact(ctx, m, order, n, dev, 1)
+    exp, acc = oracle.nmost_concat(*engine.concat(seqs), n, k, ns)
+    summ = sel.summary()
+    assert summ.n_accepts == acc and acc >= 1, (summ.n_accepts, acc)
+    elab, edelta, _, _ = exp.members()
+    mem = sel.members(with_freqs=False)
+    assert mem.positions.tolist() == elab.tolist()
+    np.testing.assert_allclose(mem.delta_jsd, edelta, rtol=RTOL, atol=1e-13)
+    np.testing.assert_allclose(summ.total_jsd, exp.total_jsd, rtol=RTOL)
+    sel.close()
+    m.close()
+
+
 def test_exact_mode_status_history(ctx):
     """dvs_select_step_peek: the engine's status behind an earlier apply launch, read from the history the step kernel keeps
     in pinned host memory -- no sync.  Driven one step at a time with a look at the launch before the last: running until the
