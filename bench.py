@@ -37,8 +37,8 @@ import numpy as np
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nseq", type=int, default=100_000, help="sequences per GPU")
     ap.add_argument("--length", type=int, default=5_000)
     ap.add_argument("-k", type=int, default=6)
