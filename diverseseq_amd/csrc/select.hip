@@ -1979,6 +1979,9 @@ static void sel_free(dvs_select *s) {
                     (void *)s->dev.order, (void *)s->dev.labels};
     for (void *p : ptrs)
         dvs_dev_free(s->ctx, p);
+    // (step kernels still queued -- a driver that gave up half-way -- write their status words into the pinned history:
+    // they are waited for before the block goes back to the cache, where the next selection's control mirror may take it)
+    if (s->h_fshist && s->fs_launches && s->ctx) (void)hipStreamSynchronize(s->ctx->stream);
     dvs_pinned_put(s->ctx, s->h_ctl);
     if (s->h_fshist) dvs_pinned_put(s->ctx, s->h_fshist);
     for (hipEvent_t e : s->ev_pool) dvs_event_put(s->ctx, e);
