@@ -189,3 +189,70 @@ def test_exact_mode_driver(world):
             assert got[0] == lab.tolist()
             assert got[1] == delta.tolist()
             assert got[2] == e.total_jsd
+
+
+class _HistoryStepper:
+    """the library's stepwise engine as the driver sees it, without a device: launches are applied in order, the engine
+    stops for its arbiter at given launches (the syncing poll resolves that) and is done behind launch `end`; `peek(lag)`
+    answers from the status word of the launch `lag` launches back, as dvs_select_step_peek does (launches the last poll
+    has accounted for read as running), and asks for a poll when `ring_half` steps have passed since the last one"""
+
+    def __init__(self, end, stops=(), ring_half=10**9, peek=True):
+        self.end, self.stops, self.ring_half = end, set(stops), ring_half
+        self.launches = self.polls = self.floor = self.since_poll = 0
+        self.state = 0  # 0 running, 1 done, 2 stopped for the arbiter
+        self.words = {}
+        self.progress = 0  # launches that did something
+        if not peek:
+            self.peek = None
+
+    def pack(self):
+        return None
+
+    def apply(self, slot, world):
+        self.launches += 1
+        self.since_poll += 1
+        if self.state == 0:
+            self.progress += 1
+            if self.progress in self.stops:
+                self.state = 2
+            elif self.progress >= self.end:
+                self.state = 1
+        self.words[self.launches] = self.state
+
+    def peek(self, lag):
+        must = self.since_poll + lag > self.ring_half
+        back = self.launches - lag
+        if back <= 0 or back <= self.floor:
+            return 0, must
+        return self.words[back], must
+
+    def done(self):
+        self.polls += 1
+        self.since_poll = 0
+        self.floor = self.launches
+        if self.state == 2:  # the arbiter's verdict: on with the steps
+            self.state = 0
+        return self.state == 1
+
+
+@pytest.mark.parametrize("end,stops,ring_half,poll_every", [(88, (), 10**9, 16), (5, (), 10**9, 16), (200, (17, 90, 91), 10**9, 8),
+                                                          (120, (3,), 16, 16), (1, (), 10**9, 4)])
+def test_exact_driver_looks_without_syncing(end, stops, ring_half, poll_every):
+    """parallel.drive_exact over an engine that keeps a status history (dvs_select_step_peek): it runs to the end whatever
+    the engine's stops, calls the syncing poll only at the start, for every stop, when the accepted rows' ring asks for it and
+    at the end -- not every `poll_every` steps -- and enqueues at most two short batches of no-ops behind the end.  Without a
+    history (max_divergent, the multi-launch kernels) it polls every `poll_every` steps as before."""
+    import torch
+
+    from diverseseq_amd import parallel
+
+    st = _HistoryStepper(end, stops, ring_half)
+    parallel.drive_exact(st, 1, torch.device("cpu"), poll_every=poll_every)
+    assert st.state == 1 and st.progress == end
+    ring_polls = 0 if ring_half > 10**6 else st.launches // max(1, ring_half - 4) + 1
+    assert st.polls <= 2 + len(stops) + ring_polls, (st.polls, st.launches)
+    assert st.launches <= end + len(stops) * 8 + max(poll_every, 8) + 8, (st.launches, end)
+    old = _HistoryStepper(end, stops, ring_half, peek=False)
+    parallel.drive_exact(old, 1, torch.device("cpu"), poll_every=poll_every)
+    assert old.state == 1 and old.polls >= end // poll_every
